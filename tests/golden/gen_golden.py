@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""
+Generate golden input/output vectors from the REAL reference (read-only mount at
+/root/reference).  Runs ONLY in the build container; the GPU box never has the
+reference.  Output: tests/golden/*.npz (inputs + expected outputs = data, no
+reference source).
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_golden.py
+
+``cv2`` is absent in the image; the reference imports it at module scope but
+never uses it on this path, so it is mocked.
+"""
+import os
+import sys
+from unittest.mock import MagicMock
+
+import numpy as np
+import torch
+
+sys.dont_write_bytecode = True
+sys.modules.setdefault("cv2", MagicMock())
+sys.path.insert(0, os.environ.get("LENSLESS_REFERENCE", "/root/reference"))
+
+from lensless.recon.admm import ADMM, finite_diff, finite_diff_adj, finite_diff_gram, soft_thresh  # noqa: E402
+from lensless.recon.gd import FISTA, GradientDescent, NesterovGradientDescent  # noqa: E402
+from lensless.recon.rfft_convolve import RealFFTConvolve2D  # noqa: E402
+from scipy.fftpack import next_fast_len  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def make_inputs(h, w, c, seed, d=1):
+    rng = np.random.default_rng(seed)
+    psf = rng.random((d, h, w, c)).astype(np.float32) ** 6
+    psf /= np.linalg.norm(psf.ravel())
+    data = rng.random((h, w, c)).astype(np.float32)
+    data /= data.max()
+    return psf, data
+
+
+def t(x):
+    return torch.from_numpy(np.ascontiguousarray(x))
+
+
+def admm_case(name, h, w, c, seed, iters, dtype="float32", **kw):
+    psf, data = make_inputs(h, w, c, seed)
+    init = kw.pop("initial_est", None)
+    background = kw.pop("background", None)
+    two_stage = kw.pop("two_stage", None)
+    tdt = torch.float32 if dtype == "float32" else torch.float64
+    rec = ADMM(t(psf).to(tdt), dtype=dtype, **kw)
+    if init is not None:
+        rng = np.random.default_rng(seed + 100)
+        init_arr = (rng.random([1] + [int(v) for v in rec._padded_shape]).astype(np.float32) * 0.1)
+        rec._set_initial_estimate(t(init_arr.copy()).to(tdt))
+    rec.set_data(t(data).to(tdt))
+    out = {}
+    snaps = {}
+    rec.reset()
+    bg = None
+    if background is not None:
+        bg = (np.random.default_rng(seed + 7).random((h, w, c)).astype(np.float32) * 0.1)
+        rec._data = rec._data - t(bg).to(tdt)
+        rec._data[rec._data < 0] = 0
+    for i in range(max(iters)):
+        rec._update(i)
+        if (i + 1) in iters:
+            snaps[i + 1] = {
+                "V": rec._image_est.numpy().copy(),
+                "X": rec._X.numpy().copy(),
+                "U": rec._U.numpy().copy(),
+                "W": rec._W.numpy().copy(),
+                "xi": rec._xi.numpy().copy(),
+                "eta": rec._eta.numpy().copy(),
+                "rho": rec._rho.numpy().copy(),
+                "HV": rec._forward_out.numpy().copy(),
+            }
+    final = rec._form_image()[0].numpy().copy()
+    out.update(psf=psf, data=data, final=final, iters=np.array(iters), dtype=dtype,
+               padded_shape=np.array([int(v) for v in rec._padded_shape]),
+               params=np.array([rec._mu1, rec._mu2, rec._mu3, rec._tau], dtype=np.float64))
+    if init is not None:
+        out["initial_est"] = init_arr
+    if bg is not None:
+        out["background"] = bg
+    for it, st in snaps.items():
+        for k, v in st.items():
+            out[f"it{it}_{k}"] = v
+    if two_stage:
+        # apply(n1) then apply(n2, reset=False) through the public API
+        rec2 = ADMM(t(psf).to(tdt), dtype=dtype, **kw)
+        rec2.set_data(t(data).to(tdt))
+        rec2.apply(n_iter=two_stage[0], disp_iter=None, plot=False)
+        res = rec2.apply(n_iter=two_stage[1], disp_iter=None, plot=False, reset=False)
+        out["two_stage"] = np.array(two_stage)
+        out["two_stage_final"] = res.numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, {k: getattr(v, "shape", v) for k, v in out.items() if not k.startswith("it")})
+
+
+def gd_case(name, cls, h, w, c, seed, iters, d=1, dtype="float32", **kw):
+    psf, data = make_inputs(h, w, c, seed, d=d)
+    tdt = torch.float32 if dtype == "float32" else torch.float64
+    init = kw.pop("initial_est", None)
+    rec = cls(t(psf).to(tdt), dtype=dtype, **kw)
+    out = {}
+    if init is not None:
+        rng = np.random.default_rng(seed + 100)
+        init_arr = rng.random((1, d, h, w, c)).astype(np.float32)
+        out["initial_est"] = init_arr
+        rec._set_initial_estimate(t(init_arr.copy()).to(tdt))
+    rec.set_data(t(data).to(tdt))
+    rec.reset()
+    out["alpha"] = rec._alpha.numpy().copy()
+    out["x0"] = rec._image_est.numpy().copy()
+    for i in range(max(iters)):
+        rec._update(i)
+        if (i + 1) in iters:
+            out[f"it{i + 1}_x"] = rec._image_est.numpy().copy()
+    out.update(psf=psf, data=data, final=rec._form_image()[0].numpy().copy(), iters=np.array(iters),
+               dtype=dtype)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
+
+
+def operator_case():
+    rng = np.random.default_rng(5)
+    out = {}
+    # next_fast_len table (fftpack flavour, rfft_convolve.py:112)
+    ns = np.arange(1, 700)
+    out["nfl_n"] = ns
+    out["nfl_m"] = np.array([next_fast_len(int(n)) for n in ns])
+    out["nfl_big_n"] = np.array([6079, 8111, 539, 959, 2159, 3839, 13, 27, 93, 57])
+    out["nfl_big_m"] = np.array([next_fast_len(int(n)) for n in out["nfl_big_n"]])
+    for tag, (d, h, w, c) in {"a": (1, 24, 32, 3), "b": (5, 47, 29, 3), "c": (1, 8, 14, 1)}.items():
+        psf = rng.random((d, h, w, c)).astype(np.float32)
+        x = rng.random((2, d, h, w, c)).astype(np.float32)
+        for norm in ("ortho", "backward"):
+            cv = RealFFTConvolve2D(t(psf), pad=True, norm=norm)
+            out[f"{tag}_{norm}_H"] = cv._H.numpy()
+            out[f"{tag}_{norm}_conv"] = cv.convolve(t(x)).numpy()
+            out[f"{tag}_{norm}_deconv"] = cv.deconvolve(t(x)).numpy()
+            out[f"{tag}_{norm}_pad"] = cv._pad(t(x)).numpy()
+        cvn = RealFFTConvolve2D(t(psf), pad=False, norm="backward")
+        xp = rng.random([2] + [int(v) for v in cvn._padded_shape]).astype(np.float32)
+        out[f"{tag}_xp"] = xp
+        out[f"{tag}_nopad_conv"] = cvn.convolve(t(xp)).numpy()
+        out[f"{tag}_nopad_deconv"] = cvn.deconvolve(t(xp)).numpy()
+        out[f"{tag}_psf"] = psf
+        out[f"{tag}_x"] = x
+        out[f"{tag}_padded_shape"] = np.array([int(v) for v in cv._padded_shape])
+        out[f"{tag}_start"] = np.array([int(v) for v in cv._start_idx])
+    v = rng.standard_normal((1, 1, 12, 10, 3)).astype(np.float32)
+    u = rng.standard_normal((1, 1, 12, 10, 3, 2)).astype(np.float32)
+    out["fd_in"] = v
+    out["fd_out"] = finite_diff(t(v)).numpy()
+    out["fda_in"] = u
+    out["fda_out"] = finite_diff_adj(t(u)).numpy()
+    out["st_out"] = soft_thresh(t(u), 0.3).numpy()
+    out["gram_12_10_3"] = finite_diff_gram([1, 12, 10, 3], torch.float32, True).numpy()
+    out["gram_15_27_1"] = finite_diff_gram([1, 15, 27, 1], torch.float32, True).numpy()
+    np.savez_compressed(os.path.join(OUT, "operators.npz"), **out)
+    print("wrote operators")
+
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(4)
+    operator_case()
+    # default hyper-parameters (U stays 0: tau/mu2 = 10, SURVEY section 7 caveat)
+    admm_case("admm_24x32x3_default", 24, 32, 3, seed=1, iters=[1, 2, 5, 20])
+    # parameters that exercise the non-zero soft-threshold branch
+    admm_case("admm_24x32x3_tv", 24, 32, 3, seed=2, iters=[1, 2, 5, 20, 50], tau=2e-6, mu2=1e-4,
+              two_stage=(7, 13))
+    # the reference's own test dims (test/test_convolver.py:12), non-square, odd
+    admm_case("admm_47x29x3_tv", 47, 29, 3, seed=3, iters=[1, 5, 20], tau=1e-6, mu2=5e-5)
+    # odd padded sizes 15 x 27, grayscale
+    admm_case("admm_8x14x1_tv", 8, 14, 1, seed=4, iters=[1, 5, 20], tau=1e-6, mu2=5e-5)
+    # warm start + background subtraction
+    admm_case("admm_24x32x3_init_bg", 24, 32, 3, seed=5, iters=[1, 5, 10], tau=2e-6, mu2=1e-4,
+              initial_est=True, background=True)
+    admm_case("admm_24x32x1_f64", 24, 32, 1, seed=6, iters=[5, 20], dtype="float64", tau=2e-6, mu2=1e-4)
+    # profile/admm.py settings (n_iter=5, gray, float32) at reduced size
+    admm_case("admm_profile_gray", 38, 50, 1, seed=7, iters=[5])
+
+    for nm, cls in (("gd", GradientDescent), ("nesterov", NesterovGradientDescent), ("fista", FISTA)):
+        gd_case(f"{nm}_24x32x3", cls, 24, 32, 3, seed=11, iters=[1, 2, 5, 20, 60])
+        gd_case(f"{nm}_8x14x1", cls, 8, 14, 1, seed=12, iters=[1, 5, 20])
+    gd_case("fista_47x29x3_d3", FISTA, 47, 29, 3, seed=13, iters=[1, 5, 20], d=3)
+    gd_case("fista_24x32x3_init", FISTA, 24, 32, 3, seed=14, iters=[1, 5, 20], initial_est=True)
+    gd_case("fista_24x32x3_tk", FISTA, 24, 32, 3, seed=15, iters=[5, 20], tk=2.5)
+    gd_case("nesterov_24x32x3_mu", NesterovGradientDescent, 24, 32, 3, seed=16, iters=[5, 20], mu=0.7)
+    gd_case("fista_24x32x1_f64", FISTA, 24, 32, 1, seed=17, iters=[5, 20], dtype="float64")

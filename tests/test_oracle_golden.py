@@ -1,0 +1,145 @@
+"""
+Pins the CPU oracle (oracle/lensless_oracle.py) to golden vectors that were
+produced by the real reference (tests/golden/gen_golden.py, build container only).
+
+Tolerances are relative to max|reference|.  The oracle
+runs the same torch-CPU FFT library as the reference did when the vectors were
+made, so agreement is typically exact; the stated bounds are the contract.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import lensless_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    if isinstance(a, torch.Tensor):
+        a = a.numpy()
+    a, b = np.asarray(a), np.asarray(b)
+    if np.iscomplexobj(a) or np.iscomplexobj(b):
+        a, b = a.astype(np.complex128), b.astype(np.complex128)
+    else:
+        a, b = a.astype(np.float64), b.astype(np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def test_next_fast_len_table():
+    g = np.load(os.path.join(GOLDEN, "operators.npz"))
+    for n, m in zip(g["nfl_n"], g["nfl_m"]):
+        assert orc.next_fast_len_5smooth(int(n)) == int(m)
+    for n, m in zip(g["nfl_big_n"], g["nfl_big_m"]):
+        assert orc.next_fast_len_5smooth(int(n)) == int(m)
+    # the BASELINE.json sizes
+    assert orc.Geometry(3040, 4056).hp == 6144 and orc.Geometry(3040, 4056).wp == 8192
+    assert orc.Geometry(270, 480).hp == 540 and orc.Geometry(270, 480).wp == 960
+    assert orc.Geometry(1080, 1920).hp == 2160 and orc.Geometry(1080, 1920).wp == 3840
+
+
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_operator_vectors(tag):
+    g = np.load(os.path.join(GOLDEN, "operators.npz"))
+    psf, x = g[f"{tag}_psf"], torch.from_numpy(g[f"{tag}_x"])
+    for norm in ("ortho", "backward"):
+        cv = orc.ConvolverOracle(psf, pad=True, norm=norm)
+        assert [int(v) for v in g[f"{tag}_padded_shape"][1:3]] == [cv.geom.hp, cv.geom.wp]
+        assert list(g[f"{tag}_start"]) == [cv.geom.sh, cv.geom.sw]
+        assert rel(cv.H, g[f"{tag}_{norm}_H"]) <= 2e-6
+        assert rel(cv.convolve(x), g[f"{tag}_{norm}_conv"]) <= 2e-6
+        assert rel(cv.deconvolve(x), g[f"{tag}_{norm}_deconv"]) <= 2e-6
+        assert np.array_equal(cv.geom.pad(x).numpy(), g[f"{tag}_{norm}_pad"])
+        assert torch.equal(cv.geom.crop(cv.geom.pad(x)), x)  # test/test_convolver.py:11-29
+    cvn = orc.ConvolverOracle(psf, pad=False, norm="backward")
+    xp = torch.from_numpy(g[f"{tag}_xp"])
+    assert rel(cvn.convolve(xp), g[f"{tag}_nopad_conv"]) <= 2e-6
+    assert rel(cvn.deconvolve(xp), g[f"{tag}_nopad_deconv"]) <= 2e-6
+
+
+def test_tv_helpers():
+    g = np.load(os.path.join(GOLDEN, "operators.npz"))
+    assert np.array_equal(orc.finite_diff(torch.from_numpy(g["fd_in"])).numpy(), g["fd_out"])
+    assert np.array_equal(orc.finite_diff_adj(torch.from_numpy(g["fda_in"])).numpy(), g["fda_out"])
+    assert np.array_equal(orc.soft_thresh(torch.from_numpy(g["fda_in"]), 0.3).numpy(), g["st_out"])
+    for key, shp in (("gram_12_10_3", [1, 12, 10, 3]), ("gram_15_27_1", [1, 15, 27, 1])):
+        got = orc.finite_diff_gram(shp, torch.float32).numpy()
+        assert rel(got, g[key]) <= 2e-6
+
+
+ADMM_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "admm_*.npz")))
+
+
+@pytest.mark.parametrize("name", ADMM_CASES)
+def test_admm_trajectory(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    dtype = torch.float32 if str(g["dtype"]) == "float32" else torch.float64
+    mu1, mu2, mu3, tau = [float(v) for v in g["params"]]
+    init = g["initial_est"].copy() if "initial_est" in g else None
+    o = orc.ADMMOracle(g["psf"], dtype=dtype, mu1=mu1, mu2=mu2, mu3=mu3, tau=tau, initial_est=init)
+    o.set_data(g["data"])
+    o.reset()
+    if "background" in g:
+        o.data = o.data - torch.from_numpy(g["background"]).to(dtype)
+        o.data[o.data < 0] = 0
+    iters = [int(i) for i in g["iters"]]
+    tol = {1: 1e-6, 2: 1e-6, 5: 1e-6, 10: 5e-6, 20: 1e-5, 50: 5e-5}
+    for i in range(max(iters)):
+        o.step()
+        if (i + 1) in iters:
+            for key, val in (("V", o.V), ("X", o.X), ("U", o.U), ("W", o.W), ("xi", o.xi),
+                             ("eta", o.eta), ("rho", o.rho), ("HV", o.HV)):
+                ref = g[f"it{i + 1}_{key}"]
+                if np.max(np.abs(ref)) == 0:
+                    assert float(val.abs().max()) == 0.0, (key, i + 1)
+                else:
+                    assert rel(val, ref) <= tol[i + 1], (key, i + 1, rel(val, ref))
+    assert rel(o.form_image()[0], g["final"]) <= tol[max(iters)]
+    if "two_stage" in g:
+        n1, n2 = [int(v) for v in g["two_stage"]]
+        o2 = orc.ADMMOracle(g["psf"], dtype=dtype, mu1=mu1, mu2=mu2, mu3=mu3, tau=tau)
+        o2.set_data(g["data"])
+        o2.apply(n1)
+        res = o2.apply(n2, reset=False)
+        assert rel(res, g["two_stage_final"]) <= 1e-5
+
+
+def test_admm_tv_case_exercises_nonzero_U():
+    g = np.load(os.path.join(GOLDEN, "admm_24x32x3_tv.npz"))
+    assert np.count_nonzero(g["it20_U"]) > 0.05 * g["it20_U"].size
+    g0 = np.load(os.path.join(GOLDEN, "admm_24x32x3_default.npz"))
+    assert np.count_nonzero(g0["it20_U"]) == 0  # SURVEY section 7 caveat
+
+
+GD_CASES = sorted(
+    os.path.basename(p)[:-4]
+    for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+    if os.path.basename(p).split("_")[0] in ("gd", "nesterov", "fista")
+)
+
+
+@pytest.mark.parametrize("name", GD_CASES)
+def test_gd_family_trajectory(name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    kind = {"gd": "vanilla", "nesterov": "nesterov", "fista": "fista"}[name.split("_")[0]]
+    dtype = torch.float32 if str(g["dtype"]) == "float32" else torch.float64
+    kw = {}
+    if name.endswith("_tk"):
+        kw["tk"] = 2.5
+    if name.endswith("_mu"):
+        kw["mu"] = 0.7
+    init = g["initial_est"].copy() if "initial_est" in g else None
+    o = orc.GDOracle(g["psf"], kind=kind, dtype=dtype, initial_est=init, **kw)
+    o.set_data(g["data"])
+    assert rel(o.alpha, g["alpha"]) <= 2e-6
+    assert rel(o.x, g["x0"]) <= 1e-7
+    iters = [int(i) for i in g["iters"]]
+    for i in range(max(iters)):
+        o.step()
+        if (i + 1) in iters:
+            r = rel(o.x, g[f"it{i + 1}_x"])
+            assert r <= (2e-6 if i < 5 else 5e-5), (i + 1, r)
+    assert rel(o.form_image()[0], g["final"]) <= 5e-5
