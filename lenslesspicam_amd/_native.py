@@ -1,0 +1,196 @@
+"""
+ctypes binding of the C ABI declared in ``include/lpc.h``.
+
+The product library is ``lenslesspicam_amd/_lib/liblpc.so`` (hipcc, gfx950).  There is no
+CPU fallback: if the library is missing, or no HIP device is visible, the package fails
+loudly.  ``Lib`` takes an explicit path so that the test-suite can drive *other builds of
+the same C ABI* (the SIMT-emulator build under ``tests/simt_emu``) through the identical
+binding; nothing in this package ever does that.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "_lib", "liblpc.so")
+
+ALGO_CONV, ALGO_ADMM, ALGO_GD, ALGO_NESTEROV, ALGO_FISTA = range(5)
+NORM = {"backward": 0, "ortho": 1, "forward": 2}
+K_SPATIAL, K_ROW_FWD, K_COL_A_FWD, K_COL_MID, K_COL_A_INV, K_ROW_INV, K_COUNT = range(7)
+KERNEL_NAMES = ["spatial", "row_fwd", "col_a_fwd", "col_mid", "col_a_inv", "row_inv"]
+
+
+class Config(C.Structure):
+    _fields_ = [
+        ("algo", C.c_int),
+        ("height", C.c_int),
+        ("width", C.c_int),
+        ("channels", C.c_int),
+        ("depth", C.c_int),
+        ("batch", C.c_int),
+        ("norm", C.c_int),
+        ("pad", C.c_int),
+        ("mu1", C.c_double),
+        ("mu2", C.c_double),
+        ("mu3", C.c_double),
+        ("tau", C.c_double),
+        ("lip_fact", C.c_double),
+        ("nesterov_mu", C.c_double),
+        ("nesterov_p", C.c_double),
+        ("fista_tk", C.c_double),
+    ]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+class Lib:
+    """One loaded build of the C ABI."""
+
+    def __init__(self, path: str = DEFAULT_LIB):
+        if not os.path.exists(path):
+            raise NativeError(
+                f"native library not found: {path}. Build it with "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc)."
+            )
+        self.path = path
+        self.dll = C.CDLL(path)
+        d = self.dll
+        vp, ip, fp = C.c_void_p, C.POINTER(C.c_int), C.c_void_p
+        sig = {
+            "lpc_create": [C.POINTER(Config), C.POINTER(vp)],
+            "lpc_destroy": [vp],
+            "lpc_padded_shape": [vp, ip, ip, ip, ip],
+            "lpc_set_psf": [vp, fp, vp],
+            "lpc_convolve": [vp, fp, fp, C.c_int, C.c_int, vp],
+            "lpc_set_data": [vp, fp, vp],
+            "lpc_set_initial_estimate": [vp, fp, vp],
+            "lpc_reset": [vp, vp],
+            "lpc_set_momentum": [vp, C.c_double, C.c_double, C.c_double],
+            "lpc_iterate": [vp, C.c_int, vp],
+            "lpc_form_image": [vp, fp, vp],
+            "lpc_get_state": [vp, C.c_char_p, fp, vp],
+            "lpc_profile_enable": [vp, C.c_int],
+            "lpc_profile_read": [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)],
+            "lpc_kernel_bytes": [vp, C.c_int, C.POINTER(C.c_double)],
+            "lpc_workspace_bytes": [vp, C.POINTER(C.c_size_t)],
+        }
+        for name, args in sig.items():
+            fn = getattr(d, name)
+            fn.argtypes = args
+            fn.restype = C.c_int
+        d.lpc_last_error.restype = C.c_char_p
+        d.lpc_backend.restype = C.c_char_p
+
+    # -- plumbing -------------------------------------------------------------------
+    def backend(self) -> str:
+        return self.dll.lpc_backend().decode()
+
+    def check(self, rc: int):
+        if rc != 0:
+            raise NativeError(self.dll.lpc_last_error().decode())
+
+    def create(self, **kw) -> "Handle":
+        cfg = Config()
+        defaults = dict(algo=ALGO_ADMM, height=0, width=0, channels=3, depth=1, batch=1, norm=0, pad=1,
+                        mu1=1e-6, mu2=1e-5, mu3=4e-5, tau=1e-4, lip_fact=1.8, nesterov_mu=0.9,
+                        nesterov_p=0.0, fista_tk=1.0)
+        defaults.update(kw)
+        for k, v in defaults.items():
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        self.check(self.dll.lpc_create(C.byref(cfg), C.byref(h)))
+        return Handle(self, h, cfg)
+
+
+class Handle:
+    """RAII wrapper around an ``lpc_handle``.  Pointers are raw device addresses (ints)."""
+
+    def __init__(self, lib: Lib, h, cfg: Config):
+        self.lib, self.h, self.cfg = lib, h, cfg
+        hp, wp, sh, sw = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        lib.check(lib.dll.lpc_padded_shape(h, C.byref(hp), C.byref(wp), C.byref(sh), C.byref(sw)))
+        self.Hp, self.Wp, self.sh, self.sw = hp.value, wp.value, sh.value, sw.value
+
+    def close(self):
+        if self.h is not None and self.h.value:
+            self.lib.dll.lpc_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _c(self, rc):
+        self.lib.check(rc)
+
+    def set_psf(self, ptr, stream=0):
+        self._c(self.lib.dll.lpc_set_psf(self.h, ptr, stream))
+
+    def convolve(self, x_ptr, out_ptr, n, adjoint, stream=0):
+        self._c(self.lib.dll.lpc_convolve(self.h, x_ptr, out_ptr, n, int(adjoint), stream))
+
+    def set_data(self, ptr, stream=0):
+        self._c(self.lib.dll.lpc_set_data(self.h, ptr, stream))
+
+    def set_initial_estimate(self, ptr, stream=0):
+        self._c(self.lib.dll.lpc_set_initial_estimate(self.h, ptr, stream))
+
+    def reset(self, stream=0):
+        self._c(self.lib.dll.lpc_reset(self.h, stream))
+
+    def set_momentum(self, p=0.0, mu=0.9, tk=0.0):
+        self._c(self.lib.dll.lpc_set_momentum(self.h, p, mu, tk))
+
+    def iterate(self, n, stream=0):
+        self._c(self.lib.dll.lpc_iterate(self.h, int(n), stream))
+
+    def form_image(self, out_ptr, stream=0):
+        self._c(self.lib.dll.lpc_form_image(self.h, out_ptr, stream))
+
+    def get_state(self, name, out_ptr, stream=0):
+        self._c(self.lib.dll.lpc_get_state(self.h, name.encode(), out_ptr, stream))
+
+    def profile_enable(self, on=True):
+        self._c(self.lib.dll.lpc_profile_enable(self.h, int(on)))
+
+    def profile_read(self):
+        ms = (C.c_double * K_COUNT)()
+        n = (C.c_long * K_COUNT)()
+        self._c(self.lib.dll.lpc_profile_read(self.h, ms, n))
+        return {KERNEL_NAMES[k]: (ms[k], n[k]) for k in range(K_COUNT)}
+
+    def kernel_bytes(self, kid):
+        b = C.c_double()
+        self._c(self.lib.dll.lpc_kernel_bytes(self.h, kid, C.byref(b)))
+        return b.value
+
+    def workspace_bytes(self):
+        b = C.c_size_t()
+        self._c(self.lib.dll.lpc_workspace_bytes(self.h, C.byref(b)))
+        return b.value
+
+
+_default = None
+
+
+def default_lib() -> Lib:
+    """The product library (HIP).  Imports torch first so that the HIP runtime the extension
+    binds to is the one torch already loaded (same soname), then refuses to run without a GPU."""
+    global _default
+    if _default is None:
+        import torch
+
+        if not torch.cuda.is_available():
+            raise NativeError(
+                "lenslesspicam_amd needs a HIP device (MI355X); none is visible and there is no CPU path."
+            )
+        torch.cuda.init()
+        _default = Lib(DEFAULT_LIB)
+        if not _default.backend().startswith("hip"):
+            raise NativeError(f"refusing non-HIP backend {_default.backend()!r} in the product path")
+    return _default

@@ -1,0 +1,809 @@
+// lpc_engine.cpp -- host side of the engine: plans, HBM workspace, launch sequences and the
+// C ABI declared in include/lpc.h.  Compiled as HIP for gfx950 (product) or, for the CPU
+// test-suite only, as plain C++ with -DLPC_SIMT_EMU (see lpc_rt.h).
+#include "lpc_kernels.h"
+#include "lpc_gd_kernels.h"
+#include "lpc.h"
+
+#include <algorithm>
+#include <string>
+#include <type_traits>
+#include <unordered_set>
+#include <vector>
+
+// --------------------------------------------------------------------------- errors --
+static thread_local std::string g_last_error;
+static int fail(const std::string& msg) {
+  g_last_error = msg;
+  return 1;
+}
+#define LPC_RT(expr)                                                                      \
+  do {                                                                                    \
+    lpcError_t e_ = (expr);                                                               \
+    if (e_ != lpcSuccess)                                                                 \
+      return fail(std::string(#expr) + " failed: " + rt::err_string(e_));                 \
+  } while (0)
+#define LPC_OK(expr)          \
+  do {                        \
+    int r_ = (expr);          \
+    if (r_) return r_;        \
+  } while (0)
+
+// -------------------------------------------------------------------------- helpers --
+static int next_5smooth(int n) {  // scipy.fftpack.next_fast_len (rfft_convolve.py:112)
+  int m = n < 1 ? 1 : n;
+  for (;; ++m) {
+    int r = m;
+    while (r % 2 == 0) r /= 2;
+    while (r % 3 == 0) r /= 3;
+    while (r % 5 == 0) r /= 5;
+    if (r == 1) return m;
+  }
+}
+
+template <class F>
+static int dispatch_cfg(int nelem, F&& f) {
+  using std::integral_constant;
+  if (nelem <= 1024) return f(integral_constant<int, 256>{}, integral_constant<int, 4>{});
+  if (nelem <= 2048) return f(integral_constant<int, 256>{}, integral_constant<int, 8>{});
+  if (nelem <= 4096) return f(integral_constant<int, 256>{}, integral_constant<int, 16>{});
+  if (nelem <= 8192) return f(integral_constant<int, 512>{}, integral_constant<int, 16>{});
+  if (nelem <= 16384) return f(integral_constant<int, 1024>{}, integral_constant<int, 16>{});
+  return fail("FFT tile of " + std::to_string(nelem) + " points exceeds the LDS budget (16384)");
+}
+
+struct KernelTimer {
+#if !defined(LPC_SIMT_EMU)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[LPC_K_COUNT];
+  size_t used[LPC_K_COUNT] = {0};
+#endif
+  bool on = false;
+};
+
+struct lpc_engine {
+  lpc_config cfg{};
+  PlaneGeom g{};
+  int N1 = 1, N2 = 1;  // column split Hp = N1*N2 (N1 == 1: single pass)
+  int T = 16;          // image columns per column-pass tile
+  Fft1dPlan planW{}, planA{}, planB{};
+  ColPass passA{}, passB{};
+  int P = 0, Ppsf = 0, Pdata = 0;
+  std::vector<void*> allocs;
+  size_t total_bytes = 0;
+
+  // spectral constants
+  float2* Hs = nullptr;     // [Ppsf] PSF spectrum, permuted row order, norm applied
+  float* Rdiv = nullptr;    // ADMM [Ppsf]
+  float2* phr = nullptr;    // [Hp] ifftshift phase, stored row order
+  float2* phc = nullptr;    // [Wc]
+  float2* twH = nullptr;
+  // work spectra: [2][P] planes (ADMM uses both halves, others the first)
+  float2* S = nullptr;
+  // ADMM state (padded real planes)
+  float *V[2] = {nullptr, nullptr}, *HV = nullptr, *X = nullptr, *xi = nullptr, *rho = nullptr,
+        *Rsp = nullptr, *Aarr = nullptr;
+  float *eta0[2] = {nullptr, nullptr}, *eta1[2] = {nullptr, nullptr};  // ping-pong (halo reads)
+  int vcur = 0, ecur = 0;
+  // GD family state (un-padded planes)
+  float *gx = nullptr, *gaux = nullptr;  // x and (p | xk_prev)
+  float* galpha = nullptr;               // [C] device
+  float* gx0 = nullptr;                  // [C] default start value per channel
+  float2* S2 = nullptr;                  // second spectrum buffer (row-inverse+forward is out of place)
+  double tk = 1.0, nest_mu = 0.9, nest_p = 0.0;
+  // common
+  float* Y = nullptr;         // data planes, un-padded [Pdata][H][W]
+  float* init_est = nullptr;  // planar copy of the initial estimate (or null)
+  float* psf_planar = nullptr;
+  bool has_init = false, psf_set = false, data_set = false, first = true;
+  long iters_done = 0;
+  KernelTimer timer;
+  lpcStream_t stream = nullptr;
+};
+typedef lpc_engine Engine;
+
+template <class Tp>
+static int dev_alloc(Engine* e, Tp** out, size_t count) {
+  void* p = nullptr;
+  size_t bytes = count * sizeof(Tp);
+  LPC_RT(rt::dev_malloc(&p, bytes));
+  e->allocs.push_back(p);
+  e->total_bytes += bytes;
+  *out = (Tp*)p;
+  return 0;
+}
+
+// generic launcher (+ optional event bracketing of hot-loop kernels)
+template <class K, class... A>
+static int launch_k(Engine* e, int kid, K kernel, dim3 grid, int nt, size_t smem, A... args) {
+  static thread_local std::unordered_set<const void*> big_smem_done;
+  if (smem > 48 * 1024) {
+    const void* fn = (const void*)kernel;
+    if (!big_smem_done.count(fn)) {
+      LPC_RT(rt::set_max_dyn_smem(fn, smem > 65536 ? 160 * 1024 : 65536));
+      big_smem_done.insert(fn);
+    }
+  }
+#if !defined(LPC_SIMT_EMU)
+  const bool timed = e->timer.on && kid >= 0;
+  size_t slot = 0;
+  if (timed) {
+    auto& v = e->timer.ev[kid];
+    slot = e->timer.used[kid]++;
+    if (slot >= v.size()) {
+      hipEvent_t a, b;
+      LPC_RT(hipEventCreate(&a));
+      LPC_RT(hipEventCreate(&b));
+      v.push_back({a, b});
+    }
+    LPC_RT(hipEventRecord(v[slot].first, e->stream));
+  }
+  hipLaunchKernelGGL(kernel, grid, dim3(nt), smem, e->stream, args...);
+  if (timed) LPC_RT(hipEventRecord(e->timer.ev[kid][slot].second, e->stream));
+#else
+  (void)kid;
+  lpc_emu::launch(grid, dim3(nt), smem, [=]() { kernel(args...); });
+#endif
+  LPC_RT(rt::last_error());
+  return 0;
+}
+
+static dim3 grid1d(long n, int nt, long planes = 1) {
+  long b = (n + nt - 1) / nt;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return dim3((unsigned)b, (unsigned)planes, 1);
+}
+
+// ------------------------------------------------------------------------ FFT plans --
+static int upload(Engine* e, void* dst, const void* src, size_t bytes) {
+  LPC_RT(rt::copy_h2d_async(dst, src, bytes, e->stream));
+  LPC_RT(rt::stream_sync(e->stream));
+  return 0;
+}
+
+static int make_twiddles(Engine* e, int n, float2** out) {
+  std::vector<float2> h((size_t)std::max(n, 1));
+  for (int q = 0; q < n; ++q) {
+    const double a = -2.0 * M_PI * (double)q / (double)n;
+    h[q] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  LPC_OK(dev_alloc(e, out, h.size()));
+  return upload(e, *out, h.data(), h.size() * sizeof(float2));
+}
+
+static int build_plan(Engine* e, Fft1dPlan& p, int n) {
+  p.n = n;
+  p.nst = 0;
+  int r = n, a = 0;
+  while (r % 2 == 0) { r /= 2; ++a; }
+  std::vector<int> rad;
+  for (int i = 0; i < a / 3; ++i) rad.push_back(8);
+  if (a % 3 == 2) rad.push_back(4);
+  if (a % 3 == 1) rad.push_back(2);
+  while (r % 5 == 0) { r /= 5; rad.push_back(5); }
+  while (r % 3 == 0) { r /= 3; rad.push_back(3); }
+  if (r != 1) return fail("length " + std::to_string(n) + " is not 5-smooth");
+  if ((int)rad.size() > LPC_MAX_STAGES) return fail("too many FFT stages");
+  int ns = 1;
+  for (size_t s = 0; s < rad.size(); ++s) {
+    p.radix[s] = rad[s];
+    p.ns[s] = ns;
+    p.nsdiv[s] = make_fastdiv((unsigned)ns);
+    p.twstep[s] = n / (ns * rad[s]);
+    ns *= rad[s];
+  }
+  p.nst = (int)rad.size();
+  float2* tw = nullptr;
+  LPC_OK(make_twiddles(e, n, &tw));
+  p.tw = tw;
+  return 0;
+}
+
+// choose the column split Hp = N1*N2 and the tile width
+static void choose_split(int Hp, int Wc, int* N1, int* N2, int* T) {
+  int t = 16;
+  while (t > 1 && t / 2 >= Wc) t /= 2;  // tiny images: do not waste lanes on empty columns
+  int budget = 16384;                   // points per LDS tile, worst case two arrays (ADMM middle)
+  if (const char* env = std::getenv("LPC_TILE_BUDGET")) budget = std::max(64, atoi(env));  // test knob
+  for (int tt = t; tt >= (t >= 8 ? 8 : t); tt /= 2) {
+    if ((long)Hp * 2 * tt <= budget) { *N1 = 1; *N2 = Hp; *T = tt; return; }
+    if (tt == 1) break;
+  }
+  int best1 = 1, best2 = Hp, bestcost = 1 << 30;
+  for (int d = 1; d <= Hp; ++d) {
+    if (Hp % d) continue;
+    const int n2 = d, n1 = Hp / d;
+    if ((long)n2 * 2 * t > budget / 2 || (long)n1 * t > budget / 2) continue;
+    const int cost = std::max(n1, 2 * n2);
+    if (cost < bestcost) { bestcost = cost; best1 = n1; best2 = n2; }
+  }
+  *N1 = best1; *N2 = best2; *T = t;
+}
+
+// stored row p = k1*N2 + k2  <->  frequency k = k1 + N1*k2
+static inline int stored_row_freq(const Engine* e, int p) { return (p / e->N2) + e->N1 * (p % e->N2); }
+
+static int setup_geometry(Engine* e) {
+  const lpc_config& c = e->cfg;
+  PlaneGeom& g = e->g;
+  g.H = c.height; g.W = c.width;
+  g.Hp = next_5smooth(2 * g.H - 1);
+  g.Wp = next_5smooth(2 * g.W - 1);
+  g.Wc = g.Wp / 2 + 1;
+  g.sh = (g.Hp - g.H) / 2;
+  g.sw = (g.Wp - g.W) / 2;
+  g.rpitch = (g.Wp + 3) / 4 * 4;
+  g.cpitch = (g.Wc + 15) / 16 * 16;
+  g.rplane = (long)g.Hp * g.rpitch;
+  g.cplane = (long)g.Hp * g.cpitch;
+  g.uplane = (long)g.H * g.W;
+  g.DC = c.depth * c.channels;
+  g.C = c.channels;
+  e->Ppsf = g.DC;
+  e->P = c.batch * g.DC;
+  e->Pdata = c.batch * c.channels;
+  if (g.Wp > 16384) return fail("padded width " + std::to_string(g.Wp) + " > 16384 is not supported");
+  choose_split(g.Hp, g.Wc, &e->N1, &e->N2, &e->T);
+  LPC_OK(build_plan(e, e->planW, g.Wp));
+  LPC_OK(build_plan(e, e->planB, e->N2));
+  if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
+  LPC_OK(make_twiddles(e, g.Hp, &e->twH));
+  const int ntc = (g.Wc + e->T - 1) / e->T;
+  ColPass& A = e->passA;
+  A.N = e->N1; A.G = e->N2; A.istride = e->N2; A.gstride = 1; A.T = e->T; A.ntile_c = ntc;
+  A.tw_mode = 0; A.zr0 = 0; A.zr1 = g.Hp; A.twH = e->twH;
+  A.tdiv = make_fastdiv((unsigned)e->T); A.tcdiv = make_fastdiv((unsigned)ntc);
+  ColPass& B = e->passB;
+  B = A;
+  B.N = e->N2; B.G = e->N1; B.istride = 1; B.gstride = e->N2;
+  // ifftshift phases: out[i] = in[(i + n/2) mod n]  <=>  multiply bin k by exp(+2 pi i k (n/2) / n)
+  std::vector<float2> pr((size_t)g.Hp), pc((size_t)g.Wc);
+  for (int p = 0; p < g.Hp; ++p) {
+    const long k = stored_row_freq(e, p);
+    const double a = 2.0 * M_PI * (double)((k * (g.Hp / 2)) % g.Hp) / (double)g.Hp;
+    pr[p] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  for (int k = 0; k < g.Wc; ++k) {
+    const double a = 2.0 * M_PI * (double)(((long)k * (g.Wp / 2)) % g.Wp) / (double)g.Wp;
+    pc[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+  }
+  LPC_OK(dev_alloc(e, &e->phr, pr.size()));
+  LPC_OK(dev_alloc(e, &e->phc, pc.size()));
+  LPC_OK(upload(e, e->phr, pr.data(), pr.size() * sizeof(float2)));
+  LPC_OK(upload(e, e->phc, pc.data(), pc.size() * sizeof(float2)));
+  return 0;
+}
+
+// ------------------------------------------------------------- 2-D transform pieces --
+// forward rows of ONE real source (pairs of rows) into spectrum S (planes = nplanes)
+static int rows_fwd_single(Engine* e, const RealSrc& src, float2* S, int nplanes, int kid) {
+  const PlaneGeom& g = e->g;
+  const int nblk = (src.nrows + 1) / 2;
+  return dispatch_cfg(g.Wp, [&](auto NT, auto EM) {
+    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+    return launch_k(e, kid, k_rfwd_rows<nt, em>, dim3(nblk, nplanes), nt, (size_t)g.Wp * sizeof(float2), g,
+                    e->planW, src, S);
+  });
+}
+
+// column pass A (only when split) over nplanes planes; inverse => conj twiddles before FFT
+static int cols_passA(Engine* e, float2* S, int nplanes, bool inverse, int zr0, int zr1, int kid) {
+  if (e->N1 == 1) return 0;
+  const PlaneGeom& g = e->g;
+  ColPass cp = e->passA;
+  cp.tw_mode = inverse ? 2 : 1;
+  cp.zr0 = zr0; cp.zr1 = zr1;
+  const dim3 grid(cp.G * cp.ntile_c, nplanes);
+  return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
+    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+    const size_t smem = (size_t)cp.N * cp.T * sizeof(float2);
+    if (inverse) return launch_k(e, kid, k_cols<nt, em, true>, grid, nt, smem, g, e->planA, cp, S);
+    return launch_k(e, kid, k_cols<nt, em, false>, grid, nt, smem, g, e->planA, cp, S);
+  });
+}
+
+// plain forward pass B (setup transforms only)
+static int cols_passB_fwd(Engine* e, float2* S, int nplanes, int zr0, int zr1) {
+  const PlaneGeom& g = e->g;
+  ColPass cp = e->passB;
+  cp.tw_mode = 0;
+  cp.zr0 = zr0; cp.zr1 = zr1;
+  const dim3 grid(cp.G * cp.ntile_c, nplanes);
+  return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
+    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+    return launch_k(e, -1, k_cols<nt, em, false>, grid, nt, (size_t)cp.N * cp.T * sizeof(float2), g, e->planB,
+                    cp, S);
+  });
+}
+
+// full forward 2-D transform of a real source into S (used for the PSF and the TV gram)
+static int fft2_forward_setup(Engine* e, const RealSrc& src, float2* S, int nplanes) {
+  const PlaneGeom& g = e->g;
+  const int zr0 = src.out_row0, zr1 = src.out_row0 + src.nrows;
+  LPC_OK(rows_fwd_single(e, src, S, nplanes, -1));
+  if (e->N1 > 1) {
+    LPC_OK(cols_passA(e, S, nplanes, false, zr0, zr1, -1));
+    LPC_OK(cols_passB_fwd(e, S, nplanes, 0, g.Hp));
+  } else {
+    LPC_OK(cols_passB_fwd(e, S, nplanes, zr0, zr1));
+  }
+  return 0;
+}
+
+// middle of a convolution on S (nplanes): [A] -> B fwd * H * B inv -> [A inv]
+static int conv_middle(Engine* e, float2* S, int nplanes, bool adjoint, int zr0, int zr1) {
+  const PlaneGeom& g = e->g;
+  const bool split = e->N1 > 1;
+  if (split) LPC_OK(cols_passA(e, S, nplanes, false, zr0, zr1, LPC_K_COL_A_FWD));
+  ColPass cp = e->passB;
+  cp.zr0 = split ? 0 : zr0;
+  cp.zr1 = split ? g.Hp : zr1;
+  const dim3 grid(cp.G * cp.ntile_c, nplanes);
+  const float hscale = 1.0f / ((float)g.Hp * (float)g.Wp);
+  LPC_OK(dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
+    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+    return launch_k(e, LPC_K_COL_MID, k_cols_mid_mul<nt, em>, grid, nt, (size_t)cp.N * cp.T * sizeof(float2), g,
+                    e->planB, cp, S, (const float2*)e->Hs, adjoint ? 1 : 0, hscale, e->Ppsf);
+  }));
+  if (split) LPC_OK(cols_passA(e, S, nplanes, true, 0, g.Hp, LPC_K_COL_A_INV));
+  return 0;
+}
+
+static int rows_inv_single(Engine* e, const float2* S, const RealDst& dst, int nplanes, int kid) {
+  const PlaneGeom& g = e->g;
+  const int nblk = (dst.nrows + 1) / 2;
+  return dispatch_cfg(g.Wp, [&](auto NT, auto EM) {
+    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+    return launch_k(e, kid, k_rinv_rows<nt, em>, dim3(nblk, nplanes), nt, (size_t)g.Wp * sizeof(float2), g,
+                    e->planW, S, dst);
+  });
+}
+
+static RealSrc src_unpadded(const Engine* e, const float* base) {
+  const PlaneGeom& g = e->g;
+  RealSrc s;
+  s.base = base; s.plane_stride = g.uplane; s.pitch = g.W; s.nrows = g.H; s.ncols = g.W; s.col0 = g.sw;
+  s.out_row0 = g.sh;
+  return s;
+}
+static RealSrc src_padded(const Engine* e, const float* base) {
+  const PlaneGeom& g = e->g;
+  RealSrc s;
+  s.base = base; s.plane_stride = g.rplane; s.pitch = g.rpitch; s.nrows = g.Hp; s.ncols = g.Wp; s.col0 = 0;
+  s.out_row0 = 0;
+  return s;
+}
+static RealDst dst_padded(const Engine* e, float* base) {
+  const PlaneGeom& g = e->g;
+  RealDst d;
+  d.base = base; d.plane_stride = g.rplane; d.pitch = g.rpitch; d.nrows = g.Hp; d.row0 = 0; d.col0 = 0;
+  d.ncols = g.Wp;
+  return d;
+}
+static RealDst dst_cropped(const Engine* e, float* base) {
+  const PlaneGeom& g = e->g;
+  RealDst d;
+  d.base = base; d.plane_stride = g.uplane; d.pitch = g.W; d.nrows = g.H; d.row0 = g.sh; d.col0 = g.sw;
+  d.ncols = g.W;
+  return d;
+}
+
+// planar real (padded or not) -> convolution with H / H* -> planar real, same kind
+static int convolve_planar(Engine* e, const float* xin, float* xout, int nplanes, bool padded_io, bool adjoint) {
+  const PlaneGeom& g = e->g;
+  if (padded_io) {
+    LPC_OK(rows_fwd_single(e, src_padded(e, xin), e->S, nplanes, LPC_K_ROW_FWD));
+    LPC_OK(conv_middle(e, e->S, nplanes, adjoint, 0, g.Hp));
+    LPC_OK(rows_inv_single(e, e->S, dst_padded(e, xout), nplanes, LPC_K_ROW_INV));
+  } else {
+    LPC_OK(rows_fwd_single(e, src_unpadded(e, xin), e->S, nplanes, LPC_K_ROW_FWD));
+    LPC_OK(conv_middle(e, e->S, nplanes, adjoint, g.sh, g.sh + g.H));
+    LPC_OK(rows_inv_single(e, e->S, dst_cropped(e, xout), nplanes, LPC_K_ROW_INV));
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------ layout helpers --
+static int hwc_to_planar(Engine* e, const float* src, float* dst, int nimg, int rows, int cols, int pitch,
+                         long dplane) {
+  const long n = (long)rows * cols * e->cfg.channels;
+  return launch_k(e, -1, k_hwc_to_planar<256>, grid1d(n, 256, nimg), 256, 0, src, dst, rows, cols,
+                  e->cfg.channels, pitch, dplane);
+}
+static int planar_to_hwc(Engine* e, float* src, float* dst, int nimg, int rows, int cols, int pitch, long splane,
+                         int row0, int col0, int clamp) {
+  const long n = (long)rows * cols * e->cfg.channels;
+  return launch_k(e, -1, k_planar_to_hwc<256>, grid1d(n, 256, nimg), 256, 0, src, dst, rows, cols,
+                  e->cfg.channels, pitch, splane, row0, col0, clamp, 0);
+}
+
+// ------------------------------------------------------------------------------ ADMM --
+static AdmmScalars admm_scalars(const Engine* e) {
+  const lpc_config& c = e->cfg;
+  AdmmScalars p;
+  p.mu1 = (float)c.mu1; p.mu2 = (float)c.mu2; p.mu3 = (float)c.mu3;
+  p.thr = (float)(c.tau / c.mu2);                 // admm.py:246: python-double division, then float32
+  p.m_in = 1.0f / (1.0f + p.mu1);                 // admm.py:193 in float32
+  p.m_out = 1.0f / (0.0f + p.mu1);
+  p.first = e->first ? 1 : 0;
+  return p;
+}
+
+static int admm_alloc(Engine* e) {
+  const PlaneGeom& g = e->g;
+  const size_t rp = (size_t)g.rplane * e->P;
+  float** bufs[] = {&e->V[0], &e->V[1], &e->HV, &e->X, &e->xi, &e->eta0[0], &e->eta0[1], &e->eta1[0],
+                    &e->eta1[1], &e->rho, &e->Rsp, &e->Aarr};
+  for (float** b : bufs) LPC_OK(dev_alloc(e, b, rp));
+  LPC_OK(dev_alloc(e, &e->Rdiv, (size_t)g.cplane * e->Ppsf));
+  return 0;
+}
+
+static int admm_setup_constants(Engine* e) {
+  // R_divmat = 1/(mu1 |H* H| + mu2 |PsiT Psi| + mu3)  (admm.py:186-190), with the inverse
+  // FFT's 1/(Hp*Wp) folded in.  The gram spectrum is produced by the engine's own forward
+  // transform of the 5-point stencil (admm.py:385-397) so that it lands in the permuted row order.
+  const PlaneGeom& g = e->g;
+  float* stencil = e->Rsp;  // scratch: one padded plane
+  LPC_RT(rt::memset_async(stencil, 0, (size_t)g.rplane * sizeof(float), e->stream));
+  std::vector<float> host((size_t)g.rplane, 0.f);
+  // gram[0,0]=4; [0,1]=[0,-1]=[1,0]=[-1,0]=-1 with python negative indexing (later writes win)
+  host[0] = 4.f;
+  host[(size_t)(1 % g.Wp)] = -1.f;
+  host[(size_t)(g.Wp - 1)] = -1.f;
+  host[(size_t)(1 % g.Hp) * g.rpitch] = -1.f;
+  host[(size_t)(g.Hp - 1) * g.rpitch] = -1.f;
+  LPC_OK(upload(e, stencil, host.data(), host.size() * sizeof(float)));
+  float2* Gs = e->S;  // scratch spectrum plane
+  LPC_OK(fft2_forward_setup(e, src_padded(e, stencil), Gs, 1));
+  const float scale = 1.0f / ((float)g.Hp * (float)g.Wp);
+  LPC_OK(launch_k(e, -1, k_admm_rdiv<256>, grid1d((long)g.Hp * g.cpitch, 256, e->Ppsf), 256, 0, g,
+                  (const float2*)e->Hs, (const float2*)Gs, e->Rdiv, (float)e->cfg.mu1, (float)e->cfg.mu2,
+                  (float)e->cfg.mu3, scale));
+  return 0;
+}
+
+static int admm_reset(Engine* e) {
+  const PlaneGeom& g = e->g;
+  const size_t rb = (size_t)g.rplane * e->P * sizeof(float);
+  float* zero[] = {e->V[1], e->X, e->xi, e->eta0[0], e->eta1[0], e->rho, e->HV};
+  for (float* z : zero) LPC_RT(rt::memset_async(z, 0, rb, e->stream));
+  e->vcur = 0;
+  e->ecur = 0;
+  if (e->has_init) {
+    LPC_RT(rt::copy_d2d_async(e->V[0], e->init_est, rb, e->stream));
+    // admm.py:172-176: forward_out = convolve(V0)
+    LPC_OK(convolve_planar(e, e->V[0], e->HV, e->P, true, false));
+  } else {
+    LPC_RT(rt::memset_async(e->V[0], 0, rb, e->stream));
+  }
+  e->first = true;
+  e->iters_done = 0;
+  return 0;
+}
+
+static int admm_iterate(Engine* e, int n_iter) {
+  const PlaneGeom& g = e->g;
+  constexpr int TH = 16, TW = 64, NT = 256;
+  const size_t k1_smem = (size_t)(2 * (TH + 2) * (TW + 2) + (TH + 1) * TW + TH * (TW + 1)) * sizeof(float);
+  const dim3 k1_grid((g.Wp + TW - 1) / TW, (g.Hp + TH - 1) / TH, e->P);
+  float2* SA = e->S;
+  float2* SB = e->S + (size_t)e->P * g.cplane;
+  const bool split = e->N1 > 1;
+  for (int it = 0; it < n_iter; ++it) {
+    float* Vc = e->V[e->vcur];
+    float* Vo = e->V[e->vcur ^ 1];
+    AdmmScalars sc = admm_scalars(e);
+    LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial<TH, TW, NT>, k1_grid, NT, k1_smem, g, sc, (const float*)Vc,
+                    (const float*)Vo, (const float*)e->HV, e->X, e->xi, (const float*)e->eta0[e->ecur],
+                    (const float*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
+                    (const float*)e->Y, e->Rsp, e->Aarr));
+    e->ecur ^= 1;
+    e->first = false;
+    LPC_OK(dispatch_cfg(g.Wp, [&](auto NTc, auto EM) {
+      constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
+      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<nt, em>, dim3(g.Hp, e->P), nt, (size_t)g.Wp * sizeof(float2),
+                      g, e->planW, (const float*)e->Rsp, (const float*)e->Aarr, SA, SB);
+    }));
+    if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, false, 0, g.Hp, LPC_K_COL_A_FWD));
+    {
+      ColPass cp = e->passB;
+      const dim3 grid(cp.G * cp.ntile_c, e->P);
+      const FastDiv t2 = make_fastdiv((unsigned)(2 * cp.T));
+      LPC_OK(dispatch_cfg(cp.N * cp.T * 2, [&](auto NTc, auto EM) {
+        constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
+        return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<nt, em>, grid, nt,
+                        (size_t)cp.N * cp.T * 2 * sizeof(float2), g, e->planB, cp, SA, SB, (const float2*)e->Hs,
+                        (const float*)e->Rdiv, (const float2*)e->phr, (const float2*)e->phc, t2);
+      }));
+    }
+    if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, true, 0, g.Hp, LPC_K_COL_A_INV));
+    LPC_OK(dispatch_cfg(g.Wp, [&](auto NTc, auto EM) {
+      constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
+      return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em>, dim3(g.Hp, e->P), nt, (size_t)g.Wp * sizeof(float2),
+                      g, e->planW, (const float2*)SA, (const float2*)SB, Vo, e->HV);
+    }));
+    e->vcur ^= 1;  // Vo now holds the new image estimate
+    ++e->iters_done;
+  }
+  return 0;
+}
+
+#include "lpc_gd_engine.inc"
+
+// =============================================================================== C ABI ==
+extern "C" {
+
+const char* lpc_last_error(void) { return g_last_error.c_str(); }
+const char* lpc_backend(void) { return rt::backend_name(); }
+
+int lpc_create(const lpc_config* cfg, lpc_handle* out) {
+  if (!cfg || !out) return fail("lpc_create: null argument");
+  *out = nullptr;
+  if (cfg->height < 1 || cfg->width < 1) return fail("lpc_create: bad spatial size");
+  if (cfg->channels != 1 && cfg->channels != 3) return fail("PSF must either be rgb (3) or grayscale (1)");
+  if (cfg->depth < 1 || cfg->batch < 1) return fail("lpc_create: depth and batch must be >= 1");
+  if (cfg->algo < LPC_ALGO_CONV || cfg->algo > LPC_ALGO_FISTA) return fail("lpc_create: unknown algo");
+  if (cfg->norm < 0 || cfg->norm > 2) return fail("lpc_create: unknown norm");
+  int ndev = 0;
+  if (rt::device_count(&ndev) != lpcSuccess || ndev < 1)
+    return fail("no HIP device: the engine has no CPU path");
+  Engine* e = new Engine();
+  e->cfg = *cfg;
+  e->tk = cfg->fista_tk; e->nest_mu = cfg->nesterov_mu; e->nest_p = cfg->nesterov_p;
+  int rc = setup_geometry(e);
+  const PlaneGeom& g = e->g;
+  if (!rc) rc = dev_alloc(e, &e->Hs, (size_t)g.cplane * e->Ppsf);
+  if (!rc) rc = dev_alloc(e, &e->psf_planar, (size_t)g.uplane * e->Ppsf);
+  const int nspec = cfg->algo == LPC_ALGO_ADMM ? 2 : 1;
+  if (!rc) rc = dev_alloc(e, &e->S, (size_t)g.cplane * e->P * nspec);
+  if (!rc && cfg->algo != LPC_ALGO_CONV) rc = dev_alloc(e, &e->Y, (size_t)g.uplane * e->Pdata);
+  if (!rc && cfg->algo == LPC_ALGO_CONV) {  // staging planes for the channels-last <-> planar hop
+    const size_t n = (size_t)(cfg->pad ? g.uplane : g.rplane) * e->P;
+    rc = dev_alloc(e, &e->gaux, n);
+    if (!rc) rc = dev_alloc(e, &e->gx, n);
+  }
+  if (!rc && cfg->algo == LPC_ALGO_ADMM) rc = admm_alloc(e);
+  if (!rc && cfg->algo >= LPC_ALGO_GD) rc = gd_alloc(e);
+  if (rc) {
+    lpc_destroy(e);
+    return rc;
+  }
+  *out = e;
+  return 0;
+}
+
+int lpc_destroy(lpc_handle e) {
+  if (!e) return 0;
+  rt::stream_sync(e->stream);
+  for (void* p : e->allocs) rt::dev_free(p);
+#if !defined(LPC_SIMT_EMU)
+  for (auto& v : e->timer.ev)
+    for (auto& pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+#endif
+  delete e;
+  return 0;
+}
+
+int lpc_padded_shape(lpc_handle e, int* Hp, int* Wp, int* sh, int* sw) {
+  if (!e) return fail("null handle");
+  if (Hp) *Hp = e->g.Hp;
+  if (Wp) *Wp = e->g.Wp;
+  if (sh) *sh = e->g.sh;
+  if (sw) *sw = e->g.sw;
+  return 0;
+}
+
+int lpc_workspace_bytes(lpc_handle e, size_t* bytes) {
+  if (!e || !bytes) return fail("null argument");
+  *bytes = e->total_bytes;
+  return 0;
+}
+
+int lpc_set_psf(lpc_handle e, const float* dev_psf, void* stream) {
+  if (!e || !dev_psf) return fail("lpc_set_psf: null argument");
+  e->stream = (lpcStream_t)stream;
+  const PlaneGeom& g = e->g;
+  // (D,H,W,C) -> planar [D*C][H][W]
+  LPC_OK(hwc_to_planar(e, dev_psf, e->psf_planar, e->cfg.depth, g.H, g.W, g.W, g.uplane));
+  LPC_OK(fft2_forward_setup(e, src_unpadded(e, e->psf_planar), e->Hs, e->Ppsf));
+  double sc = 1.0;  // rfft_convolve.py:121 norm= of the PSF spectrum
+  if (e->cfg.norm == LPC_NORM_ORTHO) sc = 1.0 / std::sqrt((double)g.Hp * (double)g.Wp);
+  if (e->cfg.norm == LPC_NORM_FORWARD) sc = 1.0 / ((double)g.Hp * (double)g.Wp);
+  if (sc != 1.0) {
+    const long n = (long)g.cplane * e->Ppsf;
+    LPC_OK(launch_k(e, -1, k_scale_complex<256>, grid1d(n, 256), 256, 0, e->Hs, n, (float)sc));
+  }
+  e->psf_set = true;
+  if (e->cfg.algo == LPC_ALGO_ADMM) LPC_OK(admm_setup_constants(e));
+  if (e->cfg.algo >= LPC_ALGO_GD) LPC_OK(gd_setup_constants(e));
+  if (e->cfg.algo != LPC_ALGO_CONV) return lpc_reset(e, stream);
+  return 0;
+}
+
+int lpc_convolve(lpc_handle e, const float* dev_x, float* dev_out, int n, int adjoint, void* stream) {
+  if (!e || !dev_x || !dev_out) return fail("lpc_convolve: null argument");
+  if (!e->psf_set) return fail("lpc_convolve: PSF not set");
+  if (n < 1 || n > e->cfg.batch) return fail("lpc_convolve: n exceeds the configured batch");
+  if (e->cfg.algo != LPC_ALGO_CONV) return fail("lpc_convolve: handle was not created with LPC_ALGO_CONV");
+  e->stream = (lpcStream_t)stream;
+  const PlaneGeom& g = e->g;
+  const int nplanes = n * g.DC;
+  const bool padded_io = !e->cfg.pad;
+  // staging planes live in the tail of the handle's scratch
+  float* xin = (float*)e->gaux;
+  float* xout = (float*)e->gx;
+  const int nimg = n * e->cfg.depth;
+  if (padded_io) {
+    LPC_OK(hwc_to_planar(e, dev_x, xin, nimg, g.Hp, g.Wp, g.rpitch, g.rplane));
+    LPC_OK(convolve_planar(e, xin, xout, nplanes, true, adjoint != 0));
+    LPC_OK(planar_to_hwc(e, xout, dev_out, nimg, g.Hp, g.Wp, g.rpitch, g.rplane, 0, 0, 0));
+  } else {
+    LPC_OK(hwc_to_planar(e, dev_x, xin, nimg, g.H, g.W, g.W, g.uplane));
+    LPC_OK(convolve_planar(e, xin, xout, nplanes, false, adjoint != 0));
+    LPC_OK(planar_to_hwc(e, xout, dev_out, nimg, g.H, g.W, g.W, g.uplane, 0, 0, 0));
+  }
+  return 0;
+}
+
+int lpc_set_data(lpc_handle e, const float* dev_data, void* stream) {
+  if (!e || !dev_data) return fail("lpc_set_data: null argument");
+  if (e->cfg.algo == LPC_ALGO_CONV) return fail("lpc_set_data: operator-only handle");
+  e->stream = (lpcStream_t)stream;
+  const PlaneGeom& g = e->g;
+  LPC_OK(hwc_to_planar(e, dev_data, e->Y, e->cfg.batch, g.H, g.W, g.W, g.uplane));
+  e->data_set = true;
+  return 0;
+}
+
+int lpc_set_initial_estimate(lpc_handle e, const float* dev_est, void* stream) {
+  if (!e) return fail("null handle");
+  if (e->cfg.algo == LPC_ALGO_CONV) return fail("lpc_set_initial_estimate: operator-only handle");
+  e->stream = (lpcStream_t)stream;
+  const PlaneGeom& g = e->g;
+  if (!dev_est) { e->has_init = false; return 0; }
+  const bool admm = e->cfg.algo == LPC_ALGO_ADMM;
+  const size_t n = (size_t)(admm ? g.rplane : g.uplane) * e->P;
+  if (!e->init_est) LPC_OK(dev_alloc(e, &e->init_est, n));
+  const int nimg = e->cfg.batch * e->cfg.depth;
+  if (admm) LPC_OK(hwc_to_planar(e, dev_est, e->init_est, nimg, g.Hp, g.Wp, g.rpitch, g.rplane));
+  else LPC_OK(hwc_to_planar(e, dev_est, e->init_est, nimg, g.H, g.W, g.W, g.uplane));
+  e->has_init = true;
+  return 0;
+}
+
+int lpc_reset(lpc_handle e, void* stream) {
+  if (!e) return fail("null handle");
+  if (!e->psf_set) return fail("lpc_reset: PSF not set");
+  e->stream = (lpcStream_t)stream;
+  if (e->cfg.algo == LPC_ALGO_ADMM) return admm_reset(e);
+  if (e->cfg.algo >= LPC_ALGO_GD) return gd_reset(e);
+  return 0;
+}
+
+int lpc_set_momentum(lpc_handle e, double p, double mu, double tk) {
+  if (!e) return fail("null handle");
+  e->nest_p = p; e->nest_mu = mu;
+  if (tk > 0) e->tk = tk;
+  return gd_apply_momentum_reset(e);
+}
+
+int lpc_iterate(lpc_handle e, int n_iter, void* stream) {
+  if (!e) return fail("null handle");
+  if (n_iter < 0) return fail("lpc_iterate: negative iteration count");
+  if (!e->psf_set) return fail("lpc_iterate: PSF not set");
+  if (!e->data_set) return fail("Must set data with `set_data()`");
+  e->stream = (lpcStream_t)stream;
+  if (e->cfg.algo == LPC_ALGO_ADMM) return admm_iterate(e, n_iter);
+  if (e->cfg.algo >= LPC_ALGO_GD) return gd_iterate(e, n_iter);
+  return fail("lpc_iterate: operator-only handle");
+}
+
+int lpc_form_image(lpc_handle e, float* dev_out, void* stream) {
+  if (!e || !dev_out) return fail("lpc_form_image: null argument");
+  e->stream = (lpcStream_t)stream;
+  const PlaneGeom& g = e->g;
+  const int nimg = e->cfg.batch * e->cfg.depth;
+  if (e->cfg.algo == LPC_ALGO_ADMM)  // crop + clamp (admm.py:331-338) on a copy
+    return planar_to_hwc(e, e->V[e->vcur], dev_out, nimg, g.H, g.W, g.rpitch, g.rplane, g.sh, g.sw, 1);
+  if (e->cfg.algo >= LPC_ALGO_GD)    // projection (gd.py:136-140)
+    return planar_to_hwc(e, e->gx, dev_out, nimg, g.H, g.W, g.W, g.uplane, 0, 0, 1);
+  return fail("lpc_form_image: operator-only handle");
+}
+
+int lpc_get_state(lpc_handle e, const char* name, float* dev_out, void* stream) {
+  if (!e || !name || !dev_out) return fail("lpc_get_state: null argument");
+  e->stream = (lpcStream_t)stream;
+  const PlaneGeom& g = e->g;
+  const std::string nm(name);
+  const int nimg = e->cfg.batch * e->cfg.depth;
+  if (e->cfg.algo >= LPC_ALGO_GD) return gd_get_state(e, nm, dev_out);
+  if (e->cfg.algo != LPC_ALGO_ADMM) return fail("lpc_get_state: operator-only handle");
+  auto out_padded = [&](float* src) {
+    return planar_to_hwc(e, src, dev_out, nimg, g.Hp, g.Wp, g.rpitch, g.rplane, 0, 0, 0);
+  };
+  if (nm == "image_est") return out_padded(e->V[e->vcur]);
+  if (nm == "forward_out") return out_padded(e->HV);
+  if (nm == "X") return out_padded(e->X);
+  // the rest needs the pending dual update applied: materialise into scratch
+  const long ostride = (long)g.rplane * e->P;
+  float* scratch = nullptr;
+  LPC_RT(rt::dev_malloc((void**)&scratch, (size_t)ostride * 7 * sizeof(float)));
+  AdmmScalars sc = admm_scalars(e);
+  int rc = launch_k(e, -1, k_admm_flush<256>, grid1d((long)g.Hp * g.Wp, 256, e->P), 256, 0, g, sc,
+                    (const float*)e->V[e->vcur], (const float*)e->V[e->vcur ^ 1], (const float*)e->HV,
+                    (const float*)e->X, (const float*)e->xi, (const float*)e->eta0[e->ecur],
+                    (const float*)e->eta1[e->ecur], (const float*)e->rho, scratch, ostride);
+  if (!rc) {
+    if (nm == "xi") rc = out_padded(scratch + 0 * ostride);
+    else if (nm == "rho") rc = out_padded(scratch + 3 * ostride);
+    else if (nm == "W") rc = out_padded(scratch + 6 * ostride);
+    else if (nm == "eta" || nm == "U") {
+      float* a = scratch + (nm == "eta" ? 1 : 4) * ostride;
+      const long n = (long)g.Hp * g.Wp * e->cfg.channels;
+      rc = launch_k(e, -1, k_planar2_to_hwc2<256>, grid1d(n, 256, nimg), 256, 0, (const float*)a,
+                    (const float*)(a + ostride), dev_out, g.Hp, g.Wp, e->cfg.channels, g.rpitch, g.rplane);
+    } else rc = fail("lpc_get_state: unknown name '" + nm + "'");
+  }
+  rt::stream_sync(e->stream);
+  rt::dev_free(scratch);
+  return rc;
+}
+
+int lpc_profile_enable(lpc_handle e, int on) {
+  if (!e) return fail("null handle");
+#if !defined(LPC_SIMT_EMU)
+  for (int k = 0; k < LPC_K_COUNT; ++k) e->timer.used[k] = 0;
+#endif
+  e->timer.on = on != 0;
+  return 0;
+}
+
+int lpc_profile_read(lpc_handle e, double* avg_ms, long* launches) {
+  if (!e || !avg_ms || !launches) return fail("null argument");
+  for (int k = 0; k < LPC_K_COUNT; ++k) { avg_ms[k] = 0.0; launches[k] = 0; }
+#if !defined(LPC_SIMT_EMU)
+  LPC_RT(hipStreamSynchronize(e->stream));
+  for (int k = 0; k < LPC_K_COUNT; ++k) {
+    double tot = 0.0;
+    for (size_t i = 0; i < e->timer.used[k]; ++i) {
+      float ms = 0.f;
+      LPC_RT(hipEventElapsedTime(&ms, e->timer.ev[k][i].first, e->timer.ev[k][i].second));
+      tot += ms;
+    }
+    launches[k] = (long)e->timer.used[k];
+    avg_ms[k] = e->timer.used[k] ? tot / (double)e->timer.used[k] : 0.0;
+  }
+#endif
+  return 0;
+}
+
+int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
+  if (!e || !bytes) return fail("null argument");
+  const PlaneGeom& g = e->g;
+  const double R = 4.0 * g.Hp * g.Wp * e->P;          // padded real arrays, all planes
+  const double S = 8.0 * g.Hp * g.Wc * e->P;          // half spectra
+  const double R0 = 4.0 * g.H * g.W * e->Pdata;
+  const double Sc = 8.0 * g.Hp * g.Wc * e->Ppsf;      // spectral constants
+  const bool split = e->N1 > 1;
+  double b = 0.0;
+  if (e->cfg.algo == LPC_ALGO_ADMM) {
+    switch (kid) {
+      case LPC_K_SPATIAL: b = 15.0 * R + R0; break;            // reads 8R+R0, writes 7R
+      case LPC_K_ROW_FWD: b = 2.0 * R + 2.0 * S; break;
+      case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
+      case LPC_K_COL_MID: b = 4.0 * S + 1.5 * Sc; break;       // + H (complex) + Rdiv (real)
+      case LPC_K_COL_A_INV: b = split ? 4.0 * S : 0.0; break;
+      case LPC_K_ROW_INV: b = 2.0 * S + 2.0 * R; break;
+      default: return fail("bad kernel id");
+    }
+  } else if (e->cfg.algo >= LPC_ALGO_GD) {
+    return gd_kernel_bytes(e, kid, bytes);
+  } else {
+    return fail("lpc_kernel_bytes: operator-only handle");
+  }
+  *bytes = b;
+  return 0;
+}
+
+}  // extern "C"

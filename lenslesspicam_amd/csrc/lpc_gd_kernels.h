@@ -1,0 +1,219 @@
+// lpc_gd_kernels.h -- kernels of the projected-gradient family (vanilla / Nesterov / FISTA)
+// and the small reductions of the set-up path.
+//
+// One GD iteration = grad = H^T (H x - y) followed by a momentum update and the
+// non-negativity projection (lensless/recon/gd.py:128-134,183-188,235-241).  The state is
+// UN-padded; only spectra are padded.  Pad, crop, ifftshift, "- y", the momentum arithmetic
+// and the projection are all folded into the row passes:
+//   k_rfwd_rows        x rows (pad on load)                         -> spectrum rows
+//   [column passes, * H fused in the middle]
+//   k_rinv_gd_mid      spectrum rows -> irfft -> shift+crop -> - y -> pad -> rfft -> spectrum rows
+//   [column passes, * conj(H) fused in the middle]
+//   k_rinv_gd_update   spectrum rows -> irfft -> shift+crop = grad -> fused update of x (+ momentum)
+#pragma once
+#include "lpc_kernels.h"
+
+// ---- inverse rows -> residual -> forward rows, all inside LDS --------------------------------
+template <int NT, int EMAX>
+__global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan,
+                                                     const float2* LPC_RESTRICT Sin,
+                                                     float2* LPC_RESTRICT Sout,
+                                                     const float* LPC_RESTRICT Y) {
+  LPC_DYN_SMEM(smem);
+  float2* s = (float2*)smem;
+  const int tid = threadIdx.x;
+  const int u0 = 2 * blockIdx.x, u1 = u0 + 1;
+  const long pl = blockIdx.y;
+  const bool v1 = u1 < g.H;
+  const int hh = g.Hp / 2, hw = g.Wp / 2;
+  const int sr0 = wrap_add(g.sh + u0, hh, g.Hp);
+  const int sr1 = wrap_add(g.sh + (v1 ? u1 : u0), hh, g.Hp);
+  const float2* sp = Sin + pl * g.cplane;
+  tangle_load<NT>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
+  __syncthreads();
+  lds_fft<NT, EMAX, true>(s, plan, 1, make_fastdiv_dev1(), tid);
+  // residual, re-padded in place: new[i] = (i in window) ? conv[(i + Wp/2) mod Wp] - y[i - sw] : 0
+  const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
+  const float* y0 = Y + (long)dpl * g.uplane + (long)u0 * g.W;
+  const float* y1 = y0 + g.W;
+  float2 v[EMAX];
+#pragma unroll
+  for (int k = 0; k < EMAX; ++k) {
+    const int i = tid + k * NT;
+    v[k] = make_float2(0.f, 0.f);
+    if (i < g.Wp) {
+      const int c = i - g.sw;
+      if (c >= 0 && c < g.W) {
+        const float2 z = s[wrap_add(i, hw, g.Wp)];
+        v[k] = make_float2(z.x - y0[c], v1 ? z.y - y1[c] : 0.f);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < EMAX; ++k) {
+    const int i = tid + k * NT;
+    if (i < g.Wp) s[i] = v[k];
+  }
+  __syncthreads();
+  lds_fft<NT, EMAX, false>(s, plan, 1, make_fastdiv_dev1(), tid);
+  float2* o = Sout + pl * g.cplane + (long)(g.sh + u0) * g.cpitch;
+  untangle_store<NT>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
+}
+
+// ---- inverse rows -> gradient -> fused update --------------------------------------------
+struct GdScalars {
+  int kind;        // 0 vanilla, 1 nesterov, 2 fista
+  float mu;        // nesterov: float32(mu)
+  float negmu;     // nesterov: float32(-mu)
+  float onepmu;    // nesterov: float32(1 + mu)
+  float coef;      // fista: float32((t_k - 1) / t_{k+1})
+  int first;       // fista: x_k aliases the iterate during the first update (gd.py:233,236)
+};
+
+template <int NT, int EMAX>
+__global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan plan,
+                                                        const float2* LPC_RESTRICT Sin,
+                                                        float* LPC_RESTRICT X, float* LPC_RESTRICT AUX,
+                                                        const float* LPC_RESTRICT alpha, GdScalars p) {
+  LPC_DYN_SMEM(smem);
+  float2* s = (float2*)smem;
+  const int tid = threadIdx.x;
+  const int u0 = 2 * blockIdx.x, u1 = u0 + 1;
+  const long pl = blockIdx.y;
+  const bool v1 = u1 < g.H;
+  const int hh = g.Hp / 2, hw = g.Wp / 2;
+  const int sr0 = wrap_add(g.sh + u0, hh, g.Hp);
+  const int sr1 = wrap_add(g.sh + (v1 ? u1 : u0), hh, g.Hp);
+  const float2* sp = Sin + pl * g.cplane;
+  tangle_load<NT>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
+  __syncthreads();
+  lds_fft<NT, EMAX, true>(s, plan, 1, make_fastdiv_dev1(), tid);
+  const float al = alpha[pl % g.C];
+  const long base = pl * g.uplane + (long)u0 * g.W;
+  for (int c = tid; c < g.W; c += NT) {
+    const float2 z = s[wrap_add(g.sw + c, hw, g.Wp)];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+      if (r == 1 && !v1) break;
+      const long o = base + (long)r * g.W + c;
+      const float gr = r == 0 ? z.x : z.y;
+      const float x = X[o];
+      if (p.kind == 0) {                       // gd.py:132-134
+        X[o] = fmaxf(x - al * gr, 0.f);
+      } else if (p.kind == 1) {                // gd.py:183-188
+        const float pp = AUX[o];
+        const float pn = p.mu * pp - al * gr;
+        const float xn = x + (p.negmu * pp + p.onepmu * pn);
+        AUX[o] = pn;
+        X[o] = fmaxf(xn, 0.f);
+      } else {                                 // gd.py:235-241
+        const float x1 = x - al * gr;
+        const float xk = fmaxf(x1, 0.f);
+        const float xp = p.first ? x1 : AUX[o];
+        X[o] = xk + p.coef * (xk - xp);
+        AUX[o] = xk;
+      }
+    }
+  }
+}
+
+// ---- reductions (set-up only): per-plane max/min with wavefront shuffles ---------------------
+template <int NT>
+static __device__ __forceinline__ void block_minmax(float& mx, float& mn, float* scratch, int tid) {
+#if !defined(LPC_SIMT_EMU)
+  for (int off = 32; off > 0; off >>= 1) {  // 64-lane wavefront
+    mx = fmaxf(mx, __shfl_down(mx, off, 64));
+    mn = fminf(mn, __shfl_down(mn, off, 64));
+  }
+  const int wave = tid >> 6, lane = tid & 63;
+  if (lane == 0) { scratch[2 * wave] = mx; scratch[2 * wave + 1] = mn; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < NT / 64; ++w) { mx = fmaxf(mx, scratch[2 * w]); mn = fminf(mn, scratch[2 * w + 1]); }
+  }
+#else
+  scratch[2 * tid] = mx; scratch[2 * tid + 1] = mn;
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < NT; ++w) { mx = fmaxf(mx, scratch[2 * w]); mn = fminf(mn, scratch[2 * w + 1]); }
+  }
+#endif
+}
+
+// mode 0: values are |H* H| of a spectrum plane (pitch cpitch, Wc valid columns);
+// mode 1: values are a real un-padded plane.  Writes (max, min) per (plane, block).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_plane_minmax(PlaneGeom g, const float2* LPC_RESTRICT Hs,
+                                                      const float* LPC_RESTRICT real, int mode,
+                                                      float* LPC_RESTRICT partial) {
+  LPC_DYN_SMEM(smem);
+  float* scratch = (float*)smem;
+  const int tid = threadIdx.x;
+  const long pl = blockIdx.y;
+  float mx = -INFINITY, mn = INFINITY;
+  if (mode == 0) {
+    const long n = (long)g.Hp * g.Wc;
+    for (long e = (long)blockIdx.x * NT + tid; e < n; e += (long)gridDim.x * NT) {
+      const int r = (int)(e / g.Wc), c = (int)(e - (long)r * g.Wc);
+      const float2 h = Hs[pl * g.cplane + (long)r * g.cpitch + c];
+      const float a = h.x * h.x + h.y * h.y;
+      mx = fmaxf(mx, a); mn = fminf(mn, a);
+    }
+  } else {
+    const long n = g.uplane;
+    for (long e = (long)blockIdx.x * NT + tid; e < n; e += (long)gridDim.x * NT) {
+      const float a = real[pl * g.uplane + e];
+      mx = fmaxf(mx, a); mn = fminf(mn, a);
+    }
+  }
+  block_minmax<NT>(mx, mn, scratch, tid);
+  if (tid == 0) {
+    partial[2 * (pl * gridDim.x + blockIdx.x)] = mx;
+    partial[2 * (pl * gridDim.x + blockIdx.x) + 1] = mn;
+  }
+}
+
+// final per-channel combine over depth planes and blocks (gd.py:100-112 flatten (D,H,W) per channel):
+// mode 0: out[c] = lip_fact / max;  mode 1: out[c] = (max + min) / 2
+__global__ void k_channel_finish(const float* LPC_RESTRICT partial, int nblk, int D, int C, int mode, float lip,
+                                 float* LPC_RESTRICT out) {
+  const int c = threadIdx.x;
+  if (c >= C) return;
+  float mx = -INFINITY, mn = INFINITY;
+  for (int d = 0; d < D; ++d)
+    for (int b = 0; b < nblk; ++b) {
+      const long i = 2 * ((long)(d * C + c) * nblk + b);
+      mx = fmaxf(mx, partial[i]);
+      mn = fminf(mn, partial[i + 1]);
+    }
+  out[c] = mode == 0 ? lip / mx : (mx + mn) / 2;
+}
+
+// x[plane][...] = val[plane % C]
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fill_per_channel(float* LPC_RESTRICT x, long plane_elems, int C,
+                                                          const float* LPC_RESTRICT val) {
+  const long pl = blockIdx.y;
+  const float v = val[pl % C];
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < plane_elems; e += (long)gridDim.x * NT)
+    x[pl * plane_elems + e] = v;
+}
+
+// two planar arrays (component 0 / 1) -> channels-last with a trailing axis of 2
+template <int NT>
+__global__ __launch_bounds__(NT) void k_planar2_to_hwc2(const float* LPC_RESTRICT a0, const float* LPC_RESTRICT a1,
+                                                         float* LPC_RESTRICT dst, int rows, int cols, int C,
+                                                         int pitch, long splane) {
+  const long n = (long)rows * cols * C;
+  const long img = blockIdx.y;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const int c = (int)(e % C);
+    const long rc = e / C;
+    const int col = (int)(rc % cols);
+    const int row = (int)(rc / cols);
+    const long so = (img * C + c) * splane + (long)row * pitch + col;
+    dst[(img * n + e) * 2 + 0] = a0[so];
+    dst[(img * n + e) * 2 + 1] = a1[so];
+  }
+}

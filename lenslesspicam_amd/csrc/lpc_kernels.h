@@ -1,0 +1,583 @@
+// lpc_kernels.h -- device kernels of the MI355X deconvolution engine.
+//
+// Memory layout in HBM (all float32):
+//   * images are PLANAR: plane q = (b*D + d)*C + c, rows contiguous.  The reference keeps
+//     channels innermost (stride-3 FFTs); planar turns B, D and C into one batch index.
+//   * padded real plane:   [Hp][rpitch]  (rpitch >= Wp)
+//   * half spectrum plane: [Hp][cpitch]  float2 (cpitch >= Wc = Wp/2+1, 16-element padded so
+//     every tile row is a whole number of 128-byte lines)
+//   * un-padded plane:     [H][W]
+// Column (H-axis) transforms longer than LDS allows are split four-step style,
+// Hp = N1*N2: pass A = length-N1 FFTs over rows {n1*N2 + n2} (+ twiddle), pass B =
+// length-N2 FFTs over the contiguous row block {k1*N2 + n2}.  Frequencies therefore stay
+// in a PERMUTED row order (row k1*N2+k2 holds frequency k1 + N1*k2); every spectral
+// constant (H, R_divmat, phase tables) is generated in the same order, so no transpose
+// or reordering pass ever touches HBM.
+#pragma once
+#include "lpc_fft.h"
+
+struct PlaneGeom {
+  int H, W;        // un-padded spatial size
+  int Hp, Wp, Wc;  // padded rows / cols, half-spectrum cols
+  int sh, sw;      // origin of the sensor window inside the padded frame
+  int rpitch;      // floats per padded real row
+  int cpitch;      // float2 per spectrum row
+  long rplane;     // floats per padded real plane
+  long cplane;     // float2 per spectrum plane
+  long uplane;     // floats per un-padded plane
+  int DC;          // D*C: number of PSF planes (state plane q uses PSF plane q % DC)
+  int C;           // channels (data plane of state plane q = (q / DC) * C + q % C)
+};
+
+static __device__ __forceinline__ int wrap_add(int i, int d, int n) {  // (i + d) mod n for |d| <= n
+  int r = i + d;
+  if (r >= n) r -= n;
+  if (r < 0) r += n;
+  return r;
+}
+
+// ===================================================================== row passes ==
+// Two real rows ride through ONE complex FFT of length Wp (re = row A, im = row B) and are
+// separated afterwards by Hermitian symmetry; works for even and odd Wp alike.
+
+// s[] holds Z = FFT(a + i b); writes A[k], B[k] for k in [0, Wc)
+template <int NT>
+static __device__ __forceinline__ void untangle_store(const float2* s, int Wp, int Wc, float2* outA,
+                                                       float2* outB, bool validB, int tid) {
+  for (int k = tid; k < Wc; k += NT) {
+    float2 zk = s[k];
+    float2 zn = s[k == 0 ? 0 : Wp - k];
+    outA[k] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
+    if (validB) outB[k] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+  }
+}
+
+// builds Z[k] = A[k] + i B[k] over the full length from two half spectra (irfft semantics:
+// imaginary parts of the DC and Nyquist bins are ignored)
+template <int NT>
+static __device__ __forceinline__ void tangle_load(float2* s, int Wp, int Wc, const float2* inA,
+                                                    const float2* inB, bool validB, int tid) {
+  for (int k = tid; k < Wc; k += NT) {
+    float2 a = inA[k];
+    float2 b = validB ? inB[k] : make_float2(0.f, 0.f);
+    const bool selfconj = (k == 0) || (2 * k == Wp);
+    if (selfconj) { a.y = 0.f; b.y = 0.f; }
+    s[k] = make_float2(a.x - b.y, a.y + b.x);
+    if (!selfconj) s[Wp - k] = make_float2(a.x + b.y, b.x - a.y);
+  }
+}
+
+// ---- forward, ADMM: row r of array A and row r of array B -> spectra SA, SB ------------
+template <int NT, int EMAX>
+__global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
+                                                     const float* LPC_RESTRICT A,
+                                                     const float* LPC_RESTRICT B,
+                                                     float2* LPC_RESTRICT SA,
+                                                     float2* LPC_RESTRICT SB) {
+  LPC_DYN_SMEM(smem);
+  float2* s = (float2*)smem;
+  const int tid = threadIdx.x, row = blockIdx.x;
+  const long pl = blockIdx.y;
+  const float* a = A + pl * g.rplane + (long)row * g.rpitch;
+  const float* b = B + pl * g.rplane + (long)row * g.rpitch;
+  for (int i = tid; i < g.Wp; i += NT) s[i] = make_float2(a[i], b[i]);
+  __syncthreads();
+  lds_fft<NT, EMAX, false>(s, plan, 1, make_fastdiv_dev1(), tid);
+  untangle_store<NT>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
+                     SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
+}
+
+// ---- forward, generic: rows (2b, 2b+1) of ONE real source -> spectrum rows ------------
+struct RealSrc {
+  const float* base;
+  long plane_stride;  // floats
+  int pitch;          // floats per row
+  int nrows;          // rows >= nrows are implicit zeros
+  int ncols, col0;    // column c of the padded frame maps to base[...][c-col0] if in [col0,col0+ncols)
+  int out_row0;       // source row r lands in spectrum row out_row0 + r
+};
+
+template <int NT, int EMAX>
+__global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, RealSrc src,
+                                                   float2* LPC_RESTRICT S) {
+  LPC_DYN_SMEM(smem);
+  float2* s = (float2*)smem;
+  const int tid = threadIdx.x;
+  const int r0 = 2 * blockIdx.x, r1 = r0 + 1;
+  const long pl = blockIdx.y;
+  const bool v1 = r1 < src.nrows;
+  const float* a = src.base + pl * src.plane_stride + (long)r0 * src.pitch;
+  const float* b = src.base + pl * src.plane_stride + (long)r1 * src.pitch;
+  for (int i = tid; i < g.Wp; i += NT) {
+    const int c = i - src.col0;
+    const bool in = (c >= 0) && (c < src.ncols);
+    s[i] = make_float2(in ? a[c] : 0.f, (in && v1) ? b[c] : 0.f);
+  }
+  __syncthreads();
+  lds_fft<NT, EMAX, false>(s, plan, 1, make_fastdiv_dev1(), tid);
+  float2* o = S + pl * g.cplane + (long)(src.out_row0 + r0) * g.cpitch;
+  untangle_store<NT>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
+}
+
+// ---- inverse, ADMM: spectra SA, SB -> real arrays A, B (no shift, padded) ---------------
+template <int NT, int EMAX>
+__global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, Fft1dPlan plan,
+                                                     const float2* LPC_RESTRICT SA,
+                                                     const float2* LPC_RESTRICT SB,
+                                                     float* LPC_RESTRICT A, float* LPC_RESTRICT B) {
+  LPC_DYN_SMEM(smem);
+  float2* s = (float2*)smem;
+  const int tid = threadIdx.x, row = blockIdx.x;
+  const long pl = blockIdx.y;
+  tangle_load<NT>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
+                  SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
+  __syncthreads();
+  lds_fft<NT, EMAX, true>(s, plan, 1, make_fastdiv_dev1(), tid);
+  float* a = A + pl * g.rplane + (long)row * g.rpitch;
+  float* b = B + pl * g.rplane + (long)row * g.rpitch;
+  for (int i = tid; i < g.Wp; i += NT) {
+    float2 z = s[i];
+    a[i] = z.x;
+    b[i] = z.y;
+  }
+}
+
+// ---- inverse, generic: spectrum rows -> ONE real sink with ifftshift (+ crop) -----------
+// Output row i of the shifted frame comes from spectrum row (i + Hp/2) mod Hp and output
+// column c from column (c + Wp/2) mod Wp (fft.ifftshift is a roll by -(n//2)).  That is pure
+// index arithmetic on the way out of LDS: exact, and no extra pass over HBM.
+struct RealDst {
+  float* base;
+  long plane_stride;
+  int pitch;
+  int nrows;       // number of output rows (Hp if not cropping, H if cropping)
+  int row0, col0;  // output (r, c) = shifted-frame (row0 + r, col0 + c); (0,0) when not cropping
+  int ncols;       // Wp or W
+};
+
+template <int NT, int EMAX>
+__global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
+                                                   const float2* LPC_RESTRICT S, RealDst dst) {
+  LPC_DYN_SMEM(smem);
+  float2* s = (float2*)smem;
+  const int tid = threadIdx.x;
+  const int r0 = 2 * blockIdx.x, r1 = r0 + 1;
+  const long pl = blockIdx.y;
+  const bool v1 = r1 < dst.nrows;
+  const int hh = g.Hp / 2, hw = g.Wp / 2;
+  const int sr0 = wrap_add(dst.row0 + r0, hh, g.Hp);
+  const int sr1 = wrap_add(dst.row0 + (v1 ? r1 : r0), hh, g.Hp);
+  tangle_load<NT>(s, g.Wp, g.Wc, S + pl * g.cplane + (long)sr0 * g.cpitch,
+                  S + pl * g.cplane + (long)sr1 * g.cpitch, v1, tid);
+  __syncthreads();
+  lds_fft<NT, EMAX, true>(s, plan, 1, make_fastdiv_dev1(), tid);
+  float* a = dst.base + pl * dst.plane_stride + (long)r0 * dst.pitch;
+  float* b = dst.base + pl * dst.plane_stride + (long)r1 * dst.pitch;
+  for (int c = tid; c < dst.ncols; c += NT) {
+    float2 z = s[wrap_add(dst.col0 + c, hw, g.Wp)];
+    a[c] = z.x;
+    if (v1) b[c] = z.y;
+  }
+}
+
+// ================================================================== column passes ==
+struct ColPass {
+  int N;            // transform length of this pass
+  int G;            // groups along H (Hp / N)
+  int istride;      // rows between consecutive transform elements
+  int gstride;      // rows between consecutive groups:  row(g,i) = g*gstride + i*istride
+  int T;            // image columns per tile
+  int ntile_c;      // ceil(Wc / T)
+  int tw_mode;      // 0: none; 1: multiply result k by twH[g*k] (forward pass A);
+                    // 2: multiply input k by conj(twH[g*k]) (inverse pass A)
+  int zr0, zr1;     // forward only: rows outside [zr0,zr1) are implicit zeros on load
+  const float2* twH;  // exp(-2 pi i q / Hp), q in [0, Hp)
+  FastDiv tdiv;     // fast divide by T
+  FastDiv tcdiv;    // fast divide by ntile_c
+};
+
+// plain pass over ONE spectrum array, in place
+template <int NT, int EMAX, bool INV>
+__global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, Fft1dPlan plan, ColPass cp,
+                                              float2* LPC_RESTRICT S) {
+  LPC_DYN_SMEM(smem);
+  float2* s = (float2*)smem;
+  const int tid = threadIdx.x;
+  const int grp = (int)fd_div(blockIdx.x, cp.tcdiv);
+  const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * cp.T;
+  float2* base = S + (long)blockIdx.y * g.cplane + (long)grp * cp.gstride * g.cpitch + c0;
+  const int nelem = cp.N * cp.T;
+  for (int e = tid; e < nelem; e += NT) {
+    const int i = (int)fd_div((unsigned)e, cp.tdiv);
+    const int j = e - i * cp.T;
+    const int row = grp * cp.gstride + i * cp.istride;
+    float2 v = make_float2(0.f, 0.f);
+    if (c0 + j < g.Wc && (INV || (row >= cp.zr0 && row < cp.zr1))) {
+      v = base[(long)i * cp.istride * g.cpitch + j];
+      if (INV && cp.tw_mode == 2) v = cmul_conj(v, cp.twH[grp * i]);
+    }
+    s[e] = v;
+  }
+  __syncthreads();
+  lds_fft<NT, EMAX, INV>(s, plan, cp.T, cp.tdiv, tid);
+  for (int e = tid; e < nelem; e += NT) {
+    const int i = (int)fd_div((unsigned)e, cp.tdiv);
+    const int j = e - i * cp.T;
+    if (c0 + j < g.Wc) {
+      float2 v = s[e];
+      if (!INV && cp.tw_mode == 1) v = cmul(v, cp.twH[grp * i]);
+      base[(long)i * cp.istride * g.cpitch + j] = v;
+    }
+  }
+}
+
+// fused middle of a convolution: forward pass B -> multiply by the PSF spectrum (or its
+// conjugate) -> inverse pass B, one trip through HBM.  hscale folds 1/(Hp*Wp).
+template <int NT, int EMAX>
+__global__ __launch_bounds__(NT) void k_cols_mid_mul(PlaneGeom g, Fft1dPlan plan, ColPass cp,
+                                                      float2* LPC_RESTRICT S,
+                                                      const float2* LPC_RESTRICT Hs, int conjH,
+                                                      float hscale, int psf_planes) {
+  LPC_DYN_SMEM(smem);
+  float2* s = (float2*)smem;
+  const int tid = threadIdx.x;
+  const int grp = (int)fd_div(blockIdx.x, cp.tcdiv);
+  const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * cp.T;
+  const long rowoff = ((long)grp * cp.gstride) * g.cpitch + c0;
+  float2* base = S + (long)blockIdx.y * g.cplane + rowoff;
+  const float2* hb = Hs + (long)((int)blockIdx.y % psf_planes) * g.cplane + rowoff;
+  const int nelem = cp.N * cp.T;
+  for (int e = tid; e < nelem; e += NT) {
+    const int i = (int)fd_div((unsigned)e, cp.tdiv);
+    const int j = e - i * cp.T;
+    const int row = grp * cp.gstride + i * cp.istride;
+    float2 v = make_float2(0.f, 0.f);
+    if (c0 + j < g.Wc && row >= cp.zr0 && row < cp.zr1) v = base[(long)i * cp.istride * g.cpitch + j];
+    s[e] = v;
+  }
+  __syncthreads();
+  lds_fft<NT, EMAX, false>(s, plan, cp.T, cp.tdiv, tid);
+  for (int e = tid; e < nelem; e += NT) {
+    const int i = (int)fd_div((unsigned)e, cp.tdiv);
+    const int j = e - i * cp.T;
+    if (c0 + j < g.Wc) {
+      float2 h = hb[(long)i * cp.istride * g.cpitch + j];
+      float2 v = s[e];
+      v = conjH ? cmul_conj(v, h) : cmul(v, h);
+      s[e] = cscale(v, hscale);
+    }
+  }
+  __syncthreads();
+  lds_fft<NT, EMAX, true>(s, plan, cp.T, cp.tdiv, tid);
+  for (int e = tid; e < nelem; e += NT) {
+    const int i = (int)fd_div((unsigned)e, cp.tdiv);
+    const int j = e - i * cp.T;
+    if (c0 + j < g.Wc) base[(long)i * cp.istride * g.cpitch + j] = s[e];
+  }
+}
+
+// fused middle of one ADMM iteration (4-FFT form).  In: SA = rows+colsA transform of
+// r_sp, SB = same of a = mu1 X - xi.  After forward pass B:
+//   Vh  = Rdiv * (Rh + s * conj(H) * Ah)        (Rdiv already holds 1/(Hp*Wp))
+//   HVh = s * H * Vh                             (s = spectral phase of ifftshift)
+// then inverse pass B; SA <- Vh path, SB <- HVh path.
+// LDS tile: [N][2T] -- columns 0..T-1 belong to SA, T..2T-1 to SB.
+template <int NT, int EMAX>
+__global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan plan, ColPass cp,
+                                                       float2* LPC_RESTRICT SA,
+                                                       float2* LPC_RESTRICT SB,
+                                                       const float2* LPC_RESTRICT Hs,
+                                                       const float* LPC_RESTRICT Rdiv,
+                                                       const float2* LPC_RESTRICT phr,
+                                                       const float2* LPC_RESTRICT phc,
+                                                       FastDiv t2div) {
+  LPC_DYN_SMEM(smem);
+  float2* s = (float2*)smem;
+  const int tid = threadIdx.x;
+  const int T = cp.T, T2 = 2 * cp.T;
+  const int grp = (int)fd_div(blockIdx.x, cp.tcdiv);
+  const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * T;
+  const long rowoff = ((long)grp * cp.gstride) * g.cpitch + c0;
+  float2* ba = SA + (long)blockIdx.y * g.cplane + rowoff;
+  float2* bb = SB + (long)blockIdx.y * g.cplane + rowoff;
+  const int pp = (int)blockIdx.y % g.DC;
+  const float2* hb = Hs + (long)pp * g.cplane + rowoff;
+  const float* rb = Rdiv + (long)pp * g.cplane + rowoff;
+  const int nelem = cp.N * T2;
+  for (int e = tid; e < nelem; e += NT) {
+    const int i = (int)fd_div((unsigned)e, t2div);
+    const int jj = e - i * T2;
+    const int j = jj < T ? jj : jj - T;
+    float2 v = make_float2(0.f, 0.f);
+    if (c0 + j < g.Wc) v = (jj < T ? ba : bb)[(long)i * cp.istride * g.cpitch + j];
+    s[e] = v;
+  }
+  __syncthreads();
+  lds_fft<NT, EMAX, false>(s, plan, T2, t2div, tid);
+  const int npair = cp.N * T;
+  for (int e = tid; e < npair; e += NT) {
+    const int i = (int)fd_div((unsigned)e, cp.tdiv);
+    const int j = e - i * T;
+    if (c0 + j < g.Wc) {
+      const long off = (long)i * cp.istride * g.cpitch + j;
+      const float2 h = hb[off];
+      const float rd = rb[off];
+      const float2 ph = cmul(phr[grp * cp.gstride + i * cp.istride], phc[c0 + j]);
+      const float2 rh = s[i * T2 + j];
+      const float2 ah = s[i * T2 + T + j];
+      float2 t = cmul(cmul_conj(ah, h), ph);          // s * conj(H) * Ah
+      float2 vh = cscale(cadd(rh, t), rd);
+      float2 hv = cmul(cmul(vh, h), ph);
+      s[i * T2 + j] = vh;
+      s[i * T2 + T + j] = hv;
+    }
+  }
+  __syncthreads();
+  lds_fft<NT, EMAX, true>(s, plan, T2, t2div, tid);
+  for (int e = tid; e < nelem; e += NT) {
+    const int i = (int)fd_div((unsigned)e, t2div);
+    const int jj = e - i * T2;
+    const int j = jj < T ? jj : jj - T;
+    if (c0 + j < g.Wc) (jj < T ? ba : bb)[(long)i * cp.istride * g.cpitch + j] = s[e];
+  }
+}
+
+// ============================================================ ADMM spatial kernel ==
+// K1: everything of one ADMM iteration that lives in the image domain, in ONE pass:
+//   (pending) dual updates of the previous iteration  xi, eta, rho
+//   U  = soft(Psi V + eta/mu2, tau/mu2)     X = M (xi + mu1 HV + pad(y))     W = max(rho/mu3 + V, 0)
+//   r_sp = (mu3 W - rho) + Psi^T(mu2 U - eta)           a = mu1 X - xi
+// U and W are never stored: the previous iteration's U, W are recomputed from V_old (kept by
+// ping-ponging the V buffer), which replaces 3 reads + 3 writes of padded arrays by 1 read.
+// V / V_old tiles (+1 halo) and q = mu2 U - eta (+1 row / +1 col) are staged in LDS.
+// eta is read at halo pixels owned by neighbouring workgroups, so its update is written to a
+// second buffer (ping-pong, no extra traffic); every other array is touched only at owned pixels.
+struct AdmmScalars {
+  float mu1, mu2, mu3;
+  float thr;            // (float)(tau / mu2)
+  float m_in, m_out;    // X_divmat inside / outside the sensor window
+  int first;            // 1: no pending dual update (first iteration after reset)
+};
+
+static __device__ __forceinline__ float soft_thresh_dev(float a, float thr) {
+  const float m = fmaxf(fabsf(a) - thr, 0.f);
+  return a > 0.f ? m : (a < 0.f ? -m : 0.f);
+}
+
+template <int TH, int TW, int NT>
+__global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
+                                                      const float* LPC_RESTRICT V,
+                                                      const float* LPC_RESTRICT Vold,
+                                                      const float* LPC_RESTRICT HV,
+                                                      float* LPC_RESTRICT X, float* LPC_RESTRICT xi,
+                                                      const float* LPC_RESTRICT eta0,
+                                                      const float* LPC_RESTRICT eta1,
+                                                      float* LPC_RESTRICT eta0_out,
+                                                      float* LPC_RESTRICT eta1_out,
+                                                      float* LPC_RESTRICT rho,
+                                                      const float* LPC_RESTRICT Y,
+                                                      float* LPC_RESTRICT Rsp, float* LPC_RESTRICT Aout) {
+  LPC_DYN_SMEM(smem);
+  constexpr int VW = TW + 2, VH = TH + 2;
+  float* sV = (float*)smem;                 // [VH][VW], local (ly+1, lx+1)
+  float* sO = sV + VH * VW;                 // same for V_old
+  float* sQ0 = sO + VH * VW;                // [TH+1][TW]
+  float* sQ1 = sQ0 + (TH + 1) * TW;         // [TH][TW+1]
+  const int tid = threadIdx.x;
+  const int r0 = blockIdx.y * TH, c0 = blockIdx.x * TW;
+  const long pl = blockIdx.z;
+  const long poff = pl * g.rplane;
+  const float* v = V + poff;
+  const float* vo = Vold + poff;
+
+  // ---- stage V, V_old (+halo, circular) ----
+  for (int e = tid; e < VH * VW; e += NT) {
+    const int ly = e / VW, lx = e - ly * VW;
+    int gr = r0 + ly - 1, gc = c0 + lx - 1;
+    gr = gr < 0 ? gr + g.Hp : gr; gr = gr >= g.Hp ? gr - g.Hp : gr; gr = gr >= g.Hp ? gr % g.Hp : gr;
+    gc = gc < 0 ? gc + g.Wp : gc; gc = gc >= g.Wp ? gc - g.Wp : gc; gc = gc >= g.Wp ? gc % g.Wp : gc;
+    const long o = (long)gr * g.rpitch + gc;
+    sV[e] = v[o];
+    sO[e] = p.first ? 0.f : vo[o];
+  }
+  __syncthreads();
+
+  // ---- q0 over [0,TH] x [0,TW), q1 over [0,TH) x [0,TW]; eta' stored for owned pixels ----
+  for (int e = tid; e < (TH + 1) * (TW + 1); e += NT) {
+    const int ly = e / (TW + 1), lx = e - ly * (TW + 1);
+    int gr = r0 + ly, gc = c0 + lx;
+    const bool own = (ly < TH) && (lx < TW) && (gr < g.Hp) && (gc < g.Wp);
+    gr = gr >= g.Hp ? gr % g.Hp : gr;
+    gc = gc >= g.Wp ? gc % g.Wp : gc;
+    const long o = poff + (long)gr * g.rpitch + gc;
+    const int li = (ly + 1) * VW + (lx + 1);
+    const float vc = sV[li], oc = sO[li];
+    if (lx < TW) {  // component 0 (row difference)
+      float e0 = eta0[o];
+      const float psi = sV[li - VW] - vc;
+      if (!p.first) {
+        const float psio = sO[li - VW] - oc;
+        const float uo = soft_thresh_dev(psio + e0 / p.mu2, p.thr);
+        e0 = e0 + p.mu2 * (psi - uo);
+      }
+      const float un = soft_thresh_dev(psi + e0 / p.mu2, p.thr);
+      sQ0[ly * TW + lx] = p.mu2 * un - e0;
+      if (own) eta0_out[o] = e0;
+    }
+    if (ly < TH) {  // component 1 (column difference)
+      float e1 = eta1[o];
+      const float psi = sV[li - 1] - vc;
+      if (!p.first) {
+        const float psio = sO[li - 1] - oc;
+        const float uo = soft_thresh_dev(psio + e1 / p.mu2, p.thr);
+        e1 = e1 + p.mu2 * (psi - uo);
+      }
+      const float un = soft_thresh_dev(psi + e1 / p.mu2, p.thr);
+      sQ1[ly * (TW + 1) + lx] = p.mu2 * un - e1;
+      if (own) eta1_out[o] = e1;
+    }
+  }
+  __syncthreads();
+
+  // ---- owned pixels: xi, rho, X, W, r_sp, a ----
+  const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
+  const float* y = Y + (long)dpl * g.uplane;
+  for (int e = tid; e < TH * TW; e += NT) {
+    const int ly = e / TW, lx = e - ly * TW;
+    const int gr = r0 + ly, gc = c0 + lx;
+    if (gr >= g.Hp || gc >= g.Wp) continue;
+    const long o = poff + (long)gr * g.rpitch + gc;
+    const int li = (ly + 1) * VW + (lx + 1);
+    const float vc = sV[li];
+    const float hv = HV[o];
+    float xiv = xi[o], rhov = rho[o];
+    if (!p.first) {
+      const float xo = X[o];
+      xiv = xiv + p.mu1 * (hv - xo);
+      const float wo = fmaxf(rhov / p.mu3 + sO[li], 0.f);
+      rhov = rhov + p.mu3 * (vc - wo);
+    }
+    const bool inside = (gr >= g.sh) && (gr < g.sh + g.H) && (gc >= g.sw) && (gc < g.sw + g.W);
+    const float yv = inside ? y[(long)(gr - g.sh) * g.W + (gc - g.sw)] : 0.f;
+    const float xn = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
+    const float wn = fmaxf(rhov / p.mu3 + vc, 0.f);
+    const float d1 = sQ0[(ly + 1) * TW + lx] - sQ0[ly * TW + lx];
+    const float d2 = sQ1[ly * (TW + 1) + lx + 1] - sQ1[ly * (TW + 1) + lx];
+    xi[o] = xiv;
+    rho[o] = rhov;
+    X[o] = xn;
+    Rsp[o] = (p.mu3 * wn - rhov) + (d1 + d2);
+    Aout[o] = p.mu1 * xn - xiv;
+  }
+}
+
+// materialise U, W and the flushed duals for inspection (tests / get_state); no state change
+template <int NT>
+__global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
+                                                    const float* LPC_RESTRICT V,
+                                                    const float* LPC_RESTRICT Vold,
+                                                    const float* LPC_RESTRICT HV,
+                                                    const float* LPC_RESTRICT X,
+                                                    const float* LPC_RESTRICT xi,
+                                                    const float* LPC_RESTRICT eta0,
+                                                    const float* LPC_RESTRICT eta1,
+                                                    const float* LPC_RESTRICT rho, float* LPC_RESTRICT out,
+                                                    long ostride) {
+  // out planes of size ostride*: 0 xi', 1 eta0', 2 eta1', 3 rho', 4 U0, 5 U1, 6 W
+  const long n = (long)g.Hp * g.Wp;
+  const long pl = blockIdx.y;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const int r = (int)(e / g.Wp), c = (int)(e - (long)r * g.Wp);
+    const long o = pl * g.rplane + (long)r * g.rpitch + c;
+    const long ou = pl * g.rplane + (long)wrap_add(r, -1, g.Hp) * g.rpitch + c;
+    const long ol = pl * g.rplane + (long)r * g.rpitch + wrap_add(c, -1, g.Wp);
+    float xiv = xi[o], e0 = eta0[o], e1 = eta1[o], rh = rho[o];
+    float u0 = 0.f, u1 = 0.f, w = 0.f;
+    if (!p.first) {
+      const float oc = Vold[o], vc = V[o];
+      u0 = soft_thresh_dev((Vold[ou] - oc) + e0 / p.mu2, p.thr);
+      u1 = soft_thresh_dev((Vold[ol] - oc) + e1 / p.mu2, p.thr);
+      w = fmaxf(rh / p.mu3 + oc, 0.f);
+      xiv = xiv + p.mu1 * (HV[o] - X[o]);
+      e0 = e0 + p.mu2 * ((V[ou] - vc) - u0);
+      e1 = e1 + p.mu2 * ((V[ol] - vc) - u1);
+      rh = rh + p.mu3 * (vc - w);
+    }
+    out[0 * ostride + o] = xiv;
+    out[1 * ostride + o] = e0;
+    out[2 * ostride + o] = e1;
+    out[3 * ostride + o] = rh;
+    out[4 * ostride + o] = u0;
+    out[5 * ostride + o] = u1;
+    out[6 * ostride + o] = w;
+  }
+}
+
+// ========================================================= layout / setup kernels ==
+// channels-last (n, rows, cols, C) <-> planar (n*C planes)[rows][pitch]
+template <int NT>
+__global__ __launch_bounds__(NT) void k_hwc_to_planar(const float* LPC_RESTRICT src, float* LPC_RESTRICT dst,
+                                                       int rows, int cols, int C, int pitch, long dplane) {
+  const long n = (long)rows * cols * C;
+  const long img = blockIdx.y;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const int c = (int)(e % C);
+    const long rc = e / C;
+    const int col = (int)(rc % cols);
+    const int row = (int)(rc / cols);
+    dst[(img * C + c) * dplane + (long)row * pitch + col] = src[img * n + e];
+  }
+}
+
+// planar -> channels-last with optional crop window and clamp (>= 0).  clamp_src: also write
+// the clamped value back into the planar source (the reference's ADMM._form_image clamps
+// its state IN PLACE, admm.py:331-338).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_planar_to_hwc(float* LPC_RESTRICT src, float* LPC_RESTRICT dst,
+                                                       int rows, int cols, int C, int pitch, long splane,
+                                                       int row0, int col0, int clamp, int clamp_src) {
+  const long n = (long)rows * cols * C;
+  const long img = blockIdx.y;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const int c = (int)(e % C);
+    const long rc = e / C;
+    const int col = (int)(rc % cols);
+    const int row = (int)(rc / cols);
+    const long so = (img * C + c) * splane + (long)(row0 + row) * pitch + (col0 + col);
+    float v = src[so];
+    if (clamp && v < 0.f) {
+      v = 0.f;
+      if (clamp_src) src[so] = 0.f;
+    }
+    dst[img * n + e] = v;
+  }
+}
+
+// Rdiv = scale / (mu1 |H* H| + mu2 |G| + mu3)      (admm.py:186-190, real part only)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_admm_rdiv(PlaneGeom g, const float2* LPC_RESTRICT Hs,
+                                                   const float2* LPC_RESTRICT Gs, float* LPC_RESTRICT Rdiv,
+                                                   float mu1, float mu2, float mu3, float scale) {
+  const long n = (long)g.Hp * g.cpitch;
+  const long pl = blockIdx.y;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const float2 h = Hs[pl * g.cplane + e];
+    const float2 hh = cmul_conj(h, h);                       // Hadj * H
+    const float2 gg = Gs[e];
+    const float a = sqrtf(hh.x * hh.x + hh.y * hh.y);        // |.|
+    const float b = sqrtf(gg.x * gg.x + gg.y * gg.y);
+    Rdiv[pl * g.cplane + e] = scale * (1.0f / (mu1 * a + mu2 * b + mu3));
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_scale_complex(float2* LPC_RESTRICT S, long n, float sc) {
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    S[e] = cscale(S[e], sc);
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void k_fill(float* LPC_RESTRICT p, long n, float v) {
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) p[e] = v;
+}

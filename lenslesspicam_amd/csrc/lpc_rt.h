@@ -1,0 +1,143 @@
+// lpc_rt.h -- thin runtime layer for the deconvolution engine.
+//
+// Product build (hipcc, gfx950): everything maps 1:1 onto the HIP runtime.
+//
+// LPC_SIMT_EMU build (g++, tests only): the SAME kernel sources are compiled for
+// the host and executed by a cooperative-fibre SIMT emulator that lives under
+// tests/simt_emu/.  It exists because the build container has no GPU: it lets the
+// CPU test-suite execute the real kernel bodies (index maths, LDS staging, barrier
+// structure) against the oracle before a GPU-minute is spent.  It is NOT a product
+// path: lenslesspicam_amd never builds, ships or loads it, and the product library
+// refuses to run without a HIP device.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+
+#if defined(LPC_SIMT_EMU)
+
+// ----------------------------------------------------------------- emulator --
+#include <functional>
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+
+namespace lpc_emu {
+struct ThreadCtx { dim3 tid, bid, bdim, gdim; char* smem; };
+ThreadCtx& ctx();                 // current fibre's coordinates
+void barrier();                   // __syncthreads()
+void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
+}  // namespace lpc_emu
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define LPC_RESTRICT
+#define threadIdx (lpc_emu::ctx().tid)
+#define blockIdx (lpc_emu::ctx().bid)
+#define blockDim (lpc_emu::ctx().bdim)
+#define gridDim (lpc_emu::ctx().gdim)
+#define __syncthreads() lpc_emu::barrier()
+#define LPC_DYN_SMEM(name) char* name = lpc_emu::ctx().smem
+
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32); }
+
+typedef void* lpcStream_t;
+typedef int lpcError_t;
+#define lpcSuccess 0
+
+namespace rt {
+static inline const char* err_string(lpcError_t) { return "emu"; }
+static inline lpcError_t dev_malloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 1; }
+static inline lpcError_t dev_free(void* p) { std::free(p); return 0; }
+static inline lpcError_t memset_async(void* p, int v, size_t n, lpcStream_t) { std::memset(p, v, n); return 0; }
+static inline lpcError_t copy_d2d_async(void* d, const void* s, size_t n, lpcStream_t) { std::memmove(d, s, n); return 0; }
+static inline lpcError_t copy_h2d_async(void* d, const void* s, size_t n, lpcStream_t) { std::memcpy(d, s, n); return 0; }
+static inline lpcError_t copy_d2h_async(void* d, const void* s, size_t n, lpcStream_t) { std::memcpy(d, s, n); return 0; }
+static inline lpcError_t stream_sync(lpcStream_t) { return 0; }
+static inline lpcError_t last_error() { return 0; }
+static inline lpcError_t device_count(int* n) { *n = 1; return 0; }
+static inline lpcError_t set_max_dyn_smem(const void*, size_t) { return 0; }
+static inline const char* backend_name() { return "simt-emu(test-only)"; }
+}  // namespace rt
+
+#define LPC_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  lpc_emu::launch((grid), (block), (smem), [=]() { kernel(__VA_ARGS__); })
+
+#else
+
+// ---------------------------------------------------------------------- HIP --
+#include <hip/hip_runtime.h>
+
+#define LPC_RESTRICT __restrict__
+// all LDS is dynamic and 16-byte aligned (guide: Guideline 17)
+#define LPC_DYN_SMEM(name)                                              \
+  extern __shared__ __attribute__((aligned(16))) char lpc_dyn_smem_[];  \
+  char* name = lpc_dyn_smem_
+
+typedef hipStream_t lpcStream_t;
+typedef hipError_t lpcError_t;
+#define lpcSuccess hipSuccess
+
+namespace rt {
+static inline const char* err_string(lpcError_t e) { return hipGetErrorString(e); }
+static inline lpcError_t dev_malloc(void** p, size_t n) { return hipMalloc(p, n ? n : 1); }
+static inline lpcError_t dev_free(void* p) { return hipFree(p); }
+static inline lpcError_t memset_async(void* p, int v, size_t n, lpcStream_t s) { return hipMemsetAsync(p, v, n, s); }
+static inline lpcError_t copy_d2d_async(void* d, const void* s, size_t n, lpcStream_t st) { return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st); }
+static inline lpcError_t copy_h2d_async(void* d, const void* s, size_t n, lpcStream_t st) { return hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st); }
+static inline lpcError_t copy_d2h_async(void* d, const void* s, size_t n, lpcStream_t st) { return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, st); }
+static inline lpcError_t stream_sync(lpcStream_t s) { return hipStreamSynchronize(s); }
+static inline lpcError_t last_error() { return hipGetLastError(); }
+static inline lpcError_t device_count(int* n) { return hipGetDeviceCount(n); }
+static inline lpcError_t set_max_dyn_smem(const void* fn, size_t bytes) {
+  return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+static inline const char* backend_name() { return "hip-gfx950"; }
+}  // namespace rt
+
+#define LPC_LAUNCH(kernel, grid, block, smem, stream, ...) \
+  hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+
+#endif
+
+// ------------------------------------------------------------ small helpers --
+struct cfloat { float x, y; };  // POD complex, layout-compatible with float2
+
+static __host__ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+static __host__ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {  // a * conj(b)
+  return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+}
+static __host__ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+static __host__ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+static __host__ __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+static __host__ __device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+
+// division of small non-negative ints by a plan-time constant: q = floor(n/d) for
+// n*d < 2^32 (all tile-local indices here are < 2^16).
+struct FastDiv {
+  unsigned d, m;  // m = floor(2^32/d) + 1  (d >= 2);  d == 1 handled separately
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+  FastDiv f; f.d = d; f.m = d > 1 ? (unsigned)((0x100000000ull / d) + 1ull) : 0u; return f;
+}
+static __host__ __device__ __forceinline__ FastDiv make_fastdiv_dev1() {
+  FastDiv f; f.d = 1; f.m = 0; return f;
+}
+static __device__ __forceinline__ unsigned fd_div(unsigned n, FastDiv f) {
+  return f.d == 1 ? n : __umulhi(n, f.m);
+}
