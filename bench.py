@@ -1,0 +1,248 @@
+#!/usr/bin/env python3
+"""
+bench.py -- headline benchmark of the MI355X deconvolution engine.
+
+Metric (BASELINE.json): ADMM iterations/s at 4056x3040x3, 100 iterations (+ PSNR delta vs ref).
+Workload C2 (BASELINE.json configs[1]): one 12-MP RPi-HQ frame (3040 x 4056 x 3, padded FFT frame
+6144 x 8192) per GPU, ADMM-TV, 100 iterations.  A "step" is one full 100-iteration
+reconstruction (`apply(n_iter=100)`) of one frame per GPU with inputs resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: frames are independent, so rank r reconstructs its own frame (weak scaling, no
+collective inside the loop); one RCCL all-gather of the final images closes each step, as the
+path would do when a batch is sharded over the node.  value = total iterations of all ranks /
+max-over-ranks wall time.
+
+Rank 0 prints ONE JSON line.  On top of the driver's contract it carries:
+  roofline      fused ADMM prox/update kernel: algorithmic bytes (15R + R0)
+                / mean launch duration from HIP events recorded inside the timed region
+  cpu_baseline  the CPU oracle (torch-CPU float32 restatement of the reference, kind "port")
+                timed on this host for a bounded sample of the same workload
+  parity        engine vs oracle after the sampled iterations at full size, and the PSNR delta
+                after 100 iterations on the 270x480x3 DiffuserCam-sized frame (configs[0] size)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n-iter", type=int, default=100)
+    ap.add_argument("--height", type=int, default=3040)
+    ap.add_argument("--width", type=int, default=4056)
+    ap.add_argument("--algo", default="admm", choices=["admm", "fista"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--no-parity", action="store_true")
+    return ap.parse_args()
+
+
+def synth_inputs(H, W, C, seed, device):
+    """PSF: rng.random**12, L2-normalised (io.py:375).  Scene: Gaussian blobs.  Measurement:
+    clip(crop(scene (*) psf), 0)/max (io.py:196-197), produced with the engine's own operator
+    (it is only input data)."""
+    import lenslesspicam_amd as lpa
+    from oracle import lensless_oracle as orc
+
+    psf = torch.from_numpy(orc.synthetic_psf(1, H, W, C, seed=0)).to(device)
+    scene = torch.from_numpy(orc.synthetic_scene(H, W, C, seed=1 + seed)).to(device)
+    conv = lpa.RealFFTConvolve2D(psf, pad=True, norm="backward")
+    y = conv.convolve(scene[None, None])[0, 0].clamp_(min=0)
+    y = y / y.max()
+    del conv
+    return psf, scene, y.contiguous()
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a HIP device"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+    assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
+
+    import lenslesspicam_amd as lpa
+    from lenslesspicam_amd import _native
+    from oracle import lensless_oracle as orc
+
+    H, W, C, n_iter = args.height, args.width, 3, args.n_iter
+    psf, scene, y = synth_inputs(H, W, C, rank, dev)
+    if args.algo == "admm":
+        rec = lpa.ADMM(psf, n_iter=n_iter)
+    else:
+        rec = lpa.FISTA(psf, n_iter=n_iter)
+    rec.set_data(y)
+    hp, wp = rec._padded_shape[1], rec._padded_shape[2]
+
+    gathered = [torch.empty((1, H, W, C), dtype=torch.float32, device=dev) for _ in range(world)] if dist else None
+
+    def step():
+        out = rec.apply(n_iter=n_iter, disp_iter=None, plot=False)
+        if dist:
+            dist.all_gather(gathered, out.contiguous())  # the single end-of-batch collective
+        return out
+
+    for _ in range(args.warmup):
+        step()
+    rec._handle.profile_enable(True)
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    prof = rec._handle.profile_read()
+    rec._handle.profile_enable(False)
+
+    result = None
+    if rank == 0:
+        total_iters = world * args.steps * n_iter
+        value = total_iters / elapsed
+        kid = _native.K_SPATIAL
+        kbytes = rec._handle.kernel_bytes(kid)
+        k_ms, k_n = prof["spatial"]
+        achieved = kbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "k1_traffic.json")
+        if os.path.exists(tf) and args.algo == "admm" and (H, W) == (3040, 4056):
+            try:
+                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        kernels = {}
+        for i, name in enumerate(_native.KERNEL_NAMES):
+            ms, n = prof[name]
+            if n:
+                b = rec._handle.kernel_bytes(i)
+                kernels[name] = {"ms": round(ms, 4), "launches": n, "alg_GB": round(b / 1e9, 3),
+                                 "GBps": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+        result = {
+            "metric": "ADMM iterations/sec at 4056x3040x3, 100 iters" if args.algo == "admm"
+            else "FISTA iterations/sec at 4056x3040x3",
+            "value": round(value, 3),
+            "unit": "iterations/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"C2: one {H}x{W}x{C} frame per GPU, {args.algo.upper()}"
+                            f"{'-TV' if args.algo == 'admm' else ''} {n_iter} iterations per step",
+                "frame": [H, W, C], "padded_fft_frame": [hp, wp], "n_iter": n_iter,
+                "frames_per_gpu": 1, "parallelism": f"frames sharded over {world} GPU(s), one all-gather per step",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_admm_spatial (fused prox/update)" if args.algo == "admm" else "k_rinv_gd_update",
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "alg_bytes_per_launch": kbytes, "avg_launch_ms": round(k_ms, 4), "launches_timed": k_n,
+                "traffic": traffic,
+            },
+            "kernels": kernels,
+            "hbm_workspace_GB": round(rec._handle.workspace_bytes() / 1e9, 2),
+        }
+
+    # ---- CPU baseline + parity: rank 0, N == 1 only --------------------------------------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.algo == "admm":
+        import psutil
+
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        avail_gb = psutil.virtual_memory().available / 1e9
+        need_gb = 32.0 * hp * wp * C * 4 / 1e9  # ~32 padded float32 arrays incl. complex spectra + temporaries
+        bH, bW, note = H, W, ""
+        if avail_gb < need_gb * 1.3:
+            bH, bW = 1520, 2028
+            note = f" (host has {avail_gb:.0f} GB free < {need_gb * 1.3:.0f} GB: sampled at {bH}x{bW} instead)"
+        if (bH, bW) == (H, W):
+            psf_c, y_c = psf.cpu().numpy(), y.cpu().numpy()
+        else:
+            psf_c = orc.synthetic_psf(1, bH, bW, C, seed=0)
+            y_c = np.random.default_rng(0).random((bH, bW, C), dtype=np.float32)
+        o = orc.ADMMOracle(psf_c)
+        o.set_data(y_c)
+        o.reset()
+        t0 = time.perf_counter()
+        for _ in range(args.cpu_iters):
+            o.step()
+        cpu_s = time.perf_counter() - t0
+        cpu_ips = args.cpu_iters / cpu_s
+        result["cpu_baseline"] = {
+            "value": round(cpu_ips, 5), "unit": "iterations/s", "cores": torch.get_num_threads(),
+            "kind": "port",
+            "sample": f"{args.cpu_iters} ADMM iterations of the same {bH}x{bW}x{C} frame (oracle: torch-CPU float32 "
+                      f"restatement of the reference, set-up excluded){note}",
+        }
+        result["speedup_vs_cpu"] = round(result["value"] / cpu_ips, 1) if (bH, bW) == (H, W) else None
+        if not args.no_parity:
+            parity = {}
+            if (bH, bW) == (H, W):
+                rec.apply(n_iter=args.cpu_iters, disp_iter=None)
+                Vg = rec._image_est
+                ref = o.V
+                parity["full_size_rel_err_after_sample"] = float(
+                    (Vg.cpu() - ref).abs().max() / ref.abs().max())
+                parity["full_size_iters"] = args.cpu_iters
+            del o
+            # PSNR delta after the full iteration count on the DiffuserCam-sized frame
+            h2, w2 = 270, 480
+            psf2 = orc.synthetic_psf(1, h2, w2, C, seed=0)
+            scene2 = orc.synthetic_scene(h2, w2, C, seed=1)
+            y2 = orc.synthetic_measurement(psf2, scene2)
+            r2 = lpa.ADMM(torch.from_numpy(psf2).to(dev))
+            r2.set_data(torch.from_numpy(y2).to(dev))
+            g2 = r2.apply(n_iter=n_iter, disp_iter=None).cpu().numpy()
+            o2 = orc.ADMMOracle(psf2)
+            o2.set_data(y2)
+            c2 = o2.apply(n_iter).numpy()
+            parity["psnr_delta_db_270x480_100it"] = orc.psnr(g2[0], scene2) - orc.psnr(c2[0], scene2)
+            parity["rel_err_270x480_100it"] = float(np.abs(g2 - c2).max() / np.abs(c2).max())
+            result["parity"] = parity
+
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,112 @@
+"""
+Projected gradient descent, Nesterov and FISTA on the MI355X engine.  Drop-in for
+``lensless.recon.gd`` (gd.py:24-263): same class names, keywords and defaults.
+
+Per iteration the engine runs four padded real 2-D FFT passes with pad-on-load,
+crop-on-store, the ``- y`` of the residual, the momentum arithmetic and the non-negativity
+projection all folded into the FFT row passes (lpc_gd_kernels.h).
+"""
+from __future__ import annotations
+
+import inspect
+import time
+
+import numpy as np
+import torch
+
+from . import _native
+from .recon import ReconstructionAlgorithm
+
+
+class GradientDescentUpdate:
+    """Gradient descent update techniques (gd.py:24-38)."""
+
+    VANILLA = "vanilla"
+    NESTEROV = "nesterov"
+    FISTA = "fista"
+
+    @staticmethod
+    def all_values():
+        return [v for k, v in inspect.getmembers(GradientDescentUpdate)
+                if not k.startswith("_") and not callable(v)]
+
+
+def non_neg(xi):
+    """Non-negative projection (gd.py:41-59).  This is the projection the engine fuses."""
+    if isinstance(xi, torch.Tensor):
+        return torch.maximum(xi, torch.zeros_like(xi))
+    return np.maximum(xi, 0)
+
+
+class GradientDescent(ReconstructionAlgorithm):
+    _ALGO = _native.ALGO_GD
+
+    def __init__(self, psf, dtype=None, proj=non_neg, lip_fact=1.8, **kwargs):
+        assert callable(proj)
+        if proj is not non_neg:
+            raise NotImplementedError(
+                "custom projection callables cannot be fused into the HIP kernels; only non_neg is supported"
+            )
+        self._proj = proj
+        self._lip_fact = lip_fact
+        super().__init__(psf, dtype, **kwargs)
+
+    def _config(self):
+        return dict(lip_fact=float(self._lip_fact))
+
+    @property
+    def _alpha(self):
+        out = self._empty((int(self._psf_shape[3]),))
+        self._handle.get_state("alpha", out.data_ptr(), self._stream())
+        return self._to_user(out)
+
+
+class NesterovGradientDescent(GradientDescent):
+    _ALGO = _native.ALGO_NESTEROV
+
+    def __init__(self, psf, dtype=None, proj=non_neg, p=0, mu=0.9, **kwargs):
+        self._p, self._mu = p, mu
+        super().__init__(psf, dtype, proj, **kwargs)
+
+    def _config(self):
+        return dict(lip_fact=float(self._lip_fact), nesterov_mu=float(self._mu), nesterov_p=float(self._p))
+
+    def reset(self, p=0, mu=0.9):
+        # same signature AND same defaults as gd.py:178-181: a bare reset() (which is what the
+        # base constructor and apply() issue) restores p=0, mu=0.9 whatever the constructor got
+        self._p, self._mu = p, mu
+        super().reset()
+        if p != 0 or mu != 0.9:
+            self._handle.set_momentum(float(p), float(mu), 0.0)
+
+
+class FISTA(GradientDescent):
+    _ALGO = _native.ALGO_FISTA
+
+    def __init__(self, psf, dtype=None, proj=non_neg, tk=1.0, **kwargs):
+        self._initial_tk = tk
+        super().__init__(psf, dtype, proj, **kwargs)
+        self._tk = tk
+
+    def _config(self):
+        return dict(lip_fact=float(self._lip_fact), fista_tk=float(self._initial_tk))
+
+    def reset(self, tk=None):
+        super().reset()
+        self._tk = tk if tk else self._initial_tk  # gd.py:227-232
+        if tk:
+            self._handle.set_momentum(0.0, 0.9, float(tk))
+
+
+def apply_gradient_descent(psf, data, n_iter, verbose=False, proj=non_neg, **kwargs):
+    """Array-level counterpart of gd.py:244-263."""
+    recon = GradientDescent(psf, n_iter=n_iter, proj=proj, **kwargs)
+    recon.set_data(data)
+    start = time.time()
+    res = recon.apply(plot=False)
+    if verbose:
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        print(f"Reconstruction time : {time.time() - start} s")
+        print(f"Reconstruction shape: {res.shape}")
+    return res

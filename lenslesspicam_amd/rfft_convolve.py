@@ -1,0 +1,108 @@
+"""
+``RealFFTConvolve2D`` on the MI355X engine: drop-in for
+``lensless.recon.rfft_convolve.RealFFTConvolve2D`` (rfft_convolve.py:26-223).
+
+convolve / deconvolve = hand-written real 2-D FFT (two real rows per complex LDS transform,
+four-step column passes) with the multiplication by the PSF spectrum fused between the
+forward and inverse column passes; padding is done on load, ``ifftshift`` and cropping on
+store, so neither costs a pass over HBM.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _native
+from .recon import _Boundary, _check_dtype
+
+
+class RealFFTConvolve2D(_Boundary):
+    def __init__(self, psf, dtype=None, pad=True, norm="ortho", rgb=None, **kwargs):
+        self._init_boundary(psf)
+        assert len(psf.shape) >= 4, "Expected 4D PSF of shape ([batch], depth, width, height, channels)"
+        if len(psf.shape) != 4:
+            raise NotImplementedError("batched PSFs (5-D) are used only by trainable models (out of scope)")
+        self._use_3d = psf.shape[-4] != 1
+        self._is_rgb = (psf.shape[-1] == 3) if rgb is None else rgb
+        assert self._is_rgb or psf.shape[-1] == 1
+        self.norm = norm
+        _check_dtype(dtype, self.is_torch)
+        self.dtype = torch.float32 if self.is_torch else np.float32
+        self.pad = pad
+        self._handle = None
+        self._handle_batch = 0
+        self.set_psf(psf)
+
+    # -- geometry helpers with the reference's names ---------------------------------------
+    def _crop(self, x):
+        return x[..., self._start_idx[0]:self._end_idx[0], self._start_idx[1]:self._end_idx[1], :]
+
+    def _pad(self, v):
+        if len(v.shape) == 5:
+            shape = [v.shape[0]] + self._padded_shape
+        elif len(v.shape) == 4:
+            shape = self._padded_shape
+        else:
+            raise ValueError("Expected 4D or 5D tensor")
+        if isinstance(v, torch.Tensor):
+            vpad = torch.zeros(size=shape, dtype=v.dtype, device=v.device)
+        else:
+            vpad = np.zeros(shape).astype(v.dtype)
+        vpad[..., self._start_idx[0]:self._end_idx[0], self._start_idx[1]:self._end_idx[1], :] = v
+        return vpad
+
+    def _make(self, batch):
+        D, H, W, C = (int(s) for s in self._psf_dev.shape)
+        if self._handle is not None:
+            self._handle.close()
+        self._handle = self._lib.create(algo=_native.ALGO_CONV, height=H, width=W, channels=C, depth=D,
+                                        batch=int(batch), norm=_native.NORM[self.norm], pad=int(bool(self.pad)))
+        self._handle_batch = int(batch)
+        self._handle.set_psf(self._psf_dev.data_ptr(), self._stream())
+
+    def set_psf(self, psf):
+        self._psf = psf.type(self.dtype) if isinstance(psf, torch.Tensor) else psf.astype(self.dtype)
+        self._psf_dev = self._to_dev(psf)
+        self._psf_shape = np.array(self._psf.shape)
+        self._make(max(self._handle_batch, 1))
+        h = self._handle
+        self._padded_shape = [int(self._psf_shape[-4]), h.Hp, h.Wp, 3 if self._is_rgb else 1]
+        self._start_idx = np.array([h.sh, h.sw])
+        self._end_idx = self._start_idx + self._psf_shape[-3:-1]
+
+    def _run(self, x, adjoint, return_fft):
+        if return_fft:
+            raise NotImplementedError(
+                "return_fft exposes the reference's spectrum layout; the engine keeps spectra in a "
+                "permuted (four-step) order and does not export them"
+            )
+        was_torch = isinstance(x, torch.Tensor)
+        xd = self._to_dev(x)
+        lead = xd.shape[:-4]
+        D = int(self._psf_shape[0])
+        x5 = xd.reshape((-1,) + tuple(xd.shape[-4:]))
+        if x5.shape[1] != D:  # broadcasting of depth, like `rfft2(x) * H`
+            assert x5.shape[1] == 1, "depth of the input must be 1 or match the PSF"
+            x5 = x5.expand(-1, D, -1, -1, -1)
+        x5 = x5.contiguous()
+        n = int(x5.shape[0])
+        if n > self._handle_batch:
+            self._make(n)
+        out = torch.empty_like(x5)
+        self._handle.convolve(x5.data_ptr(), out.data_ptr(), n, adjoint, self._stream())
+        out = out.reshape(tuple(lead) + tuple(out.shape[1:]))
+        if was_torch:
+            return out.to(x.device)
+        return out.cpu().numpy()
+
+    def convolve(self, x, return_fft=False):
+        """rfft_convolve.py:133-176"""
+        y = self._run(x, False, return_fft)
+        assert y.shape[-3:-1] == x.shape[-3:-1]
+        return y
+
+    def deconvolve(self, y, return_fft=False):
+        """rfft_convolve.py:178-223 (multiplication by the conjugate spectrum)"""
+        x = self._run(y, True, return_fft)
+        assert x.shape[-3:-1] == y.shape[-3:-1]
+        return x

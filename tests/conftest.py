@@ -1,4 +1,5 @@
 import os
+import subprocess
 import sys
 
 import pytest
@@ -8,10 +9,56 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+EMU_DIR = os.path.join(ROOT, "tests", "simt_emu")
+EMU_LIB = os.path.join(EMU_DIR, "_build", "liblpc_emu.so")
 
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _emu_sources():
+    csrc = os.path.join(ROOT, "lenslesspicam_amd", "csrc")
+    files = [os.path.join(csrc, f) for f in os.listdir(csrc)]
+    files += [os.path.join(EMU_DIR, "emu.cpp"), os.path.join(ROOT, "include", "lpc.h")]
+    return files
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    """SIMT-emulator build of the engine's real kernel sources (tests only, see lpc_rt.h)."""
+    from lenslesspicam_amd import _native
+
+    stale = not os.path.exists(EMU_LIB) or any(
+        os.path.getmtime(f) > os.path.getmtime(EMU_LIB) for f in _emu_sources()
+    )
+    if stale:
+        subprocess.check_call(["sh", os.path.join(EMU_DIR, "build_emu.sh")])
+    return _native.Lib(EMU_LIB)
+
+
+class Backend:
+    def __init__(self, kind, lib, device):
+        self.kind, self.lib, self.device = kind, lib, device
+
+
+@pytest.fixture(params=["emu", pytest.param("hip", marks=pytest.mark.gpu)])
+def backend(request, monkeypatch):
+    """'emu': the kernel sources on the CPU SIMT emulator (default suite);
+    'hip': the product library on cuda:0 (-m gpu).  Both go through the same C ABI and the
+    same Python boundary classes."""
+    import torch
+
+    from lenslesspicam_amd import recon
+
+    if request.param == "emu":
+        lib = request.getfixturevalue("emu_lib")
+        dev = torch.device("cpu")
+        monkeypatch.setattr(recon, "runtime", lambda: (lib, dev))
+        return Backend("emu", lib, dev)
+    lib, dev = recon.runtime()  # raises without a GPU / without the HIP library
+    assert lib.backend().startswith("hip")
+    return Backend("hip", lib, dev)
 
 
 @pytest.fixture(scope="session")

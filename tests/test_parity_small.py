@@ -1,0 +1,193 @@
+"""
+Parity of the engine with (a) the golden vectors produced by the REAL reference and (b) the
+pinned CPU oracle, on small frames.  Every case runs twice: on the SIMT emulator in the
+default CPU suite ('emu' -- same kernel sources, executed on the host) and on the MI355X
+through the product library ('hip', -m gpu).
+
+Float32 tolerances, relative to max|reference|:
+  operator <= 2e-6;  ADMM after 5 / 20 / 50 iterations <= 5e-6 / 1e-5 / 5e-5;
+  GD family <= 5e-6 up to 20 iterations, 5e-5 after 60.
+The engine uses the 4-FFT form of ADMM and its own FFT, so agreement is to round-off, not
+bit-exact; iteration counts are exact by construction (no early exit exists).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import lenslesspicam_amd as lpa
+from oracle import lensless_oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def rel(a, b):
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    if isinstance(b, torch.Tensor):
+        b = b.detach().cpu().numpy()
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+# --------------------------------------------------------------------------- operator --
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_convolver_golden(backend, tag):
+    g = np.load(os.path.join(GOLDEN, "operators.npz"))
+    psf, x = g[f"{tag}_psf"], g[f"{tag}_x"]
+    for norm in ("ortho", "backward"):
+        cv = lpa.RealFFTConvolve2D(psf, pad=True, norm=norm)
+        assert cv._padded_shape == [int(v) for v in g[f"{tag}_padded_shape"]]
+        assert list(cv._start_idx) == list(g[f"{tag}_start"])
+        assert rel(cv.convolve(x), g[f"{tag}_{norm}_conv"]) <= 2e-6
+        assert rel(cv.deconvolve(x), g[f"{tag}_{norm}_deconv"]) <= 2e-6
+        assert np.array_equal(cv._pad(x), g[f"{tag}_{norm}_pad"])
+        assert np.array_equal(cv._crop(cv._pad(x)), x)          # test/test_convolver.py:11-29
+    cvn = lpa.RealFFTConvolve2D(psf, pad=False, norm="backward")
+    assert rel(cvn.convolve(g[f"{tag}_xp"]), g[f"{tag}_nopad_conv"]) <= 2e-6
+    assert rel(cvn.deconvolve(g[f"{tag}_xp"]), g[f"{tag}_nopad_deconv"]) <= 2e-6
+
+
+def test_convolver_slice_commutes(backend):
+    """test/test_convolver.py:32-59: no cross-batch / cross-depth / cross-channel coupling."""
+    rng = np.random.default_rng(0)
+    psf = torch.from_numpy(rng.random((5, 47, 29, 3), dtype=np.float32))
+    data = torch.from_numpy(rng.random((6, 1, 47, 29, 3), dtype=np.float32))
+    cv = lpa.RealFFTConvolve2D(psf, pad=True)
+    full = cv.convolve(data)
+    assert isinstance(full, torch.Tensor) and full.shape == (6, 5, 47, 29, 3)
+    part = cv.convolve(data[:1])
+    torch.testing.assert_close(full[:1], part, rtol=0, atol=0)  # frames are independent: identical bits
+    psf1 = psf[:1].contiguous()
+    cv1 = lpa.RealFFTConvolve2D(psf1, pad=True)
+    torch.testing.assert_close(cv1.convolve(data[:2])[:, 0], full[:2, 0], rtol=0, atol=0)
+
+
+def test_convolver_adjointness(backend):
+    """<H x, y> == <x, H^T y>: a size-independent property of the operator pair.  It holds for
+    EVEN padded sizes only (ifftshift is then an involution that commutes with the circular
+    convolution); for odd sizes the reference's deconvolve is not the exact adjoint either."""
+    rng = np.random.default_rng(1)
+    psf = rng.random((1, 24, 32, 3), dtype=np.float32)
+    x = rng.standard_normal((1, 1, 24, 32, 3)).astype(np.float32)
+    y = rng.standard_normal((1, 1, 24, 32, 3)).astype(np.float32)
+    cv = lpa.RealFFTConvolve2D(psf, pad=True, norm="ortho")
+    lhs = float(np.sum(cv.convolve(x).astype(np.float64) * y))
+    rhs = float(np.sum(x * cv.deconvolve(y).astype(np.float64)))
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+
+
+# -------------------------------------------------------------------------------- ADMM --
+ADMM_CASES = sorted(
+    os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, "admm_*.npz")) if "f64" not in p
+)
+ADMM_TOL = {1: 2e-6, 2: 2e-6, 5: 5e-6, 10: 1e-5, 20: 1e-5, 50: 5e-5}
+
+
+@pytest.mark.parametrize("name", ADMM_CASES)
+def test_admm_matches_reference_golden(backend, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    mu1, mu2, mu3, tau = [float(v) for v in g["params"]]
+    kw = dict(mu1=mu1, mu2=mu2, mu3=mu3, tau=tau)
+    if "initial_est" in g:
+        kw["initial_est"] = g["initial_est"].copy()
+    rec = lpa.ADMM(g["psf"], **kw)
+    assert rec._padded_shape == [int(v) for v in g["padded_shape"]]
+    rec.set_data(g["data"])
+    bg = g["background"] if "background" in g else None
+    done = 0
+    for n in [int(i) for i in g["iters"]]:
+        res = rec.apply(n_iter=n - done, disp_iter=None, plot=False, reset=(done == 0),
+                        background=bg if done == 0 else None)
+        done = n
+        assert isinstance(res, np.ndarray) and res.dtype == np.float32 and res.shape == g["psf"].shape
+        for key, attr in (("V", "_image_est"), ("X", "_X"), ("W", "_W"), ("U", "_U"), ("xi", "_xi"),
+                          ("eta", "_eta"), ("rho", "_rho"), ("HV", "_forward_out")):
+            ref = g[f"it{n}_{key}"]
+            got = getattr(rec, attr)
+            if np.max(np.abs(ref)) == 0:
+                assert float(np.abs(got).max()) == 0.0, (key, n)
+            else:
+                tol = ADMM_TOL[n] * (10 if key in ("eta", "rho", "U") else 1)  # duals sit 5 decades below V
+                assert rel(got, ref) <= tol, (key, n, rel(got, ref))
+    assert rel(res, g["final"]) <= ADMM_TOL[done]
+
+
+def test_admm_vs_oracle_odd_and_gray(backend):
+    rng = np.random.default_rng(3)
+    psf = orc.synthetic_psf(1, 21, 13, 1, seed=3)          # pads to 45 x 25: odd x odd
+    data = rng.random((21, 13, 1), dtype=np.float32)
+    rec = lpa.ADMM(torch.from_numpy(psf), tau=1e-6, mu2=5e-5)
+    assert rec._padded_shape[1] % 2 == 1 and rec._padded_shape[2] % 2 == 1
+    rec.set_data(torch.from_numpy(data))
+    res = rec.apply(n_iter=15, disp_iter=None)
+    o = orc.ADMMOracle(psf, tau=1e-6, mu2=5e-5)
+    o.set_data(data)
+    assert isinstance(res, torch.Tensor) and res.dtype == torch.float32
+    assert rel(res, o.apply(15)) <= 1e-5
+
+
+def test_admm_batch_equals_singles(backend):
+    """Config 4's contract: a batch equals B independent apply() calls."""
+    rng = np.random.default_rng(4)
+    psf = orc.synthetic_psf(1, 16, 20, 3, seed=4)
+    frames = rng.random((3, 16, 20, 3), dtype=np.float32)
+    rec = lpa.ADMM(psf, tau=2e-6, mu2=1e-4)
+    rec.set_data(frames[:, None])
+    batch = rec.apply_batch(n_iter=8)
+    assert batch.shape == (3, 1, 16, 20, 3)
+    for b in range(3):
+        single = lpa.ADMM(psf, tau=2e-6, mu2=1e-4)
+        single.set_data(frames[b])
+        assert np.array_equal(single.apply(n_iter=8, disp_iter=None), batch[b])
+
+
+def test_admm_depth_planes_are_independent(backend):
+    """Row A9: D > 1 = D independent problems sharing the measurement; oracle = per-plane loop."""
+    rng = np.random.default_rng(5)
+    psf = orc.synthetic_psf(3, 12, 18, 3, seed=5)
+    data = rng.random((12, 18, 3), dtype=np.float32)
+    rec = lpa.ADMM(psf, tau=2e-6, mu2=1e-4)
+    rec.set_data(data)
+    res = rec.apply(n_iter=10, disp_iter=None)
+    assert res.shape == (3, 12, 18, 3)
+    for d in range(3):
+        o = orc.ADMMOracle(psf[d:d + 1], tau=2e-6, mu2=1e-4)
+        o.set_data(data)
+        assert rel(res[d], o.apply(10)[0]) <= 1e-5
+
+
+# --------------------------------------------------------------------------- GD family --
+GD_CLASSES = {"gd": lpa.GradientDescent, "nesterov": lpa.NesterovGradientDescent, "fista": lpa.FISTA}
+GD_CASES = sorted(
+    os.path.basename(p)[:-4]
+    for p in glob.glob(os.path.join(GOLDEN, "*.npz"))
+    if os.path.basename(p).split("_")[0] in GD_CLASSES and "f64" not in p
+)
+
+
+@pytest.mark.parametrize("name", GD_CASES)
+def test_gd_family_matches_reference_golden(backend, name):
+    g = np.load(os.path.join(GOLDEN, name + ".npz"))
+    cls = GD_CLASSES[name.split("_")[0]]
+    kw = {}
+    if name.endswith("_tk"):
+        kw["tk"] = 2.5
+    if name.endswith("_mu"):
+        kw["mu"] = 0.7
+    if "initial_est" in g:
+        kw["initial_est"] = g["initial_est"].copy()
+    rec = cls(g["psf"], **kw)
+    rec.set_data(g["data"])
+    assert rel(rec._alpha, g["alpha"]) <= 2e-6
+    assert rel(rec._image_est, g["x0"]) <= 1e-7
+    done = 0
+    for n in [int(i) for i in g["iters"]]:
+        rec.apply(n_iter=n - done, disp_iter=None, reset=(done == 0))
+        done = n
+        r = rel(rec._image_est, g[f"it{n}_x"])
+        assert r <= (5e-6 if n <= 20 else 5e-5), (n, r)
+    assert rel(rec.get_image_estimate()[0], g["final"]) <= 5e-5
