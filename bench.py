@@ -39,6 +39,14 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s HBM3E spec peak
 
 
+_T0 = time.perf_counter()
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench +{time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -90,7 +98,10 @@ def main():
     from oracle import lensless_oracle as orc
 
     H, W, C, n_iter = args.height, args.width, 3, args.n_iter
+    log("generating synthetic inputs")
     psf, scene, y = synth_inputs(H, W, C, rank, dev)
+    torch.cuda.synchronize()
+    log("inputs ready; building solver")
     if args.algo == "admm":
         rec = lpa.ADMM(psf, n_iter=n_iter)
     else:
@@ -106,8 +117,12 @@ def main():
             dist.all_gather(gathered, out.contiguous())  # the single end-of-batch collective
         return out
 
+    torch.cuda.synchronize()
+    log(f"solver ready ({rec._handle.workspace_bytes() / 1e9:.1f} GB HBM); warm-up")
     for _ in range(args.warmup):
         step()
+    torch.cuda.synchronize()
+    log("timed region")
     rec._handle.profile_enable(True)
     if dist:
         dist.barrier()
@@ -125,6 +140,7 @@ def main():
         elapsed = float(t.item())
     prof = rec._handle.profile_read()
     rec._handle.profile_enable(False)
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} step(s)")
 
     result = None
     if rank == 0:
@@ -197,14 +213,16 @@ def main():
         else:
             psf_c = orc.synthetic_psf(1, bH, bW, C, seed=0)
             y_c = np.random.default_rng(0).random((bH, bW, C), dtype=np.float32)
+        log(f"cpu baseline: oracle set-up at {bH}x{bW} on {cores} threads")
         o = orc.ADMMOracle(psf_c)
         o.set_data(y_c)
-        o.reset()
+        log("cpu baseline: timing iterations")
         t0 = time.perf_counter()
         for _ in range(args.cpu_iters):
             o.step()
         cpu_s = time.perf_counter() - t0
         cpu_ips = args.cpu_iters / cpu_s
+        log(f"cpu baseline: {cpu_s:.1f} s for {args.cpu_iters} iterations")
         result["cpu_baseline"] = {
             "value": round(cpu_ips, 5), "unit": "iterations/s", "cores": torch.get_num_threads(),
             "kind": "port",
@@ -223,6 +241,8 @@ def main():
                 parity["full_size_iters"] = args.cpu_iters
             del o
             # PSNR delta after the full iteration count on the DiffuserCam-sized frame
+            torch.set_num_threads(min(cores, 16))  # small FFTs: 256 threads only thrash
+            log("parity: 100-iteration oracle run at 270x480x3")
             h2, w2 = 270, 480
             psf2 = orc.synthetic_psf(1, h2, w2, C, seed=0)
             scene2 = orc.synthetic_scene(h2, w2, C, seed=1)
@@ -236,6 +256,7 @@ def main():
             parity["psnr_delta_db_270x480_100it"] = orc.psnr(g2[0], scene2) - orc.psnr(c2[0], scene2)
             parity["rel_err_270x480_100it"] = float(np.abs(g2 - c2).max() / np.abs(c2).max())
             result["parity"] = parity
+            log("parity done")
 
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -575,11 +575,11 @@ int lpc_create(const lpc_config* cfg, lpc_handle* out) {
 
 int lpc_destroy(lpc_handle e) {
   if (!e) return 0;
-  rt::stream_sync(e->stream);
-  for (void* p : e->allocs) rt::dev_free(p);
+  (void)rt::stream_sync(e->stream);
+  for (void* p : e->allocs) (void)rt::dev_free(p);
 #if !defined(LPC_SIMT_EMU)
   for (auto& v : e->timer.ev)
-    for (auto& pr : v) { hipEventDestroy(pr.first); hipEventDestroy(pr.second); }
+    for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }
 #endif
   delete e;
   return 0;
@@ -745,8 +745,8 @@ int lpc_get_state(lpc_handle e, const char* name, float* dev_out, void* stream) 
                     (const float*)(a + ostride), dev_out, g.Hp, g.Wp, e->cfg.channels, g.rpitch, g.rplane);
     } else rc = fail("lpc_get_state: unknown name '" + nm + "'");
   }
-  rt::stream_sync(e->stream);
-  rt::dev_free(scratch);
+  (void)rt::stream_sync(e->stream);
+  (void)rt::dev_free(scratch);
   return rc;
 }
 
