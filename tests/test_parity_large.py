@@ -89,9 +89,16 @@ def test_split_columns_760x1014_gray():
     assert rec._padded_shape[1:3] == [1536, 2048]
     rec.set_data(torch.from_numpy(y).cuda())
     g = rec.apply(n_iter=5, disp_iter=None)
-    o = orc.ADMMOracle(psf, tau=2e-6, mu2=1e-4)
-    o.set_data(y)
-    assert rel(g, o.apply(5)) <= 1e-5
+    # At this size the float32 CPU backend of the reference/oracle is itself ~3e-5 away from float64
+    # truth (tools/accuracy_probe.py, profiles/r01a_accuracy.log), so truth = the float64 oracle:
+    # the engine must be within 1e-5 of it AND no further from it than the float32 oracle is.
+    o64 = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
+    o64.set_data(y)
+    t64 = o64.apply(5)
+    o32 = orc.ADMMOracle(psf, tau=2e-6, mu2=1e-4)
+    o32.set_data(y)
+    e_gpu, e_cpu = rel(g, t64), rel(o32.apply(5), t64)
+    assert e_gpu <= 1e-5 and e_gpu <= 2 * e_cpu, (e_gpu, e_cpu)
     f = lpa.FISTA(torch.from_numpy(psf).cuda())
     f.set_data(torch.from_numpy(y).cuda())
     of = orc.GDOracle(psf, kind="fista")
@@ -132,9 +139,7 @@ def test_c2_operator_linearity_adjointness_and_delta(c2):
     dpsf = torch.zeros_like(psf)
     dpsf[0, H // 2, W // 2, :] = 1.0
     cd = lpa.RealFFTConvolve2D(dpsf, pad=True, norm="backward")
-    out = cd.convolve(x1)
-    # locate the shift from one impulse, then demand an exact translate everywhere it stays in frame
-    assert float((out - x1).abs().max()) <= 1e-5 * float(x1.abs().max()) or True
+    # one impulse in -> one impulse out (a pure translate), nothing else anywhere in the 12-MP frame
     e = torch.zeros_like(x1)
     e[0, 0, 100, 200, :] = 1.0
     r = cd.convolve(e)[0, 0, :, :, 0]
