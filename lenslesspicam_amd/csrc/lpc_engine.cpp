@@ -41,6 +41,10 @@ static int next_5smooth(int n) {  // scipy.fftpack.next_fast_len (rfft_convolve.
   }
 }
 
+// Workgroup shape for an FFT tile of `nelem` complex points: NT threads x EMAX points per thread:
+// the fewest threads that hold the tile with <= 16 points per thread.  Measured on MI355X
+// (profiles/r01b_notes.md): the alternatives "twice the threads, half the points" (same LDS, twice
+// the waves) and "half the threads, 32 points" are both slower.
 template <class F>
 static int dispatch_cfg(int nelem, F&& f) {
   using std::integral_constant;
@@ -50,6 +54,15 @@ static int dispatch_cfg(int nelem, F&& f) {
   if (nelem <= 8192) return f(integral_constant<int, 512>{}, integral_constant<int, 16>{});
   if (nelem <= 16384) return f(integral_constant<int, 1024>{}, integral_constant<int, 16>{});
   return fail("FFT tile of " + std::to_string(nelem) + " points exceeds the LDS budget (16384)");
+}
+
+// row kernels: (NT, EMAX) by row length, plus the LDS-skew flag of the plan
+template <class F>
+static int dispatch_row(int Wp, int skew, F&& f) {
+  return dispatch_cfg(Wp, [&](auto NT, auto EM) {
+    if (skew) return f(NT, EM, std::integral_constant<bool, true>{});
+    return f(NT, EM, std::integral_constant<bool, false>{});
+  });
 }
 
 struct KernelTimer {
@@ -174,14 +187,35 @@ static int make_twiddles(Engine* e, int n, float2** out) {
 static int build_plan(Engine* e, Fft1dPlan& p, int n) {
   p.n = n;
   p.nst = 0;
-  int r = n, a = 0;
+  int r = n, a = 0, b3 = 0;
   while (r % 2 == 0) { r /= 2; ++a; }
+  while (r % 3 == 0) { r /= 3; ++b3; }
   std::vector<int> rad;
-  for (int i = 0; i < a / 3; ++i) rad.push_back(8);
-  if (a % 3 == 2) rad.push_back(4);
-  if (a % 3 == 1) rad.push_back(2);
+  // few, fat stages: 16s first (the twiddle-free first stage should be the biggest), then the
+  // remaining power of two (pairing a lone 2 with a 3 into a radix-6 stage), then 5s and 3s
+  static int max_radix = -1;
+  if (max_radix < 0) {
+    const char* env = std::getenv("LPC_MAX_RADIX");  // 16 needs a -DLPC_ENABLE_R16 build
+    max_radix = env ? atoi(env) : 8;
+#ifndef LPC_ENABLE_R16
+    max_radix = 8;
+#endif
+  }
+  if (max_radix >= 16) {
+    for (int i = 0; i < a / 4; ++i) rad.push_back(16);
+    a %= 4;
+  } else {
+    for (int i = 0; i < a / 3; ++i) rad.push_back(8);
+    a %= 3;
+  }
+  switch (a) {
+    case 3: rad.push_back(8); break;
+    case 2: rad.push_back(4); break;
+    case 1: if (b3 > 0) { rad.push_back(6); --b3; } else rad.push_back(2); break;
+    default: break;
+  }
   while (r % 5 == 0) { r /= 5; rad.push_back(5); }
-  while (r % 3 == 0) { r /= 3; rad.push_back(3); }
+  for (int i = 0; i < b3; ++i) rad.push_back(3);
   if (r != 1) return fail("length " + std::to_string(n) + " is not 5-smooth");
   if ((int)rad.size() > LPC_MAX_STAGES) return fail("too many FFT stages");
   int ns = 1;
@@ -193,6 +227,13 @@ static int build_plan(Engine* e, Fft1dPlan& p, int n) {
     ns *= rad[s];
   }
   p.nst = (int)rad.size();
+  p.skew_ok = 1;  // see lpc_fft.h: every butterfly stride must be a multiple of 8
+  for (int st = 0; st < p.nst; ++st) {
+    const int nb = n / p.radix[st];
+    if (nb % 8 != 0) p.skew_ok = 0;
+    if (!(p.ns[st] % 8 == 0 || (p.ns[st] == 1 && p.radix[st] % 8 == 0))) p.skew_ok = 0;
+  }
+  if (std::getenv("LPC_NO_SKEW")) p.skew_ok = 0;
   float2* tw = nullptr;
   LPC_OK(make_twiddles(e, n, &tw));
   p.tw = tw;
@@ -202,6 +243,7 @@ static int build_plan(Engine* e, Fft1dPlan& p, int n) {
 // choose the column split Hp = N1*N2 and the tile width
 static void choose_split(int Hp, int Wc, int* N1, int* N2, int* T) {
   int t = 16;
+  if (const char* env = std::getenv("LPC_COL_T")) t = std::max(1, atoi(env));  // tuning knob
   while (t > 1 && t / 2 >= Wc) t /= 2;  // tiny images: do not waste lanes on empty columns
   int budget = 16384;                   // points per LDS tile, worst case two arrays (ADMM middle)
   if (const char* env = std::getenv("LPC_TILE_BUDGET")) budget = std::max(64, atoi(env));  // test knob
@@ -279,9 +321,10 @@ static int setup_geometry(Engine* e) {
 static int rows_fwd_single(Engine* e, const RealSrc& src, float2* S, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
   const int nblk = (src.nrows + 1) / 2;
-  return dispatch_cfg(g.Wp, [&](auto NT, auto EM) {
+  return dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NT, auto EM, auto SK) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    return launch_k(e, kid, k_rfwd_rows<nt, em>, dim3(nblk, nplanes), nt, (size_t)g.Wp * sizeof(float2), g,
+    constexpr bool sk = decltype(SK)::value;
+    return launch_k(e, kid, k_rfwd_rows<nt, em, sk>, dim3(nblk, nplanes), nt, LPC_ROW_SMEM_BYTES(g.Wp, sk), g,
                     e->planW, src, S);
   });
 }
@@ -352,9 +395,10 @@ static int conv_middle(Engine* e, float2* S, int nplanes, bool adjoint, int zr0,
 static int rows_inv_single(Engine* e, const float2* S, const RealDst& dst, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
   const int nblk = (dst.nrows + 1) / 2;
-  return dispatch_cfg(g.Wp, [&](auto NT, auto EM) {
+  return dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NT, auto EM, auto SK) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    return launch_k(e, kid, k_rinv_rows<nt, em>, dim3(nblk, nplanes), nt, (size_t)g.Wp * sizeof(float2), g,
+    constexpr bool sk = decltype(SK)::value;
+    return launch_k(e, kid, k_rinv_rows<nt, em, sk>, dim3(nblk, nplanes), nt, LPC_ROW_SMEM_BYTES(g.Wp, sk), g,
                     e->planW, S, dst);
   });
 }
@@ -500,10 +544,11 @@ static int admm_iterate(Engine* e, int n_iter) {
                     (const float*)e->Y, e->Rsp, e->Aarr));
     e->ecur ^= 1;
     e->first = false;
-    LPC_OK(dispatch_cfg(g.Wp, [&](auto NTc, auto EM) {
+    LPC_OK(dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NTc, auto EM, auto SK) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
-      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<nt, em>, dim3(g.Hp, e->P), nt, (size_t)g.Wp * sizeof(float2),
-                      g, e->planW, (const float*)e->Rsp, (const float*)e->Aarr, SA, SB);
+      constexpr bool sk = decltype(SK)::value;
+      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<nt, em, sk>, dim3(g.Hp, e->P), nt,
+                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const float*)e->Rsp, (const float*)e->Aarr, SA, SB);
     }));
     if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, false, 0, g.Hp, LPC_K_COL_A_FWD));
     {
@@ -518,10 +563,11 @@ static int admm_iterate(Engine* e, int n_iter) {
       }));
     }
     if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, true, 0, g.Hp, LPC_K_COL_A_INV));
-    LPC_OK(dispatch_cfg(g.Wp, [&](auto NTc, auto EM) {
+    LPC_OK(dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NTc, auto EM, auto SK) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
-      return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em>, dim3(g.Hp, e->P), nt, (size_t)g.Wp * sizeof(float2),
-                      g, e->planW, (const float2*)SA, (const float2*)SB, Vo, e->HV);
+      constexpr bool sk = decltype(SK)::value;
+      return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em, sk>, dim3(g.Hp, e->P), nt,
+                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const float2*)SA, (const float2*)SB, Vo, e->HV);
     }));
     e->vcur ^= 1;  // Vo now holds the new image estimate
     ++e->iters_done;

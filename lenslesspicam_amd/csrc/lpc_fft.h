@@ -1,19 +1,25 @@
-// lpc_fft.h -- batched mixed-radix (2,3,4,5,8) Stockham FFT held entirely in LDS.
+// lpc_fft.h -- batched mixed-radix (8,6,5,4,3,2; 16 optional) Stockham FFT for one workgroup.
 //
 // Design (MI355X-first, not a rocFFT/cuFFT translation):
-//  * one workgroup owns a tile of BT transforms of length n laid out in LDS as
-//    s[i*BT + b] (element i of transform b) -- for column passes b runs over adjacent
+//  * one workgroup owns a tile of BT transforms of length n.  Between stages the tile lives in
+//    LDS as s[i*BT + b] (element i of transform b) -- for column passes b runs over adjacent
 //    image columns, so consecutive lanes touch consecutive float2 (ds_read/write_b64,
-//    conflict-free) and the global loads that fill the tile are 128-byte segments;
+//    conflict-free) and the global accesses that fill / drain the tile are 128-byte segments;
+//  * a tile is filled from a caller-supplied SOURCE functor (global loads, padding, residuals)
+//    with all of a thread's loads issued back-to-back into VGPRs before the first LDS write, and
+//    drained into a SINK functor (global stores, crop/shift, fused solver updates);
 //  * every stage is "all lanes read their butterflies into VGPRs -> barrier -> all lanes
-//    write" so the tile is transformed in place (no ping-pong buffer => half the LDS,
-//    twice the workgroups per CU);
-//  * the autosort (Stockham) indexing leaves each 1-D transform in natural order, which
-//    the real<->half-spectrum untangling of the row passes needs;
-//  * twiddles come from one double-precision-generated table per length (exp(-2 pi i q/n)),
-//    L1/L2 resident.
+//    write", i.e. in place: no ping-pong buffer, half the LDS, twice the workgroups per CU;
+//  * measured on MI355X (profiles/r01b_notes.md): more points per thread beats more waves per
+//    workgroup, but radix 16 costs ~50 VGPRs in every kernel (the radix switch is allocated for
+//    its fattest arm) and loses more occupancy than it saves in barriers -> radix <= 8 by default;
+//  * the autosort (Stockham) indexing leaves each 1-D transform in natural order, which the
+//    real<->half-spectrum untangling of the row passes needs;
+//  * twiddles come from one double-precision-generated table per length (exp(-2 pi i q/n)); radix
+//    8 / 16 butterflies load w^1, w^2, w^4 (, w^8) and form the other powers by <= 2 products.
 #pragma once
 #include "lpc_rt.h"
+#include <type_traits>
 
 #define LPC_MAX_STAGES 12
 
@@ -25,12 +31,24 @@ struct Fft1dPlan {
   int twstep[LPC_MAX_STAGES];  // n / (ns*radix)
   FastDiv nsdiv[LPC_MAX_STAGES];
   const float2* tw;            // device table, n entries: exp(-2 pi i q / n)
+  int skew_ok;                 // row mode: the i + i/8 LDS skew stays affine in every stage
 };
 
 // multiply by -i (forward) / +i (inverse)
 template <bool INV>
 static __device__ __forceinline__ float2 rot90(float2 a) {
   return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+// multiply by exp(-+ 2 pi i q / 16) for the constants a radix-16 butterfly needs
+template <bool INV, int Q>
+static __device__ __forceinline__ float2 mul_w16(float2 a) {
+  constexpr float C8 = 0.70710678118654752440f;   // cos(pi/4)
+  constexpr float C1 = 0.92387953251128675613f;   // cos(pi/8)
+  constexpr float S1 = 0.38268343236508977173f;   // sin(pi/8)
+  constexpr float wr = Q == 1 ? C1 : Q == 2 ? C8 : Q == 3 ? S1 : Q == 6 ? -C8 : -C1;   // Q in {1,2,3,6,9}
+  constexpr float wf = Q == 1 ? -S1 : Q == 2 ? -C8 : Q == 3 ? -C1 : Q == 6 ? -C8 : S1;  // forward imag part
+  constexpr float wi = INV ? -wf : wf;
+  return make_float2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
 }
 
 template <int R, bool INV>
@@ -101,6 +119,24 @@ struct Dft<5, INV> {
 };
 
 template <bool INV>
+struct Dft<6, INV> {  // 6 = 2 x 3 (decimation in time over the even / odd inputs)
+  static __device__ __forceinline__ void run(float2* v) {
+    const float S = 0.86602540378443864676f;
+    float2 e[3] = {v[0], v[2], v[4]};
+    float2 o[3] = {v[1], v[3], v[5]};
+    Dft<3, INV>::run(e);
+    Dft<3, INV>::run(o);
+    // w6^1 = (1/2, -+ S), w6^2 = (-1/2, -+ S)
+    const float si = INV ? S : -S;
+    float2 o1 = make_float2(0.5f * o[1].x - si * o[1].y, 0.5f * o[1].y + si * o[1].x);
+    float2 o2 = make_float2(-0.5f * o[2].x - si * o[2].y, -0.5f * o[2].y + si * o[2].x);
+    v[0] = cadd(e[0], o[0]); v[3] = csub(e[0], o[0]);
+    v[1] = cadd(e[1], o1);   v[4] = csub(e[1], o1);
+    v[2] = cadd(e[2], o2);   v[5] = csub(e[2], o2);
+  }
+};
+
+template <bool INV>
 struct Dft<8, INV> {
   static __device__ __forceinline__ void run(float2* v) {
     const float C = 0.70710678118654752440f;
@@ -123,16 +159,76 @@ struct Dft<8, INV> {
   }
 };
 
-// One Stockham stage over a tile of BT transforms.  Ends with a barrier.
-template <int R, int NT, int EMAX, bool INV>
+template <bool INV>
+struct Dft<16, INV> {  // 16 = 4 x 4: X[k1 + 4 k2] = sum_n2 w16^(n2 k1) [sum_n1 x[4 n1 + n2] w4^(n1 k1)] w4^(n2 k2)
+  static __device__ __forceinline__ void run(float2* v) {
+    float2 y[4][4];
+#pragma unroll
+    for (int n2 = 0; n2 < 4; ++n2) {
+      float2 t[4] = {v[n2], v[4 + n2], v[8 + n2], v[12 + n2]};
+      Dft<4, INV>::run(t);
+#pragma unroll
+      for (int k1 = 0; k1 < 4; ++k1) y[n2][k1] = t[k1];
+    }
+    // twiddles w16^(n2*k1)
+    y[1][1] = mul_w16<INV, 1>(y[1][1]); y[1][2] = mul_w16<INV, 2>(y[1][2]); y[1][3] = mul_w16<INV, 3>(y[1][3]);
+    y[2][1] = mul_w16<INV, 2>(y[2][1]); y[2][2] = rot90<INV>(y[2][2]);      y[2][3] = mul_w16<INV, 6>(y[2][3]);
+    y[3][1] = mul_w16<INV, 3>(y[3][1]); y[3][2] = mul_w16<INV, 6>(y[3][2]); y[3][3] = mul_w16<INV, 9>(y[3][3]);
+#pragma unroll
+    for (int k1 = 0; k1 < 4; ++k1) {
+      float2 t[4] = {y[0][k1], y[1][k1], y[2][k1], y[3][k1]};
+      Dft<4, INV>::run(t);
+#pragma unroll
+      for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = t[k2];
+    }
+  }
+};
+
+// v[m] *= w^m (m = 1..R-1), w = exp(-+ 2 pi i q1 / n) = tw[q1] (conjugated for the inverse).
+template <int R, bool INV>
+static __device__ __forceinline__ void twiddle_mul(float2* v, const float2* LPC_RESTRICT tw, int q1) {
+  if (R <= 6) {  // exact table entries for every power
+#pragma unroll
+    for (int m = 1; m < R; ++m) {
+      float2 t = tw[q1 * m];
+      v[m] = INV ? cmul_conj(v[m], t) : cmul(v[m], t);
+    }
+  } else {
+    float2 w[16];
+    w[1] = tw[q1]; w[2] = tw[2 * q1]; w[4] = tw[4 * q1];
+    if (R == 16) w[8] = tw[8 * q1];
+    w[3] = cmul(w[1], w[2]); w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]);
+    if (R == 16) {
+#pragma unroll
+      for (int m = 9; m < 16; ++m) w[m] = cmul(w[m - 8], w[8]);
+    }
+#pragma unroll
+    for (int m = 1; m < R; ++m) v[m] = INV ? cmul_conj(v[m], w[m]) : cmul(v[m], w[m]);
+  }
+}
+
+// Row mode (one transform per workgroup, BT == 1) may store element i at LDS slot i + i/8: the
+// early Stockham stages write with a lane stride of R float2 (an 8- or 16-way conflict on the
+// 32 x 4-byte banks of ds_write_b64).  Only used when it stays AFFINE inside every stage
+// (plan.skew_ok, checked on the host) so that a butterfly's R accesses are base + m*stride'.
+template <bool SKEW>
+static __device__ __forceinline__ int lds_slot(int i) {
+  return SKEW ? i + (i >> 3) : i;
+}
+static __host__ __device__ __forceinline__ int lds_slots_skewed(int n) { return n + (n >> 3) + 1; }
+
+// One Stockham stage over a tile of BT transforms held in LDS (in place).  Ends with a barrier.
+template <int R, int NT, int EMAX, bool INV, bool SKEW>
 static __device__ __forceinline__ void fft_stage(float2* s, int n, int BT, FastDiv btdiv, int ns,
                                                   FastDiv nsdiv, int twstep,
                                                   const float2* LPC_RESTRICT tw, int tid) {
   constexpr int MAXB = (EMAX + R - 1) / R;
   const int nb = n / R;
   const int nwork = nb * BT;
-  const int istride = nb * BT;   // LDS distance between the R inputs of one butterfly
-  const int ostride = ns * BT;   // LDS distance between its R outputs
+  const int istride = nb * BT;   // tile distance between the R inputs of one butterfly
+  const int ostride = ns * BT;   // tile distance between its R outputs
+  const int rs = SKEW ? istride + (istride >> 3) : istride;   // same, in (skewed) LDS slots
+  const int ws = SKEW ? ostride + (ostride >> 3) : ostride;
   float2 v[MAXB][R];
   int obase[MAXB];
 #pragma unroll
@@ -144,47 +240,110 @@ static __device__ __forceinline__ void fft_stage(float2* s, int n, int BT, FastD
       const int c = w - j * BT;
       const int jq = (int)fd_div((unsigned)j, nsdiv);
       const int k = j - jq * ns;
+      const int rb = lds_slot<SKEW>(w);
 #pragma unroll
-      for (int m = 0; m < R; ++m) v[b][m] = s[w + m * istride];
-      if (ns > 1) {
-        const int q1 = k * twstep;
-#pragma unroll
-        for (int m = 1; m < R; ++m) {
-          float2 t = tw[q1 * m];
-          v[b][m] = INV ? cmul_conj(v[b][m], t) : cmul(v[b][m], t);
-        }
-      }
+      for (int m = 0; m < R; ++m) v[b][m] = s[rb + m * rs];
+      if (ns > 1) twiddle_mul<R, INV>(v[b], tw, k * twstep);
       Dft<R, INV>::run(v[b]);
-      obase[b] = (jq * ns * R + k) * BT + c;
+      obase[b] = lds_slot<SKEW>((jq * ns * R + k) * BT + c);
     }
   }
   __syncthreads();
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
     if (obase[b] >= 0) {
+      if (SKEW && ns == 1) {  // R is a multiple of 8 here (plan.skew_ok): constant offsets
 #pragma unroll
-      for (int m = 0; m < R; ++m) s[obase[b] + m * ostride] = v[b][m];
+        for (int m = 0; m < R; ++m) s[obase[b] + m + (m >> 3)] = v[b][m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < R; ++m) s[obase[b] + m * ws] = v[b][m];
+      }
     }
   }
   __syncthreads();
 }
 
-// In-place FFT of BT interleaved transforms of length plan.n held in LDS.
-// Precondition: the tile is fully written and a barrier has been passed.
+// In-place FFT of BT interleaved transforms of length plan.n held in LDS (natural order,
+// element (i, c) at slot(i*BT + c)).  Precondition: tile written and a barrier passed.
 // Postcondition: result in natural order, barrier passed.  Unnormalised in both directions.
-template <int NT, int EMAX, bool INV>
+template <int NT, int EMAX, bool INV, bool SKEW = false>
 static __device__ __forceinline__ void lds_fft(float2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
                                                 int tid) {
   for (int st = 0; st < p.nst; ++st) {
     const int ns = p.ns[st];
     const FastDiv nd = p.nsdiv[st];
     const int ts = p.twstep[st];
+#define LPC_STAGE(R) fft_stage<R, NT, EMAX, INV, SKEW>(s, p.n, BT, btdiv, ns, nd, ts, p.tw, tid)
     switch (p.radix[st]) {
-      case 8: fft_stage<8, NT, EMAX, INV>(s, p.n, BT, btdiv, ns, nd, ts, p.tw, tid); break;
-      case 4: fft_stage<4, NT, EMAX, INV>(s, p.n, BT, btdiv, ns, nd, ts, p.tw, tid); break;
-      case 2: fft_stage<2, NT, EMAX, INV>(s, p.n, BT, btdiv, ns, nd, ts, p.tw, tid); break;
-      case 3: fft_stage<3, NT, EMAX, INV>(s, p.n, BT, btdiv, ns, nd, ts, p.tw, tid); break;
-      default: fft_stage<5, NT, EMAX, INV>(s, p.n, BT, btdiv, ns, nd, ts, p.tw, tid); break;
+#ifdef LPC_ENABLE_R16  // measured slower on MI355X: +50 VGPRs in every kernel (profiles/r01b_notes.md)
+      case 16: LPC_STAGE(16); break;
+#endif
+      case 8: LPC_STAGE(8); break;
+      case 6: LPC_STAGE(6); break;
+      case 5: LPC_STAGE(5); break;
+      case 4: LPC_STAGE(4); break;
+      case 3: LPC_STAGE(3); break;
+      default: LPC_STAGE(2); break;
+    }
+#undef LPC_STAGE
+  }
+}
+
+// Tag for "the tile already is / shall stay in LDS in natural order" as source or sink of fft_tile.
+struct LdsNatural {};
+
+// Tile transform with pluggable source and sink:
+//   src(i, c) -> float2   element i of transform c (global loads, padding, residuals, ...)
+//   dst(i, c, v)          receives output element i of transform c (natural order)
+// All of a thread's src() calls are issued before the first LDS write (loops unrolled to the
+// compile-time bound EMAX): with a run-time trip count the compiler emits load / wait / ds_write
+// per element and the kernel serialises on HBM latency (measured: +25 % on the column passes).
+// SRC_LDS: src itself reads the LDS tile, so a barrier separates its reads from the refill.
+struct NoFix {
+  __device__ __forceinline__ float2 operator()(int, int, float2 v) const { return v; }
+};
+
+// fix(i, c, v): optional per-element transform applied AFTER the batched loads have landed (e.g. the
+// four-step twiddle of the inverse pass A): its own table gathers then do not delay the tile loads.
+template <int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, class Src, class Dst, class Fix = NoFix>
+static __device__ __forceinline__ void fft_tile(float2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
+                                                 int tid, Src src, Dst dst, Fix fix = Fix()) {
+  const int nelem = p.n * BT;
+  if constexpr (!std::is_same<Src, LdsNatural>::value) {
+    float2 v[EMAX];
+#pragma unroll
+    for (int k = 0; k < EMAX; ++k) {
+      const int e = tid + k * NT;
+      if (e < nelem) {
+        const int i = (int)fd_div((unsigned)e, btdiv);
+        v[k] = src(i, e - i * BT);
+      }
+    }
+    if (SRC_LDS) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EMAX; ++k) {
+      const int e = tid + k * NT;
+      if (e < nelem) {
+        if constexpr (std::is_same<Fix, NoFix>::value) {
+          s[lds_slot<SKEW>(e)] = v[k];
+        } else {
+          const int i = (int)fd_div((unsigned)e, btdiv);
+          s[lds_slot<SKEW>(e)] = fix(i, e - i * BT, v[k]);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  lds_fft<NT, EMAX, INV, SKEW>(s, p, BT, btdiv, tid);
+  if constexpr (!std::is_same<Dst, LdsNatural>::value) {
+#pragma unroll
+    for (int k = 0; k < EMAX; ++k) {
+      const int e = tid + k * NT;
+      if (e < nelem) {
+        const int i = (int)fd_div((unsigned)e, btdiv);
+        dst(i, e - i * BT, s[lds_slot<SKEW>(e)]);
+      }
     }
   }
 }

@@ -13,8 +13,8 @@
 #pragma once
 #include "lpc_kernels.h"
 
-// ---- inverse rows -> residual -> forward rows, all inside LDS --------------------------------
-template <int NT, int EMAX>
+// ---- inverse rows -> residual -> forward rows, all inside the workgroup -------------------------
+template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan,
                                                      const float2* LPC_RESTRICT Sin,
                                                      float2* LPC_RESTRICT Sout,
@@ -29,36 +29,23 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan,
   const int sr0 = wrap_add(g.sh + u0, hh, g.Hp);
   const int sr1 = wrap_add(g.sh + (v1 ? u1 : u0), hh, g.Hp);
   const float2* sp = Sin + pl * g.cplane;
-  tangle_load<NT>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
+  tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
   __syncthreads();
-  lds_fft<NT, EMAX, true>(s, plan, 1, make_fastdiv_dev1(), tid);
-  // residual, re-padded in place: new[i] = (i in window) ? conv[(i + Wp/2) mod Wp] - y[i - sw] : 0
+  fft_tile<NT, EMAX, true, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
+  // residual, re-padded: sample i of the new row = (i in window) ? conv[(i + Wp/2) mod Wp] - y[i - sw] : 0,
+  // evaluated on the fly as the source of the forward transform's first stage
   const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
   const float* y0 = Y + (long)dpl * g.uplane + (long)u0 * g.W;
   const float* y1 = y0 + g.W;
-  float2 v[EMAX];
-#pragma unroll
-  for (int k = 0; k < EMAX; ++k) {
-    const int i = tid + k * NT;
-    v[k] = make_float2(0.f, 0.f);
-    if (i < g.Wp) {
-      const int c = i - g.sw;
-      if (c >= 0 && c < g.W) {
-        const float2 z = s[wrap_add(i, hw, g.Wp)];
-        v[k] = make_float2(z.x - y0[c], v1 ? z.y - y1[c] : 0.f);
-      }
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < EMAX; ++k) {
-    const int i = tid + k * NT;
-    if (i < g.Wp) s[i] = v[k];
-  }
-  __syncthreads();
-  lds_fft<NT, EMAX, false>(s, plan, 1, make_fastdiv_dev1(), tid);
+  auto resid = [&](int i, int) {
+    const int c = i - g.sw;
+    if (c < 0 || c >= g.W) return make_float2(0.f, 0.f);
+    const float2 z = s[lds_slot<SK>(wrap_add(i, hw, g.Wp))];
+    return make_float2(z.x - y0[c], v1 ? z.y - y1[c] : 0.f);
+  };
+  fft_tile<NT, EMAX, false, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, resid, LdsNatural{});
   float2* o = Sout + pl * g.cplane + (long)(g.sh + u0) * g.cpitch;
-  untangle_store<NT>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
+  untangle_store<NT, SK>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
 }
 
 // ---- inverse rows -> gradient -> fused update --------------------------------------------
@@ -71,7 +58,27 @@ struct GdScalars {
   int first;       // fista: x_k aliases the iterate during the first update (gd.py:233,236)
 };
 
-template <int NT, int EMAX>
+static __device__ __forceinline__ void gd_update_one(float* LPC_RESTRICT X, float* LPC_RESTRICT AUX, long o,
+                                                      float gr, float al, const GdScalars& p) {
+  const float x = X[o];
+  if (p.kind == 0) {                       // gd.py:132-134
+    X[o] = fmaxf(x - al * gr, 0.f);
+  } else if (p.kind == 1) {                // gd.py:183-188
+    const float pp = AUX[o];
+    const float pn = p.mu * pp - al * gr;
+    const float xn = x + (p.negmu * pp + p.onepmu * pn);
+    AUX[o] = pn;
+    X[o] = fmaxf(xn, 0.f);
+  } else {                                 // gd.py:235-241
+    const float x1 = x - al * gr;
+    const float xk = fmaxf(x1, 0.f);
+    const float xp = p.first ? x1 : AUX[o];
+    X[o] = xk + p.coef * (xk - xp);
+    AUX[o] = xk;
+  }
+}
+
+template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan plan,
                                                         const float2* LPC_RESTRICT Sin,
                                                         float* LPC_RESTRICT X, float* LPC_RESTRICT AUX,
@@ -86,36 +93,19 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan pl
   const int sr0 = wrap_add(g.sh + u0, hh, g.Hp);
   const int sr1 = wrap_add(g.sh + (v1 ? u1 : u0), hh, g.Hp);
   const float2* sp = Sin + pl * g.cplane;
-  tangle_load<NT>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
+  tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
   __syncthreads();
-  lds_fft<NT, EMAX, true>(s, plan, 1, make_fastdiv_dev1(), tid);
   const float al = alpha[pl % g.C];
   const long base = pl * g.uplane + (long)u0 * g.W;
-  for (int c = tid; c < g.W; c += NT) {
-    const float2 z = s[wrap_add(g.sw + c, hw, g.Wp)];
-#pragma unroll
-    for (int r = 0; r < 2; ++r) {
-      if (r == 1 && !v1) break;
-      const long o = base + (long)r * g.W + c;
-      const float gr = r == 0 ? z.x : z.y;
-      const float x = X[o];
-      if (p.kind == 0) {                       // gd.py:132-134
-        X[o] = fmaxf(x - al * gr, 0.f);
-      } else if (p.kind == 1) {                // gd.py:183-188
-        const float pp = AUX[o];
-        const float pn = p.mu * pp - al * gr;
-        const float xn = x + (p.negmu * pp + p.onepmu * pn);
-        AUX[o] = pn;
-        X[o] = fmaxf(xn, 0.f);
-      } else {                                 // gd.py:235-241
-        const float x1 = x - al * gr;
-        const float xk = fmaxf(x1, 0.f);
-        const float xp = p.first ? x1 : AUX[o];
-        X[o] = xk + p.coef * (xk - xp);
-        AUX[o] = xk;
-      }
+  // the drain of the inverse transform hands each gradient sample straight to the fused update (shift + crop)
+  auto upd = [&](int i, int, float2 z) {
+    const int c = shifted_col(i, hw, g.sw, g.Wp);
+    if (c < g.W) {
+      gd_update_one(X, AUX, base + c, z.x, al, p);
+      if (v1) gd_update_one(X, AUX, base + g.W + c, z.y, al, p);
     }
-  }
+  };
+  fft_tile<NT, EMAX, true, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, upd);
 }
 
 // ---- reductions (set-up only): per-plane max/min with wavefront shuffles ---------------------

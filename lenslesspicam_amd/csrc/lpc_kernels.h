@@ -39,36 +39,56 @@ static __device__ __forceinline__ int wrap_add(int i, int d, int n) {  // (i + d
 // ===================================================================== row passes ==
 // Two real rows ride through ONE complex FFT of length Wp (re = row A, im = row B) and are
 // separated afterwards by Hermitian symmetry; works for even and odd Wp alike.
+// The first FFT stage pulls its inputs straight from global memory (source lambda) and the last
+// stage pushes its outputs straight out (sink lambda); LDS only carries the tile between stages
+// and the Hermitian (un)tangling, which pairs bins k and Wp-k held by different lanes.
+#define LPC_ROW_SMEM_BYTES(Wp, skew) ((size_t)((skew) ? lds_slots_skewed(Wp) : (Wp)) * sizeof(float2))
 
-// s[] holds Z = FFT(a + i b); writes A[k], B[k] for k in [0, Wc)
-template <int NT>
+// s[] holds Z = FFT(a + i b) in natural order; writes A[k], B[k] for k in [0, Wc)
+template <int NT, bool SK>
 static __device__ __forceinline__ void untangle_store(const float2* s, int Wp, int Wc, float2* outA,
                                                        float2* outB, bool validB, int tid) {
   for (int k = tid; k < Wc; k += NT) {
-    float2 zk = s[k];
-    float2 zn = s[k == 0 ? 0 : Wp - k];
+    float2 zk = s[lds_slot<SK>(k)];
+    float2 zn = s[lds_slot<SK>(k == 0 ? 0 : Wp - k)];
     outA[k] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
     if (validB) outB[k] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
   }
 }
 
 // builds Z[k] = A[k] + i B[k] over the full length from two half spectra (irfft semantics:
-// imaginary parts of the DC and Nyquist bins are ignored)
-template <int NT>
+// imaginary parts of the DC and Nyquist bins are ignored).  All loads are issued before the
+// first LDS write (unrolled to the compile-time bound) so they overlap in flight.
+template <int NT, int EMAX, bool SK>
 static __device__ __forceinline__ void tangle_load(float2* s, int Wp, int Wc, const float2* inA,
                                                     const float2* inB, bool validB, int tid) {
-  for (int k = tid; k < Wc; k += NT) {
-    float2 a = inA[k];
-    float2 b = validB ? inB[k] : make_float2(0.f, 0.f);
-    const bool selfconj = (k == 0) || (2 * k == Wp);
-    if (selfconj) { a.y = 0.f; b.y = 0.f; }
-    s[k] = make_float2(a.x - b.y, a.y + b.x);
-    if (!selfconj) s[Wp - k] = make_float2(a.x + b.y, b.x - a.y);
+  constexpr int EH = EMAX / 2 + 1;
+  float2 a[EH], b[EH];
+#pragma unroll
+  for (int q = 0; q < EH; ++q) {
+    const int k = tid + q * NT;
+    a[q] = make_float2(0.f, 0.f);
+    b[q] = make_float2(0.f, 0.f);
+    if (k < Wc) {
+      a[q] = inA[k];
+      if (validB) b[q] = inB[k];
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < EH; ++q) {
+    const int k = tid + q * NT;
+    if (k < Wc) {
+      float2 av = a[q], bv = b[q];
+      const bool selfconj = (k == 0) || (2 * k == Wp);
+      if (selfconj) { av.y = 0.f; bv.y = 0.f; }
+      s[lds_slot<SK>(k)] = make_float2(av.x - bv.y, av.y + bv.x);
+      if (!selfconj) s[lds_slot<SK>(Wp - k)] = make_float2(av.x + bv.y, bv.x - av.y);
+    }
   }
 }
 
 // ---- forward, ADMM: row r of array A and row r of array B -> spectra SA, SB ------------
-template <int NT, int EMAX>
+template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
                                                      const float* LPC_RESTRICT A,
                                                      const float* LPC_RESTRICT B,
@@ -80,11 +100,10 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
   const long pl = blockIdx.y;
   const float* a = A + pl * g.rplane + (long)row * g.rpitch;
   const float* b = B + pl * g.rplane + (long)row * g.rpitch;
-  for (int i = tid; i < g.Wp; i += NT) s[i] = make_float2(a[i], b[i]);
-  __syncthreads();
-  lds_fft<NT, EMAX, false>(s, plan, 1, make_fastdiv_dev1(), tid);
-  untangle_store<NT>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
-                     SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
+  auto src = [&](int i, int) { return make_float2(a[i], b[i]); };
+  fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
+  untangle_store<NT, SK>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
+                         SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
 }
 
 // ---- forward, generic: rows (2b, 2b+1) of ONE real source -> spectrum rows ------------
@@ -97,7 +116,7 @@ struct RealSrc {
   int out_row0;       // source row r lands in spectrum row out_row0 + r
 };
 
-template <int NT, int EMAX>
+template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, RealSrc src,
                                                    float2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
@@ -108,19 +127,18 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, R
   const bool v1 = r1 < src.nrows;
   const float* a = src.base + pl * src.plane_stride + (long)r0 * src.pitch;
   const float* b = src.base + pl * src.plane_stride + (long)r1 * src.pitch;
-  for (int i = tid; i < g.Wp; i += NT) {
+  auto in = [&](int i, int) {   // pad on load
     const int c = i - src.col0;
-    const bool in = (c >= 0) && (c < src.ncols);
-    s[i] = make_float2(in ? a[c] : 0.f, (in && v1) ? b[c] : 0.f);
-  }
-  __syncthreads();
-  lds_fft<NT, EMAX, false>(s, plan, 1, make_fastdiv_dev1(), tid);
+    const bool ok = (c >= 0) && (c < src.ncols);
+    return make_float2(ok ? a[c] : 0.f, (ok && v1) ? b[c] : 0.f);
+  };
+  fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, in, LdsNatural{});
   float2* o = S + pl * g.cplane + (long)(src.out_row0 + r0) * g.cpitch;
-  untangle_store<NT>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
+  untangle_store<NT, SK>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
 }
 
 // ---- inverse, ADMM: spectra SA, SB -> real arrays A, B (no shift, padded) ---------------
-template <int NT, int EMAX>
+template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, Fft1dPlan plan,
                                                      const float2* LPC_RESTRICT SA,
                                                      const float2* LPC_RESTRICT SB,
@@ -129,23 +147,19 @@ __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, Fft1dPlan plan,
   float2* s = (float2*)smem;
   const int tid = threadIdx.x, row = blockIdx.x;
   const long pl = blockIdx.y;
-  tangle_load<NT>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
-                  SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
+  tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
+                            SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
   __syncthreads();
-  lds_fft<NT, EMAX, true>(s, plan, 1, make_fastdiv_dev1(), tid);
   float* a = A + pl * g.rplane + (long)row * g.rpitch;
   float* b = B + pl * g.rplane + (long)row * g.rpitch;
-  for (int i = tid; i < g.Wp; i += NT) {
-    float2 z = s[i];
-    a[i] = z.x;
-    b[i] = z.y;
-  }
+  auto out = [&](int i, int, float2 v) { a[i] = v.x; b[i] = v.y; };
+  fft_tile<NT, EMAX, true, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
 }
 
 // ---- inverse, generic: spectrum rows -> ONE real sink with ifftshift (+ crop) -----------
 // Output row i of the shifted frame comes from spectrum row (i + Hp/2) mod Hp and output
-// column c from column (c + Wp/2) mod Wp (fft.ifftshift is a roll by -(n//2)).  That is pure
-// index arithmetic on the way out of LDS: exact, and no extra pass over HBM.
+// column c from FFT sample (c + Wp/2) mod Wp (fft.ifftshift is a roll by -(n//2)).  That is pure
+// index arithmetic in the sink of the last FFT stage: exact, and no extra pass over HBM.
 struct RealDst {
   float* base;
   long plane_stride;
@@ -155,7 +169,15 @@ struct RealDst {
   int ncols;       // Wp or W
 };
 
-template <int NT, int EMAX>
+// FFT sample i of a row lands in output column (i - Wp/2 - col0) mod Wp (if < ncols)
+static __device__ __forceinline__ int shifted_col(int i, int hw, int col0, int Wp) {
+  int c = i - hw - col0;
+  if (c < 0) c += Wp;
+  if (c < 0) c += Wp;
+  return c;
+}
+
+template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
                                                    const float2* LPC_RESTRICT S, RealDst dst) {
   LPC_DYN_SMEM(smem);
@@ -167,17 +189,19 @@ __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
   const int hh = g.Hp / 2, hw = g.Wp / 2;
   const int sr0 = wrap_add(dst.row0 + r0, hh, g.Hp);
   const int sr1 = wrap_add(dst.row0 + (v1 ? r1 : r0), hh, g.Hp);
-  tangle_load<NT>(s, g.Wp, g.Wc, S + pl * g.cplane + (long)sr0 * g.cpitch,
-                  S + pl * g.cplane + (long)sr1 * g.cpitch, v1, tid);
+  tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, S + pl * g.cplane + (long)sr0 * g.cpitch,
+                            S + pl * g.cplane + (long)sr1 * g.cpitch, v1, tid);
   __syncthreads();
-  lds_fft<NT, EMAX, true>(s, plan, 1, make_fastdiv_dev1(), tid);
   float* a = dst.base + pl * dst.plane_stride + (long)r0 * dst.pitch;
   float* b = dst.base + pl * dst.plane_stride + (long)r1 * dst.pitch;
-  for (int c = tid; c < dst.ncols; c += NT) {
-    float2 z = s[wrap_add(dst.col0 + c, hw, g.Wp)];
-    a[c] = z.x;
-    if (v1) b[c] = z.y;
-  }
+  auto out = [&](int i, int, float2 v) {
+    const int c = shifted_col(i, hw, dst.col0, g.Wp);
+    if (c < dst.ncols) {
+      a[c] = v.x;
+      if (v1) b[c] = v.y;
+    }
+  };
+  fft_tile<NT, EMAX, true, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
 }
 
 // ================================================================== column passes ==
@@ -196,7 +220,7 @@ struct ColPass {
   FastDiv tcdiv;    // fast divide by ntile_c
 };
 
-// plain pass over ONE spectrum array, in place
+// plain pass over ONE spectrum array, in place (global -> registers -> [LDS] -> registers -> global)
 template <int NT, int EMAX, bool INV>
 __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, Fft1dPlan plan, ColPass cp,
                                               float2* LPC_RESTRICT S) {
@@ -206,29 +230,25 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, Fft1dPlan plan, ColPas
   const int grp = (int)fd_div(blockIdx.x, cp.tcdiv);
   const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * cp.T;
   float2* base = S + (long)blockIdx.y * g.cplane + (long)grp * cp.gstride * g.cpitch + c0;
-  const int nelem = cp.N * cp.T;
-  for (int e = tid; e < nelem; e += NT) {
-    const int i = (int)fd_div((unsigned)e, cp.tdiv);
-    const int j = e - i * cp.T;
-    const int row = grp * cp.gstride + i * cp.istride;
-    float2 v = make_float2(0.f, 0.f);
-    if (c0 + j < g.Wc && (INV || (row >= cp.zr0 && row < cp.zr1))) {
-      v = base[(long)i * cp.istride * g.cpitch + j];
-      if (INV && cp.tw_mode == 2) v = cmul_conj(v, cp.twH[grp * i]);
+  const long rstep = (long)cp.istride * g.cpitch;
+  const int row0 = grp * cp.gstride;
+  auto in = [&](int i, int c) {
+    float2 x = make_float2(0.f, 0.f);
+    const int row = row0 + i * cp.istride;
+    if (c0 + c < g.Wc && (INV || (row >= cp.zr0 && row < cp.zr1))) x = base[i * rstep + c];
+    return x;
+  };
+  auto untwiddle = [&](int i, int, float2 x) {   // inverse pass A: conj four-step twiddle on the way in
+    return (INV && cp.tw_mode == 2) ? cmul_conj(x, cp.twH[grp * i]) : x;
+  };
+  auto out = [&](int i, int c, float2 x) {
+    if (c0 + c < g.Wc) {
+      if (!INV && cp.tw_mode == 1) x = cmul(x, cp.twH[grp * i]);
+      base[i * rstep + c] = x;
     }
-    s[e] = v;
-  }
-  __syncthreads();
-  lds_fft<NT, EMAX, INV>(s, plan, cp.T, cp.tdiv, tid);
-  for (int e = tid; e < nelem; e += NT) {
-    const int i = (int)fd_div((unsigned)e, cp.tdiv);
-    const int j = e - i * cp.T;
-    if (c0 + j < g.Wc) {
-      float2 v = s[e];
-      if (!INV && cp.tw_mode == 1) v = cmul(v, cp.twH[grp * i]);
-      base[(long)i * cp.istride * g.cpitch + j] = v;
-    }
-  }
+  };
+  if (INV) fft_tile<NT, EMAX, INV, false, false>(s, plan, cp.T, cp.tdiv, tid, in, out, untwiddle);
+  else fft_tile<NT, EMAX, INV, false, false>(s, plan, cp.T, cp.tdiv, tid, in, out);
 }
 
 // fused middle of a convolution: forward pass B -> multiply by the PSF spectrum (or its
@@ -241,39 +261,45 @@ __global__ __launch_bounds__(NT) void k_cols_mid_mul(PlaneGeom g, Fft1dPlan plan
   LPC_DYN_SMEM(smem);
   float2* s = (float2*)smem;
   const int tid = threadIdx.x;
+  const int T = cp.T;
   const int grp = (int)fd_div(blockIdx.x, cp.tcdiv);
-  const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * cp.T;
+  const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * T;
   const long rowoff = ((long)grp * cp.gstride) * g.cpitch + c0;
   float2* base = S + (long)blockIdx.y * g.cplane + rowoff;
   const float2* hb = Hs + (long)((int)blockIdx.y % psf_planes) * g.cplane + rowoff;
-  const int nelem = cp.N * cp.T;
-  for (int e = tid; e < nelem; e += NT) {
-    const int i = (int)fd_div((unsigned)e, cp.tdiv);
-    const int j = e - i * cp.T;
-    const int row = grp * cp.gstride + i * cp.istride;
-    float2 v = make_float2(0.f, 0.f);
-    if (c0 + j < g.Wc && row >= cp.zr0 && row < cp.zr1) v = base[(long)i * cp.istride * g.cpitch + j];
-    s[e] = v;
+  const int nelem = cp.N * T;
+  const long rstep = (long)cp.istride * g.cpitch;
+  const int row0 = grp * cp.gstride;
+  float2 h[EMAX];
+#pragma unroll
+  for (int k = 0; k < EMAX; ++k) {   // PSF spectrum tile: in flight during the forward transform
+    const int e = tid + k * NT;
+    h[k] = make_float2(0.f, 0.f);
+    if (e < nelem) {
+      const int i = (int)fd_div((unsigned)e, cp.tdiv);
+      const int j = e - i * T;
+      if (c0 + j < g.Wc) h[k] = hb[i * rstep + j];
+    }
   }
-  __syncthreads();
-  lds_fft<NT, EMAX, false>(s, plan, cp.T, cp.tdiv, tid);
-  for (int e = tid; e < nelem; e += NT) {
-    const int i = (int)fd_div((unsigned)e, cp.tdiv);
-    const int j = e - i * cp.T;
-    if (c0 + j < g.Wc) {
-      float2 h = hb[(long)i * cp.istride * g.cpitch + j];
-      float2 v = s[e];
-      v = conjH ? cmul_conj(v, h) : cmul(v, h);
-      s[e] = cscale(v, hscale);
+  auto in = [&](int i, int c) {
+    const int row = row0 + i * cp.istride;
+    return (c0 + c < g.Wc && row >= cp.zr0 && row < cp.zr1) ? base[i * rstep + c] : make_float2(0.f, 0.f);
+  };
+  fft_tile<NT, EMAX, false, false, false>(s, plan, T, cp.tdiv, tid, in, LdsNatural{});
+#pragma unroll
+  for (int k = 0; k < EMAX; ++k) {
+    const int e = tid + k * NT;
+    if (e < nelem) {
+      float2 x = s[e];
+      x = conjH ? cmul_conj(x, h[k]) : cmul(x, h[k]);
+      s[e] = cscale(x, hscale);
     }
   }
   __syncthreads();
-  lds_fft<NT, EMAX, true>(s, plan, cp.T, cp.tdiv, tid);
-  for (int e = tid; e < nelem; e += NT) {
-    const int i = (int)fd_div((unsigned)e, cp.tdiv);
-    const int j = e - i * cp.T;
-    if (c0 + j < g.Wc) base[(long)i * cp.istride * g.cpitch + j] = s[e];
-  }
+  auto out = [&](int i, int c, float2 x) {
+    if (c0 + c < g.Wc) base[i * rstep + c] = x;
+  };
+  fft_tile<NT, EMAX, true, false, true>(s, plan, T, cp.tdiv, tid, LdsNatural{}, out);
 }
 
 // fused middle of one ADMM iteration (4-FFT form).  In: SA = rows+colsA transform of
@@ -281,7 +307,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_mul(PlaneGeom g, Fft1dPlan plan
 //   Vh  = Rdiv * (Rh + s * conj(H) * Ah)        (Rdiv already holds 1/(Hp*Wp))
 //   HVh = s * H * Vh                             (s = spectral phase of ifftshift)
 // then inverse pass B; SA <- Vh path, SB <- HVh path.
-// LDS tile: [N][2T] -- columns 0..T-1 belong to SA, T..2T-1 to SB.
+// Tile: [N][2T] -- columns 0..T-1 belong to SA, T..2T-1 to SB.
 template <int NT, int EMAX>
 __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan plan, ColPass cp,
                                                        float2* LPC_RESTRICT SA,
@@ -303,43 +329,52 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
   const int pp = (int)blockIdx.y % g.DC;
   const float2* hb = Hs + (long)pp * g.cplane + rowoff;
   const float* rb = Rdiv + (long)pp * g.cplane + rowoff;
-  const int nelem = cp.N * T2;
-  for (int e = tid; e < nelem; e += NT) {
-    const int i = (int)fd_div((unsigned)e, t2div);
-    const int jj = e - i * T2;
-    const int j = jj < T ? jj : jj - T;
-    float2 v = make_float2(0.f, 0.f);
-    if (c0 + j < g.Wc) v = (jj < T ? ba : bb)[(long)i * cp.istride * g.cpitch + j];
-    s[e] = v;
-  }
-  __syncthreads();
-  lds_fft<NT, EMAX, false>(s, plan, T2, t2div, tid);
   const int npair = cp.N * T;
-  for (int e = tid; e < npair; e += NT) {
-    const int i = (int)fd_div((unsigned)e, cp.tdiv);
-    const int j = e - i * T;
-    if (c0 + j < g.Wc) {
-      const long off = (long)i * cp.istride * g.cpitch + j;
-      const float2 h = hb[off];
-      const float rd = rb[off];
-      const float2 ph = cmul(phr[grp * cp.gstride + i * cp.istride], phc[c0 + j]);
-      const float2 rh = s[i * T2 + j];
-      const float2 ah = s[i * T2 + T + j];
-      float2 t = cmul(cmul_conj(ah, h), ph);          // s * conj(H) * Ah
-      float2 vh = cscale(cadd(rh, t), rd);
-      float2 hv = cmul(cmul(vh, h), ph);
-      s[i * T2 + j] = vh;
-      s[i * T2 + T + j] = hv;
+  const long rstep = (long)cp.istride * g.cpitch;
+  constexpr int EP = (EMAX + 1) / 2;
+  float2 h[EP];
+  float rd[EP];
+#pragma unroll
+  for (int k = 0; k < EP; ++k) {      // spectral constants: in flight during the forward FFT
+    const int e = tid + k * NT;
+    h[k] = make_float2(0.f, 0.f);
+    rd[k] = 0.f;
+    if (e < npair) {
+      const int i = (int)fd_div((unsigned)e, cp.tdiv);
+      const int j = e - i * T;
+      if (c0 + j < g.Wc) { h[k] = hb[i * rstep + j]; rd[k] = rb[i * rstep + j]; }
+    }
+  }
+  auto in = [&](int i, int c) {
+    const int j = c < T ? c : c - T;
+    return (c0 + j < g.Wc) ? (c < T ? ba : bb)[i * rstep + j] : make_float2(0.f, 0.f);
+  };
+  fft_tile<NT, EMAX, false, false, false>(s, plan, T2, t2div, tid, in, LdsNatural{});
+#pragma unroll
+  for (int k = 0; k < EP; ++k) {
+    const int e = tid + k * NT;
+    if (e < npair) {
+      const int i = (int)fd_div((unsigned)e, cp.tdiv);
+      const int j = e - i * T;
+      if (c0 + j < g.Wc) {
+        const float2 hh = h[k];
+        const float2 ph = cmul(phr[grp * cp.gstride + i * cp.istride], phc[c0 + j]);
+        const float2 rh = s[i * T2 + j];
+        const float2 ah = s[i * T2 + T + j];
+        float2 t = cmul(cmul_conj(ah, hh), ph);          // s * conj(H) * Ah
+        float2 vh = cscale(cadd(rh, t), rd[k]);
+        float2 hv = cmul(cmul(vh, hh), ph);
+        s[i * T2 + j] = vh;
+        s[i * T2 + T + j] = hv;
+      }
     }
   }
   __syncthreads();
-  lds_fft<NT, EMAX, true>(s, plan, T2, t2div, tid);
-  for (int e = tid; e < nelem; e += NT) {
-    const int i = (int)fd_div((unsigned)e, t2div);
-    const int jj = e - i * T2;
-    const int j = jj < T ? jj : jj - T;
-    if (c0 + j < g.Wc) (jj < T ? ba : bb)[(long)i * cp.istride * g.cpitch + j] = s[e];
-  }
+  auto out = [&](int i, int c, float2 x) {
+    const int j = c < T ? c : c - T;
+    if (c0 + j < g.Wc) (c < T ? ba : bb)[i * rstep + j] = x;
+  };
+  fft_tile<NT, EMAX, true, false, true>(s, plan, T2, t2div, tid, LdsNatural{}, out);
 }
 
 // ============================================================ ADMM spatial kernel ==
