@@ -87,9 +87,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
-    if world > 1:
+    if "RANK" in os.environ and "WORLD_SIZE" in os.environ:  # launched by torchrun (any world size)
         import torch.distributed as dist
 
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (see task environment notes)
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 

@@ -530,7 +530,8 @@ static int admm_iterate(Engine* e, int n_iter) {
   const PlaneGeom& g = e->g;
   constexpr int TH = 16, TW = 64, NT = 256;
   const size_t k1_smem = (size_t)(2 * (TH + 2) * (TW + 2) + (TH + 1) * TW + TH * (TW + 1)) * sizeof(float);
-  const dim3 k1_grid((g.Wp + TW - 1) / TW, (g.Hp + TH - 1) / TH, e->P);
+  const unsigned tiles_x = (g.Wp + TW - 1) / TW, tiles_y = (g.Hp + TH - 1) / TH;
+  const dim3 k1_grid(tiles_x * tiles_y, e->P, 1);
   float2* SA = e->S;
   float2* SB = e->S + (size_t)e->P * g.cplane;
   const bool split = e->N1 > 1;
@@ -541,7 +542,7 @@ static int admm_iterate(Engine* e, int n_iter) {
     LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial<TH, TW, NT>, k1_grid, NT, k1_smem, g, sc, (const float*)Vc,
                     (const float*)Vo, (const float*)e->HV, e->X, e->xi, (const float*)e->eta0[e->ecur],
                     (const float*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
-                    (const float*)e->Y, e->Rsp, e->Aarr));
+                    (const float*)e->Y, e->Rsp, e->Aarr, tiles_x));
     e->ecur ^= 1;
     e->first = false;
     LPC_OK(dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NTc, auto EM, auto SK) {

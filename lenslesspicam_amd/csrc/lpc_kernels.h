@@ -411,7 +411,8 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
                                                       float* LPC_RESTRICT eta1_out,
                                                       float* LPC_RESTRICT rho,
                                                       const float* LPC_RESTRICT Y,
-                                                      float* LPC_RESTRICT Rsp, float* LPC_RESTRICT Aout) {
+                                                      float* LPC_RESTRICT Rsp, float* LPC_RESTRICT Aout,
+                                                      unsigned tiles_x) {
   LPC_DYN_SMEM(smem);
   constexpr int VW = TW + 2, VH = TH + 2;
   float* sV = (float*)smem;                 // [VH][VW], local (ly+1, lx+1)
@@ -419,8 +420,15 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
   float* sQ0 = sO + VH * VW;                // [TH+1][TW]
   float* sQ1 = sQ0 + (TH + 1) * TW;         // [TH][TW+1]
   const int tid = threadIdx.x;
-  const int r0 = blockIdx.y * TH, c0 = blockIdx.x * TW;
-  const long pl = blockIdx.z;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed
+  // only).  Give each XCD a contiguous band of tiles so that the halo lines shared by neighbouring
+  // tiles are re-read from the SAME L2 instead of from the fabric.
+  const unsigned nblk = gridDim.x, b = blockIdx.x;
+  const unsigned q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+  const unsigned tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  const unsigned ty_ = tile / tiles_x;
+  const int r0 = (int)ty_ * TH, c0 = (int)(tile - ty_ * tiles_x) * TW;
+  const long pl = blockIdx.y;
   const long poff = pl * g.rplane;
   const float* v = V + poff;
   const float* vo = Vold + poff;
