@@ -269,8 +269,8 @@ static __device__ __forceinline__ void fft_stage(float2* s, int n, int BT, FastD
 // Postcondition: result in natural order, barrier passed.  Unnormalised in both directions.
 template <int NT, int EMAX, bool INV, bool SKEW = false>
 static __device__ __forceinline__ void lds_fft(float2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
-                                                int tid) {
-  for (int st = 0; st < p.nst; ++st) {
+                                                int tid, int first_stage = 0) {
+  for (int st = first_stage; st < p.nst; ++st) {
     const int ns = p.ns[st];
     const FastDiv nd = p.nsdiv[st];
     const int ts = p.twstep[st];
@@ -300,16 +300,81 @@ struct LdsNatural {};
 // compile-time bound EMAX): with a run-time trip count the compiler emits load / wait / ds_write
 // per element and the kernel serialises on HBM latency (measured: +25 % on the column passes).
 // SRC_LDS: src itself reads the LDS tile, so a barrier separates its reads from the refill.
+// First Stockham stage (ns = 1: no twiddles) fused into the tile fill: every thread loads exactly the
+// R inputs of its own butterflies (element j + m*n/R, still coalesced across lanes), transforms them
+// in the staging registers and writes the stage OUTPUT to LDS -- one LDS round trip and two barriers
+// less per transform.  Register need = the EMAX staging registers the plain fill uses anyway.
+template <int R, int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, class Src, class Fix>
+static __device__ __forceinline__ void fft_first_stage_fused(float2* s, int n, int BT, FastDiv btdiv, int tid,
+                                                              Src& src, Fix& fix) {
+  constexpr int MAXB = (EMAX + R - 1) / R;
+  const int nb = n / R;
+  const int nwork = nb * BT;
+  float2 v[MAXB][R];
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int w = tid + b * NT;
+    if (w < nwork) {
+      const int j = (int)fd_div((unsigned)w, btdiv);
+      const int c = w - j * BT;
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[b][m] = src(j + m * nb, c);
+    }
+  }
+  if (SRC_LDS) __syncthreads();
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int w = tid + b * NT;
+    if (w < nwork) {
+      const int j = (int)fd_div((unsigned)w, btdiv);
+      const int c = w - j * BT;
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[b][m] = fix(j + m * nb, c, v[b][m]);
+      Dft<R, INV>::run(v[b]);
+      const int ob = lds_slot<SKEW>(j * R * BT + c);
+      if (SKEW) {  // row mode, BT == 1: element j*R + m (R % 8 == 0 by plan.skew_ok)
+#pragma unroll
+        for (int m = 0; m < R; ++m) s[ob + m + (m >> 3)] = v[b][m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < R; ++m) s[ob + m * BT] = v[b][m];
+      }
+    }
+  }
+  __syncthreads();
+}
+
 struct NoFix {
   __device__ __forceinline__ float2 operator()(int, int, float2 v) const { return v; }
 };
 
 // fix(i, c, v): optional per-element transform applied AFTER the batched loads have landed (e.g. the
 // four-step twiddle of the inverse pass A): its own table gathers then do not delay the tile loads.
-template <int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, class Src, class Dst, class Fix = NoFix>
+// FUSE1: fuse the first stage into the fill (fft_first_stage_fused).  A per-call-site choice, measured
+// on MI355X (profiles/r01b_notes.md): it pays for the forward row pass (-10 %) and the inverse column
+// pass A (-13 %), costs +25 % on the forward pass A, and compiling BOTH paths slows the fused middle.
+template <int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, bool FUSE1 = false, class Src, class Dst,
+          class Fix = NoFix>
 static __device__ __forceinline__ void fft_tile(float2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
                                                  int tid, Src src, Dst dst, Fix fix = Fix()) {
   const int nelem = p.n * BT;
+  int first_stage = 0;
+  if constexpr (FUSE1 && !std::is_same<Src, LdsNatural>::value) {
+    if (p.nst >= 1) {
+#define LPC_FUSED(R) fft_first_stage_fused<R, NT, EMAX, INV, SKEW, SRC_LDS>(s, p.n, BT, btdiv, tid, src, fix)
+      switch (p.radix[0]) {
+        case 8: LPC_FUSED(8); break;
+        case 6: LPC_FUSED(6); break;
+        case 5: LPC_FUSED(5); break;
+        case 4: LPC_FUSED(4); break;
+        case 3: LPC_FUSED(3); break;
+        default: LPC_FUSED(2); break;
+      }
+#undef LPC_FUSED
+      first_stage = 1;
+    }
+  }
+  if (first_stage == 0)
   if constexpr (!std::is_same<Src, LdsNatural>::value) {
     float2 v[EMAX];
 #pragma unroll
@@ -335,7 +400,7 @@ static __device__ __forceinline__ void fft_tile(float2* s, const Fft1dPlan& p, i
     }
     __syncthreads();
   }
-  lds_fft<NT, EMAX, INV, SKEW>(s, p, BT, btdiv, tid);
+  lds_fft<NT, EMAX, INV, SKEW>(s, p, BT, btdiv, tid, first_stage);
   if constexpr (!std::is_same<Dst, LdsNatural>::value) {
 #pragma unroll
     for (int k = 0; k < EMAX; ++k) {

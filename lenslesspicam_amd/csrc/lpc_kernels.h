@@ -101,7 +101,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
   const float* a = A + pl * g.rplane + (long)row * g.rpitch;
   const float* b = B + pl * g.rplane + (long)row * g.rpitch;
   auto src = [&](int i, int) { return make_float2(a[i], b[i]); };
-  fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
+  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
   untangle_store<NT, SK>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
                          SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
 }
@@ -132,7 +132,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, R
     const bool ok = (c >= 0) && (c < src.ncols);
     return make_float2(ok ? a[c] : 0.f, (ok && v1) ? b[c] : 0.f);
   };
-  fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, in, LdsNatural{});
+  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, in, LdsNatural{});
   float2* o = S + pl * g.cplane + (long)(src.out_row0 + r0) * g.cpitch;
   untangle_store<NT, SK>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
 }
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, Fft1dPlan plan, ColPas
       base[i * rstep + c] = x;
     }
   };
-  if (INV) fft_tile<NT, EMAX, INV, false, false>(s, plan, cp.T, cp.tdiv, tid, in, out, untwiddle);
+  if (INV) fft_tile<NT, EMAX, INV, false, false, true>(s, plan, cp.T, cp.tdiv, tid, in, out, untwiddle);
   else fft_tile<NT, EMAX, INV, false, false>(s, plan, cp.T, cp.tdiv, tid, in, out);
 }
 
