@@ -269,8 +269,8 @@ static __device__ __forceinline__ void fft_stage(float2* s, int n, int BT, FastD
 // Postcondition: result in natural order, barrier passed.  Unnormalised in both directions.
 template <int NT, int EMAX, bool INV, bool SKEW = false>
 static __device__ __forceinline__ void lds_fft(float2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
-                                                int tid, int first_stage = 0) {
-  for (int st = first_stage; st < p.nst; ++st) {
+                                                int tid, int first_stage = 0, int skip_last = 0) {
+  for (int st = first_stage; st < p.nst - skip_last; ++st) {
     const int ns = p.ns[st];
     const FastDiv nd = p.nsdiv[st];
     const int ts = p.twstep[st];
@@ -344,6 +344,45 @@ static __device__ __forceinline__ void fft_first_stage_fused(float2* s, int n, i
   __syncthreads();
 }
 
+// Last Stockham stage fused into the drain: outputs go from the butterfly registers straight to the sink
+// (coalesced: consecutive lanes hold consecutive output elements) -- again one LDS round trip and two
+// barriers less.  The tile must have passed a barrier after the previous stage's writes.
+template <int R, int NT, int EMAX, bool INV, bool SKEW, class Dst>
+static __device__ __forceinline__ void fft_last_stage_fused(float2* s, int n, int BT, FastDiv btdiv, int ns,
+                                                             FastDiv nsdiv, int twstep,
+                                                             const float2* LPC_RESTRICT tw, int tid, Dst& dst) {
+  constexpr int MAXB = (EMAX + R - 1) / R;
+  const int nb = n / R;
+  const int nwork = nb * BT;
+  const int istride = nb * BT;
+  const int rs = SKEW ? istride + (istride >> 3) : istride;
+  float2 v[MAXB][R];
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int w = tid + b * NT;
+    if (w < nwork) {
+      const int rb = lds_slot<SKEW>(w);
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[b][m] = s[rb + m * rs];
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int w = tid + b * NT;
+    if (w < nwork) {
+      const int j = (int)fd_div((unsigned)w, btdiv);
+      const int c = w - j * BT;
+      const int jq = (int)fd_div((unsigned)j, nsdiv);
+      const int k = j - jq * ns;
+      if (ns > 1) twiddle_mul<R, INV>(v[b], tw, k * twstep);
+      Dft<R, INV>::run(v[b]);
+      const int oi = jq * ns * R + k;
+#pragma unroll
+      for (int m = 0; m < R; ++m) dst(oi + m * ns, c, v[b][m]);
+    }
+  }
+}
+
 struct NoFix {
   __device__ __forceinline__ float2 operator()(int, int, float2 v) const { return v; }
 };
@@ -353,8 +392,9 @@ struct NoFix {
 // FUSE1: fuse the first stage into the fill (fft_first_stage_fused).  A per-call-site choice, measured
 // on MI355X (profiles/r01b_notes.md): it pays for the forward row pass (-10 %) and the inverse column
 // pass A (-13 %), costs +25 % on the forward pass A, and compiling BOTH paths slows the fused middle.
-template <int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, bool FUSE1 = false, class Src, class Dst,
-          class Fix = NoFix>
+// FUSEL: fuse the last stage into the drain (fft_last_stage_fused); same per-call-site rule.
+template <int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, bool FUSE1 = false, bool FUSEL = false, class Src,
+          class Dst, class Fix = NoFix>
 static __device__ __forceinline__ void fft_tile(float2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
                                                  int tid, Src src, Dst dst, Fix fix = Fix()) {
   const int nelem = p.n * BT;
@@ -399,6 +439,24 @@ static __device__ __forceinline__ void fft_tile(float2* s, const Fft1dPlan& p, i
       }
     }
     __syncthreads();
+  }
+  if constexpr (FUSEL && !std::is_same<Dst, LdsNatural>::value) {
+    if (p.nst - first_stage >= 1) {
+      lds_fft<NT, EMAX, INV, SKEW>(s, p, BT, btdiv, tid, first_stage, 1);
+      const int st = p.nst - 1;
+#define LPC_FUSEDL(R) \
+  fft_last_stage_fused<R, NT, EMAX, INV, SKEW>(s, p.n, BT, btdiv, p.ns[st], p.nsdiv[st], p.twstep[st], p.tw, tid, dst)
+      switch (p.radix[st]) {
+        case 8: LPC_FUSEDL(8); break;
+        case 6: LPC_FUSEDL(6); break;
+        case 5: LPC_FUSEDL(5); break;
+        case 4: LPC_FUSEDL(4); break;
+        case 3: LPC_FUSEDL(3); break;
+        default: LPC_FUSEDL(2); break;
+      }
+#undef LPC_FUSEDL
+      return;
+    }
   }
   lds_fft<NT, EMAX, INV, SKEW>(s, p, BT, btdiv, tid, first_stage);
   if constexpr (!std::is_same<Dst, LdsNatural>::value) {

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan,
     const float2 z = s[lds_slot<SK>(wrap_add(i, hw, g.Wp))];
     return make_float2(z.x - y0[c], v1 ? z.y - y1[c] : 0.f);
   };
-  fft_tile<NT, EMAX, false, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, resid, LdsNatural{});
+  fft_tile<NT, EMAX, false, SK, true, true>(s, plan, 1, make_fastdiv_dev1(), tid, resid, LdsNatural{});
   float2* o = Sout + pl * g.cplane + (long)(g.sh + u0) * g.cpitch;
   untangle_store<NT, SK>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
 }
@@ -105,7 +105,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan pl
       if (v1) gd_update_one(X, AUX, base + g.W + c, z.y, al, p);
     }
   };
-  fft_tile<NT, EMAX, true, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, upd);
+  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, upd);
 }
 
 // ---- reductions (set-up only): per-plane max/min with wavefront shuffles ---------------------

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, Fft1dPlan plan,
   float* a = A + pl * g.rplane + (long)row * g.rpitch;
   float* b = B + pl * g.rplane + (long)row * g.rpitch;
   auto out = [&](int i, int, float2 v) { a[i] = v.x; b[i] = v.y; };
-  fft_tile<NT, EMAX, true, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
+  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
 }
 
 // ---- inverse, generic: spectrum rows -> ONE real sink with ifftshift (+ crop) -----------
@@ -201,9 +201,12 @@ __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
       if (v1) b[c] = v.y;
     }
   };
-  fft_tile<NT, EMAX, true, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
+  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
 }
 
+#ifndef LPC_COLS_FUSEL
+#define LPC_COLS_FUSEL true
+#endif
 // ================================================================== column passes ==
 struct ColPass {
   int N;            // transform length of this pass
@@ -247,8 +250,8 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, Fft1dPlan plan, ColPas
       base[i * rstep + c] = x;
     }
   };
-  if (INV) fft_tile<NT, EMAX, INV, false, false, true>(s, plan, cp.T, cp.tdiv, tid, in, out, untwiddle);
-  else fft_tile<NT, EMAX, INV, false, false>(s, plan, cp.T, cp.tdiv, tid, in, out);
+  if (INV) fft_tile<NT, EMAX, INV, false, false, true, LPC_COLS_FUSEL>(s, plan, cp.T, cp.tdiv, tid, in, out, untwiddle);
+  else fft_tile<NT, EMAX, INV, false, false, false, LPC_COLS_FUSEL>(s, plan, cp.T, cp.tdiv, tid, in, out);
 }
 
 // fused middle of a convolution: forward pass B -> multiply by the PSF spectrum (or its
@@ -299,7 +302,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_mul(PlaneGeom g, Fft1dPlan plan
   auto out = [&](int i, int c, float2 x) {
     if (c0 + c < g.Wc) base[i * rstep + c] = x;
   };
-  fft_tile<NT, EMAX, true, false, true>(s, plan, T, cp.tdiv, tid, LdsNatural{}, out);
+  fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL>(s, plan, T, cp.tdiv, tid, LdsNatural{}, out);
 }
 
 // fused middle of one ADMM iteration (4-FFT form).  In: SA = rows+colsA transform of
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
     const int j = c < T ? c : c - T;
     if (c0 + j < g.Wc) (c < T ? ba : bb)[i * rstep + j] = x;
   };
-  fft_tile<NT, EMAX, true, false, true>(s, plan, T2, t2div, tid, LdsNatural{}, out);
+  fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL>(s, plan, T2, t2div, tid, LdsNatural{}, out);
 }
 
 // ============================================================ ADMM spatial kernel ==
