@@ -535,10 +535,24 @@ static int admm_iterate(Engine* e, int n_iter) {
   float2* SA = e->S;
   float2* SB = e->S + (size_t)e->P * g.cplane;
   const bool split = e->N1 > 1;
+  // 16-byte-lane kernel whenever the padded width allows aligned float4 rows (every BASELINE size does)
+  static int force_scalar = -1;
+  if (force_scalar < 0) force_scalar = std::getenv("LPC_K1_SCALAR") ? 1 : 0;
+  const bool vec4 = (g.Wp % 4 == 0) && !force_scalar;
+  constexpr int TH4 = 8, TW4 = 256;
+  const unsigned tiles_x4 = (g.Wp + TW4 - 1) / TW4, tiles_y4 = (g.Hp + TH4 - 1) / TH4;
+  const dim3 k1_grid4(tiles_x4 * tiles_y4, e->P, 1);
+  const size_t k1_smem4 = (size_t)2 * (TH4 + 2) * (TW4 + 8) * sizeof(float);
   for (int it = 0; it < n_iter; ++it) {
     float* Vc = e->V[e->vcur];
     float* Vo = e->V[e->vcur ^ 1];
     AdmmScalars sc = admm_scalars(e);
+    if (vec4)
+      LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT>, k1_grid4, NT, k1_smem4, g, sc, (const float*)Vc,
+                      (const float*)Vo, (const float*)e->HV, e->X, e->xi, (const float*)e->eta0[e->ecur],
+                      (const float*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
+                      (const float*)e->Y, e->Rsp, e->Aarr, tiles_x4));
+    else
     LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial<TH, TW, NT>, k1_grid, NT, k1_smem, g, sc, (const float*)Vc,
                     (const float*)Vo, (const float*)e->HV, e->X, e->xi, (const float*)e->eta0[e->ecur],
                     (const float*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,

@@ -204,6 +204,9 @@ __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
   fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
 }
 
+#ifndef LPC_MID_FUSE1
+#define LPC_MID_FUSE1 false  // measured: no gain on the fused middle (profiles/r01b_notes.md)
+#endif
 #ifndef LPC_COLS_FUSEL
 #define LPC_COLS_FUSEL true
 #endif
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_mul(PlaneGeom g, Fft1dPlan plan
     const int row = row0 + i * cp.istride;
     return (c0 + c < g.Wc && row >= cp.zr0 && row < cp.zr1) ? base[i * rstep + c] : make_float2(0.f, 0.f);
   };
-  fft_tile<NT, EMAX, false, false, false>(s, plan, T, cp.tdiv, tid, in, LdsNatural{});
+  fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1>(s, plan, T, cp.tdiv, tid, in, LdsNatural{});
 #pragma unroll
   for (int k = 0; k < EMAX; ++k) {
     const int e = tid + k * NT;
@@ -352,7 +355,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
     const int j = c < T ? c : c - T;
     return (c0 + j < g.Wc) ? (c < T ? ba : bb)[i * rstep + j] : make_float2(0.f, 0.f);
   };
-  fft_tile<NT, EMAX, false, false, false>(s, plan, T2, t2div, tid, in, LdsNatural{});
+  fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1>(s, plan, T2, t2div, tid, in, LdsNatural{});
 #pragma unroll
   for (int k = 0; k < EP; ++k) {
     const int e = tid + k * NT;
@@ -514,6 +517,150 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
     X[o] = xn;
     Rsp[o] = (p.mu3 * wn - rhov) + (d1 + d2);
     Aout[o] = p.mu1 * xn - xiv;
+  }
+}
+
+// ---- K1, 16-byte-lane version (padded width a multiple of 4) -----------------------------------
+// Same arithmetic as k_admm_spatial, re-shaped for HBM: every lane moves float4 (a wave covers 1 KiB of
+// one image row per array), tiles are 8 rows x 256 columns, only V / V_old are staged in LDS (+1 halo,
+// circular); q = mu2 U - eta of the lower / right neighbour is RECOMPUTED in registers from the LDS
+// tile and one extra (L1/L2-resident) load of eta instead of being exchanged through LDS, so there is
+// one barrier and 21 KiB of LDS per workgroup (7 workgroups per CU).
+static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// eta' and q for one pixel and one difference direction
+static __device__ __forceinline__ void tv_component(const AdmmScalars& p, float vc, float vn, float oc, float on,
+                                                     float eta, float& eta_new, float& q) {
+  const float psi = vn - vc;                       // finite_diff: roll(+1) - x   (admm.py:349-359)
+  if (!p.first) {
+    const float uo = soft_thresh_dev((on - oc) + eta / p.mu2, p.thr);
+    eta = eta + p.mu2 * (psi - uo);                // pending eta update of the previous iteration
+  }
+  const float un = soft_thresh_dev(psi + eta / p.mu2, p.thr);
+  eta_new = eta;
+  q = p.mu2 * un - eta;
+}
+
+template <int TH, int NT>
+__global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars p,
+                                                         const float* LPC_RESTRICT V,
+                                                         const float* LPC_RESTRICT Vold,
+                                                         const float* LPC_RESTRICT HV,
+                                                         float* LPC_RESTRICT X, float* LPC_RESTRICT xi,
+                                                         const float* LPC_RESTRICT eta0,
+                                                         const float* LPC_RESTRICT eta1,
+                                                         float* LPC_RESTRICT eta0_out,
+                                                         float* LPC_RESTRICT eta1_out,
+                                                         float* LPC_RESTRICT rho,
+                                                         const float* LPC_RESTRICT Y,
+                                                         float* LPC_RESTRICT Rsp, float* LPC_RESTRICT Aout,
+                                                         unsigned tiles_x) {
+  LPC_DYN_SMEM(smem);
+  constexpr int TW = 256, LP = TW + 8;          // LDS row: [3] = col -1, [4..259] = cols 0..255, [260] = col 256
+  constexpr int VH = TH + 2;
+  float* sV = (float*)smem;                     // [VH][LP]
+  float* sO = sV + VH * LP;
+  const int tid = threadIdx.x;
+  const unsigned nblk = gridDim.x, bid = blockIdx.x;   // XCD-aware tile order (see k_admm_spatial)
+  const unsigned qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  const unsigned tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+  const unsigned ty_ = tile / tiles_x;
+  const int r0 = (int)ty_ * TH, c0 = (int)(tile - ty_ * tiles_x) * TW;
+  const long pl = blockIdx.y;
+  const long poff = pl * g.rplane;
+  const float* v = V + poff;
+  const float* vo = Vold + poff;
+  auto wrap_r = [&](int r) { r = r < 0 ? r + g.Hp : r; return r >= g.Hp ? r % g.Hp : r; };
+  auto wrap_c = [&](int c) { c = c < 0 ? c + g.Wp : c; return c >= g.Wp ? c % g.Wp : c; };
+
+  // ---- stage V, V_old: body as float4, the two halo columns as scalars ----
+  for (int e = tid; e < VH * (TW / 4); e += NT) {
+    const int ly = e / (TW / 4), l4 = e - ly * (TW / 4);
+    const long o = (long)wrap_r(r0 + ly - 1) * g.rpitch + wrap_c(c0 + 4 * l4);
+    st4(sV + ly * LP + 4 + 4 * l4, ld4(v + o));
+    st4(sO + ly * LP + 4 + 4 * l4, p.first ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(vo + o));
+  }
+  for (int e = tid; e < VH * 2; e += NT) {
+    const int ly = e >> 1, side = e & 1;
+    const long o = (long)wrap_r(r0 + ly - 1) * g.rpitch + wrap_c(side ? c0 + TW : c0 - 1);
+    sV[ly * LP + (side ? 4 + TW : 3)] = v[o];
+    sO[ly * LP + (side ? 4 + TW : 3)] = p.first ? 0.f : vo[o];
+  }
+  __syncthreads();
+
+  const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
+  const float* y = Y + (long)dpl * g.uplane;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int gc = c0 + 4 * lane;
+#pragma unroll
+  for (int rr = 0; rr < TH / (NT / 64); ++rr) {
+    const int ly = wv + rr * (NT / 64);
+    const int gr = r0 + ly;
+    if (gr >= g.Hp || gc >= g.Wp) continue;
+    const long o = poff + (long)gr * g.rpitch + gc;
+    const long o_dn = poff + (long)wrap_r(gr + 1) * g.rpitch + gc;        // eta0 of the row below
+    const long o_rt = poff + (long)gr * g.rpitch + wrap_c(gc + 4);        // eta1 of the pixel right of the quad
+    // global loads first (all independent)
+    const float4 hv4 = ld4(HV + o), xi4 = ld4(xi + o), rho4 = ld4(rho + o);
+    const float4 e04 = ld4(eta0 + o), e14 = ld4(eta1 + o), e0d4 = ld4(eta0 + o_dn);
+    const float e1r = eta1[o_rt];
+    float4 xo4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!p.first) xo4 = ld4(X + o);
+    // LDS neighbourhood: rows ly-1, ly, ly+1 of the quad, plus the pixel left and right of it
+    const float* rowm = sV + ly * LP + 4 + 4 * lane;        // global row gr-1  (local ly)
+    const float* rowc = rowm + LP;                          // gr
+    const float* rowp = rowc + LP;                          // gr+1
+    const float* orm = sO + ly * LP + 4 + 4 * lane;
+    const float* orc = orm + LP;
+    const float* orp = orc + LP;
+    const float4 vm4 = ld4(rowm), vc4 = ld4(rowc), vp4 = ld4(rowp);
+    const float4 om4 = ld4(orm), oc4 = ld4(orc), op4 = ld4(orp);
+    const float vl = rowc[-1], vr = rowc[4], ol = orc[-1], orr = orc[4];
+    const float vcs[6] = {vl, vc4.x, vc4.y, vc4.z, vc4.w, vr};       // cols gc-1 .. gc+4 of row gr
+    const float ocs[6] = {ol, oc4.x, oc4.y, oc4.z, oc4.w, orr};
+    const float vms[4] = {vm4.x, vm4.y, vm4.z, vm4.w}, vps[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
+    const float oms[4] = {om4.x, om4.y, om4.z, om4.w}, ops[4] = {op4.x, op4.y, op4.z, op4.w};
+    const float hvs[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, xis[4] = {xi4.x, xi4.y, xi4.z, xi4.w};
+    const float rhs[4] = {rho4.x, rho4.y, rho4.z, rho4.w}, xos[4] = {xo4.x, xo4.y, xo4.z, xo4.w};
+    const float e0s[4] = {e04.x, e04.y, e04.z, e04.w}, e0ds[4] = {e0d4.x, e0d4.y, e0d4.z, e0d4.w};
+    const float e1s[5] = {e14.x, e14.y, e14.z, e14.w, e1r};
+    float q1[5], e1n[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)   // column-difference component at cols gc .. gc+4 (the 5th only for q)
+      tv_component(p, vcs[i + 1], vcs[i], ocs[i + 1], ocs[i], e1s[i], e1n[i], q1[i]);
+    float xin[4], e0n[4], rhn[4], xn[4], rs[4], as[4];
+    const bool row_in = (gr >= g.sh) && (gr < g.sh + g.H);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      float q0c, q0d, dummy;
+      tv_component(p, vcs[i + 1], vms[i], ocs[i + 1], oms[i], e0s[i], e0n[i], q0c);   // this pixel
+      tv_component(p, vps[i], vcs[i + 1], ops[i], ocs[i + 1], e0ds[i], dummy, q0d);   // the pixel below
+      const float vc = vcs[i + 1], hv = hvs[i];
+      float xiv = xis[i], rhov = rhs[i];
+      if (!p.first) {
+        xiv = xiv + p.mu1 * (hv - xos[i]);
+        const float wo = fmaxf(rhov / p.mu3 + ocs[i + 1], 0.f);
+        rhov = rhov + p.mu3 * (vc - wo);
+      }
+      const int cc = gc + i;
+      const bool inside = row_in && (cc >= g.sw) && (cc < g.sw + g.W);
+      const float yv = inside ? y[(long)(gr - g.sh) * g.W + (cc - g.sw)] : 0.f;
+      const float xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
+      const float wn = fmaxf(rhov / p.mu3 + vc, 0.f);
+      const float d1 = q0d - q0c;
+      const float d2 = q1[i + 1] - q1[i];
+      xin[i] = xiv; rhn[i] = rhov; xn[i] = xnew;
+      rs[i] = (p.mu3 * wn - rhov) + (d1 + d2);
+      as[i] = p.mu1 * xnew - xiv;
+    }
+    st4(xi + o, make_float4(xin[0], xin[1], xin[2], xin[3]));
+    st4(rho + o, make_float4(rhn[0], rhn[1], rhn[2], rhn[3]));
+    st4(X + o, make_float4(xn[0], xn[1], xn[2], xn[3]));
+    st4(eta0_out + o, make_float4(e0n[0], e0n[1], e0n[2], e0n[3]));
+    st4(eta1_out + o, make_float4(e1n[0], e1n[1], e1n[2], e1n[3]));
+    st4(Rsp + o, make_float4(rs[0], rs[1], rs[2], rs[3]));
+    st4(Aout + o, make_float4(as[0], as[1], as[2], as[3]));
   }
 }
 
