@@ -191,8 +191,8 @@ static int build_plan(Engine* e, Fft1dPlan& p, int n) {
   while (r % 2 == 0) { r /= 2; ++a; }
   while (r % 3 == 0) { r /= 3; ++b3; }
   std::vector<int> rad;
-  // few, fat stages: 16s first (the twiddle-free first stage should be the biggest), then the
-  // remaining power of two (pairing a lone 2 with a 3 into a radix-6 stage), then 5s and 3s
+  // few, fat stages: choose the number of radix-6 stages (each pairs a 2 with a 3) that minimises the
+  // stage count; ties keep more radix-8 stages.  8s first (the twiddle-free first stage should be fat).
   static int max_radix = -1;
   if (max_radix < 0) {
     const char* env = std::getenv("LPC_MAX_RADIX");  // 16 needs a -DLPC_ENABLE_R16 build
@@ -201,19 +201,27 @@ static int build_plan(Engine* e, Fft1dPlan& p, int n) {
     max_radix = 8;
 #endif
   }
+  int c5 = 0;
+  { int t = r; while (t % 5 == 0) { t /= 5; ++c5; } }
+  int best_k6 = 0, best_cnt = 1 << 30;
+  for (int k6 = 0; k6 <= std::min(a, b3); ++k6) {
+    const int a2 = a - k6;
+    const int cnt = k6 + a2 / 3 + (a2 % 3 ? 1 : 0) + (b3 - k6) + c5;
+    if (cnt < best_cnt) { best_cnt = cnt; best_k6 = k6; }
+  }
   if (max_radix >= 16) {
-    for (int i = 0; i < a / 4; ++i) rad.push_back(16);
-    a %= 4;
+    best_k6 = (a % 4 == 1 && b3 > 0) ? 1 : 0;
+    for (int i = 0; i < (a - best_k6) / 4; ++i) rad.push_back(16);
+    a = (a - best_k6) % 4;
   } else {
+    a -= best_k6;
     for (int i = 0; i < a / 3; ++i) rad.push_back(8);
     a %= 3;
   }
-  switch (a) {
-    case 3: rad.push_back(8); break;
-    case 2: rad.push_back(4); break;
-    case 1: if (b3 > 0) { rad.push_back(6); --b3; } else rad.push_back(2); break;
-    default: break;
-  }
+  for (int i = 0; i < best_k6; ++i) rad.push_back(6);
+  b3 -= best_k6;
+  if (a == 2) rad.push_back(4);
+  if (a == 1) rad.push_back(2);
   while (r % 5 == 0) { r /= 5; rad.push_back(5); }
   for (int i = 0; i < b3; ++i) rad.push_back(3);
   if (r != 1) return fail("length " + std::to_string(n) + " is not 5-smooth");

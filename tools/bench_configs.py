@@ -48,8 +48,14 @@ for B in (64, 8):
     psf, y = rand_inputs(1, 270, 480, 3, B)
     r = lpa.ADMM(psf); r.set_data(y[:, None])
     t = timed(lambda: r.apply_batch(n_iter=20), reps=3)
+    r._handle.profile_enable(True)
+    r.apply_batch(n_iter=20)
+    prof = r._handle.profile_read()
+    r._handle.profile_enable(False)
+    kern = {k: {"ms": round(v[0], 4), "GBps": round(r._handle.kernel_bytes(i) / (v[0] * 1e-3) / 1e9, 0)}
+            for i, (k, v) in enumerate(prof.items()) if v[1]}
     out.append({"config": f"C4 batch {B} x 270x480x3 ADMM 20 it on 1 GPU", "ms_per_batch": t * 1e3,
-                "frame_it_per_s": B * 20 / t})
+                "frame_it_per_s": B * 20 / t, "kernels": kern})
     del r
 # C5: 16 depth planes 1080x1920x3, ADMM 50 iterations
 psf, y = rand_inputs(16, 1080, 1920, 3, 1)
