@@ -143,6 +143,22 @@ def main():
     rec._handle.profile_enable(False)
     log(f"timed region done: {elapsed:.3f} s for {args.steps} step(s)")
 
+    # achievable-HBM yardstick measured in the same run: plain device-to-device copy
+    copy_gbps = None
+    if rank == 0:
+        src_buf = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=dev)   # 1 GiB
+        dst_buf = torch.empty_like(src_buf)
+        dst_buf.copy_(src_buf)
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        for _ in range(10):
+            dst_buf.copy_(src_buf)
+        ev1.record()
+        torch.cuda.synchronize()
+        copy_gbps = 10 * 2 * src_buf.numel() * 4 / (ev0.elapsed_time(ev1) * 1e-3) / 1e9
+        del src_buf, dst_buf
+
     result = None
     if rank == 0:
         total_iters = world * args.steps * n_iter
@@ -194,6 +210,8 @@ def main():
                 "traffic": traffic,
             },
             "kernels": kernels,
+            "alg_GB_per_iteration": round(sum(v["alg_GB"] for v in kernels.values()), 3),
+            "device_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
             "hbm_workspace_GB": round(rec._handle.workspace_bytes() / 1e9, 2),
         }
 

@@ -9,7 +9,7 @@ gradient-descent family (vanilla / Nesterov / FISTA).
 Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
 leg may import this module, and only as the *checker* (or the timed CPU
 baseline) -- never as the thing that is shipped.  The product package
-``lenslesspicam_amd`` must not import it (tests/test_layout.py enforces that).
+``lenslesspicam_amd`` must not import it (tests/test_abi_and_layout.py enforces that).
 
 Parity pin: the reference's own tests hold no numerical values for this path
 (SURVEY.md section 8c), so this oracle is pinned against outputs of the reference
