@@ -97,7 +97,8 @@ int lpc_set_momentum(lpc_handle h, double p, double mu, double tk);
 int lpc_iterate(lpc_handle h, int n_iter, void* stream);
 
 /* _form_image(): ADMM crop + clamp (admm.py:331-338), GD family projection (gd.py:136-140).
- * dev_out: (B,D,H,W,C).  The engine returns a clamped COPY and leaves its state untouched. */
+ * dev_out: (B,D,H,W,C).  Like the reference, the ADMM clamp is an in-place side effect on the image
+ * estimate: it is visible to the W-update of the following iterations (and to "image_est"). */
 int lpc_form_image(lpc_handle h, float* dev_out, void* stream);
 
 /* inspection (tests, warm starts).  name: "image_est" (solver state shape), and for ADMM

@@ -97,6 +97,11 @@ struct lpc_engine {
         *Rsp = nullptr, *Aarr = nullptr;
   float *eta0[2] = {nullptr, nullptr}, *eta1[2] = {nullptr, nullptr};  // ping-pong (halo reads)
   int vcur = 0, ecur = 0;
+  // the reference clamps the image estimate IN PLACE whenever _form_image runs (admm.py:331-338);
+  // only the W-update ever sees that clamped copy: Vw[0] = V as seen by the next iteration's W,
+  // Vw[1] = V as seen by the previous iteration's W (needed to recompute W_old).  Null = same as V.
+  float* Vw[2] = {nullptr, nullptr};
+  bool vw_cur = false, vw_old = false;
   // GD family state (un-padded planes)
   float *gx = nullptr, *gaux = nullptr;  // x and (p | xk_prev)
   float* galpha = nullptr;               // [C] device
@@ -522,6 +527,7 @@ static int admm_reset(Engine* e) {
   for (float* z : zero) LPC_RT(rt::memset_async(z, 0, rb, e->stream));
   e->vcur = 0;
   e->ecur = 0;
+  e->vw_cur = e->vw_old = false;
   if (e->has_init) {
     LPC_RT(rt::copy_d2d_async(e->V[0], e->init_est, rb, e->stream));
     // admm.py:172-176: forward_out = convolve(V0)
@@ -559,12 +565,17 @@ static int admm_iterate(Engine* e, int n_iter) {
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT>, k1_grid4, NT, k1_smem4, g, sc, (const float*)Vc,
                       (const float*)Vo, (const float*)e->HV, e->X, e->xi, (const float*)e->eta0[e->ecur],
                       (const float*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
-                      (const float*)e->Y, e->Rsp, e->Aarr, tiles_x4));
+                      (const float*)e->Y, e->Rsp, e->Aarr, tiles_x4,
+                      (const float*)(e->vw_cur ? e->Vw[0] : nullptr), (const float*)(e->vw_old ? e->Vw[1] : nullptr)));
     else
     LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial<TH, TW, NT>, k1_grid, NT, k1_smem, g, sc, (const float*)Vc,
                     (const float*)Vo, (const float*)e->HV, e->X, e->xi, (const float*)e->eta0[e->ecur],
                     (const float*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
-                    (const float*)e->Y, e->Rsp, e->Aarr, tiles_x));
+                    (const float*)e->Y, e->Rsp, e->Aarr, tiles_x,
+                    (const float*)(e->vw_cur ? e->Vw[0] : nullptr), (const float*)(e->vw_old ? e->Vw[1] : nullptr)));
+    std::swap(e->Vw[0], e->Vw[1]);  // this iteration's "V for W" becomes the next one's "V_old for W_old"
+    e->vw_old = e->vw_cur;
+    e->vw_cur = false;
     e->ecur ^= 1;
     e->first = false;
     LPC_OK(dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NTc, auto EM, auto SK) {
@@ -773,8 +784,20 @@ int lpc_form_image(lpc_handle e, float* dev_out, void* stream) {
   e->stream = (lpcStream_t)stream;
   const PlaneGeom& g = e->g;
   const int nimg = e->cfg.batch * e->cfg.depth;
-  if (e->cfg.algo == LPC_ALGO_ADMM)  // crop + clamp (admm.py:331-338) on a copy
-    return planar_to_hwc(e, e->V[e->vcur], dev_out, nimg, g.H, g.W, g.rpitch, g.rplane, g.sh, g.sw, 1);
+  if (e->cfg.algo == LPC_ALGO_ADMM) {  // crop + clamp (admm.py:331-338)
+    LPC_OK(planar_to_hwc(e, e->V[e->vcur], dev_out, nimg, g.H, g.W, g.rpitch, g.rplane, g.sh, g.sw, 1));
+    // ... which the reference applies IN PLACE to its state: remember the clamped estimate for the
+    // W-updates of the next two iterations (everything else keeps using the un-clamped V, exactly
+    // like the reference's cached _Psi_out / _forward_out do)
+    if (!e->Vw[0]) {
+      LPC_OK(dev_alloc(e, &e->Vw[0], (size_t)g.rplane * e->P));
+      LPC_OK(dev_alloc(e, &e->Vw[1], (size_t)g.rplane * e->P));
+    }
+    LPC_OK(launch_k(e, -1, k_clamp_window_copy<256>, grid1d((long)g.Hp * g.rpitch, 256, e->P), 256, 0, g,
+                    (const float*)e->V[e->vcur], e->Vw[0]));
+    e->vw_cur = true;
+    return 0;
+  }
   if (e->cfg.algo >= LPC_ALGO_GD)    // projection (gd.py:136-140)
     return planar_to_hwc(e, e->gx, dev_out, nimg, g.H, g.W, g.W, g.uplane, 0, 0, 1);
   return fail("lpc_form_image: operator-only handle");
@@ -791,7 +814,7 @@ int lpc_get_state(lpc_handle e, const char* name, float* dev_out, void* stream) 
   auto out_padded = [&](float* src) {
     return planar_to_hwc(e, src, dev_out, nimg, g.Hp, g.Wp, g.rpitch, g.rplane, 0, 0, 0);
   };
-  if (nm == "image_est") return out_padded(e->V[e->vcur]);
+  if (nm == "image_est") return out_padded(e->vw_cur ? e->Vw[0] : e->V[e->vcur]);
   if (nm == "forward_out") return out_padded(e->HV);
   if (nm == "X") return out_padded(e->X);
   // the rest needs the pending dual update applied: materialise into scratch
@@ -802,7 +825,8 @@ int lpc_get_state(lpc_handle e, const char* name, float* dev_out, void* stream) 
   int rc = launch_k(e, -1, k_admm_flush<256>, grid1d((long)g.Hp * g.Wp, 256, e->P), 256, 0, g, sc,
                     (const float*)e->V[e->vcur], (const float*)e->V[e->vcur ^ 1], (const float*)e->HV,
                     (const float*)e->X, (const float*)e->xi, (const float*)e->eta0[e->ecur],
-                    (const float*)e->eta1[e->ecur], (const float*)e->rho, scratch, ostride);
+                    (const float*)e->eta1[e->ecur], (const float*)e->rho, scratch, ostride,
+                    (const float*)(e->vw_old ? e->Vw[1] : nullptr));
   if (!rc) {
     if (nm == "xi") rc = out_padded(scratch + 0 * ostride);
     else if (nm == "rho") rc = out_padded(scratch + 3 * ostride);

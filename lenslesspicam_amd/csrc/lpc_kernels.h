@@ -418,7 +418,8 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
                                                       float* LPC_RESTRICT rho,
                                                       const float* LPC_RESTRICT Y,
                                                       float* LPC_RESTRICT Rsp, float* LPC_RESTRICT Aout,
-                                                      unsigned tiles_x) {
+                                                      unsigned tiles_x, const float* LPC_RESTRICT VWc,
+                                                      const float* LPC_RESTRICT VWo) {
   LPC_DYN_SMEM(smem);
   constexpr int VW = TW + 2, VH = TH + 2;
   float* sV = (float*)smem;                 // [VH][VW], local (ly+1, lx+1)
@@ -503,13 +504,13 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
     if (!p.first) {
       const float xo = X[o];
       xiv = xiv + p.mu1 * (hv - xo);
-      const float wo = fmaxf(rhov / p.mu3 + sO[li], 0.f);
+      const float wo = fmaxf(rhov / p.mu3 + (VWo ? VWo[o] : sO[li]), 0.f);
       rhov = rhov + p.mu3 * (vc - wo);
     }
     const bool inside = (gr >= g.sh) && (gr < g.sh + g.H) && (gc >= g.sw) && (gc < g.sw + g.W);
     const float yv = inside ? y[(long)(gr - g.sh) * g.W + (gc - g.sw)] : 0.f;
     const float xn = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
-    const float wn = fmaxf(rhov / p.mu3 + vc, 0.f);
+    const float wn = fmaxf(rhov / p.mu3 + (VWc ? VWc[o] : vc), 0.f);
     const float d1 = sQ0[(ly + 1) * TW + lx] - sQ0[ly * TW + lx];
     const float d2 = sQ1[ly * (TW + 1) + lx + 1] - sQ1[ly * (TW + 1) + lx];
     xi[o] = xiv;
@@ -555,7 +556,8 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
                                                          float* LPC_RESTRICT rho,
                                                          const float* LPC_RESTRICT Y,
                                                          float* LPC_RESTRICT Rsp, float* LPC_RESTRICT Aout,
-                                                         unsigned tiles_x) {
+                                                         unsigned tiles_x, const float* LPC_RESTRICT VWc,
+                                                         const float* LPC_RESTRICT VWo) {
   LPC_DYN_SMEM(smem);
   constexpr int TW = 256, LP = TW + 8;          // LDS row: [3] = col -1, [4..259] = cols 0..255, [260] = col 256
   constexpr int VH = TH + 2;
@@ -607,6 +609,12 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
     const float e1r = eta1[o_rt];
     float4 xo4 = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!p.first) xo4 = ld4(X + o);
+    // the image estimate as the W-update sees it: differs from V only for the two iterations that follow
+    // an in-place clamp by _form_image (admm.py:331-338), see lpc_form_image
+    float4 vwc4 = make_float4(0.f, 0.f, 0.f, 0.f), vwo4 = vwc4;
+    if (VWc) vwc4 = ld4(VWc + o);
+    if (VWo) vwo4 = ld4(VWo + o);
+    const float vwcs[4] = {vwc4.x, vwc4.y, vwc4.z, vwc4.w}, vwos[4] = {vwo4.x, vwo4.y, vwo4.z, vwo4.w};
     // LDS neighbourhood: rows ly-1, ly, ly+1 of the quad, plus the pixel left and right of it
     const float* rowm = sV + ly * LP + 4 + 4 * lane;        // global row gr-1  (local ly)
     const float* rowc = rowm + LP;                          // gr
@@ -640,14 +648,14 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
       float xiv = xis[i], rhov = rhs[i];
       if (!p.first) {
         xiv = xiv + p.mu1 * (hv - xos[i]);
-        const float wo = fmaxf(rhov / p.mu3 + ocs[i + 1], 0.f);
+        const float wo = fmaxf(rhov / p.mu3 + (VWo ? vwos[i] : ocs[i + 1]), 0.f);
         rhov = rhov + p.mu3 * (vc - wo);
       }
       const int cc = gc + i;
       const bool inside = row_in && (cc >= g.sw) && (cc < g.sw + g.W);
       const float yv = inside ? y[(long)(gr - g.sh) * g.W + (cc - g.sw)] : 0.f;
       const float xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
-      const float wn = fmaxf(rhov / p.mu3 + vc, 0.f);
+      const float wn = fmaxf(rhov / p.mu3 + (VWc ? vwcs[i] : vc), 0.f);
       const float d1 = q0d - q0c;
       const float d2 = q1[i + 1] - q1[i];
       xin[i] = xiv; rhn[i] = rhov; xn[i] = xnew;
@@ -675,7 +683,7 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
                                                     const float* LPC_RESTRICT eta0,
                                                     const float* LPC_RESTRICT eta1,
                                                     const float* LPC_RESTRICT rho, float* LPC_RESTRICT out,
-                                                    long ostride) {
+                                                    long ostride, const float* LPC_RESTRICT VWo) {
   // out planes of size ostride*: 0 xi', 1 eta0', 2 eta1', 3 rho', 4 U0, 5 U1, 6 W
   const long n = (long)g.Hp * g.Wp;
   const long pl = blockIdx.y;
@@ -690,7 +698,7 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
       const float oc = Vold[o], vc = V[o];
       u0 = soft_thresh_dev((Vold[ou] - oc) + e0 / p.mu2, p.thr);
       u1 = soft_thresh_dev((Vold[ol] - oc) + e1 / p.mu2, p.thr);
-      w = fmaxf(rh / p.mu3 + oc, 0.f);
+      w = fmaxf(rh / p.mu3 + (VWo ? VWo[o] : oc), 0.f);
       xiv = xiv + p.mu1 * (HV[o] - X[o]);
       e0 = e0 + p.mu2 * ((V[ou] - vc) - u0);
       e1 = e1 + p.mu2 * ((V[ol] - vc) - u1);
@@ -743,6 +751,20 @@ __global__ __launch_bounds__(NT) void k_planar_to_hwc(float* LPC_RESTRICT src, f
       if (clamp_src) src[so] = 0.f;
     }
     dst[img * n + e] = v;
+  }
+}
+
+// dst = src with the sensor window clamped at 0 (the reference's in-place clamp of ADMM._form_image)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_clamp_window_copy(PlaneGeom g, const float* LPC_RESTRICT src,
+                                                           float* LPC_RESTRICT dst) {
+  const long n = (long)g.Hp * g.rpitch;
+  const long pl = blockIdx.y;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const int r = (int)(e / g.rpitch), c = (int)(e - (long)r * g.rpitch);
+    float v = src[pl * g.rplane + e];
+    if (r >= g.sh && r < g.sh + g.H && c >= g.sw && c < g.sw + g.W && v < 0.f) v = 0.f;
+    dst[pl * g.rplane + e] = v;
   }
 }
 

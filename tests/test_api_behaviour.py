@@ -111,7 +111,12 @@ def test_plot_and_save_hooks(backend, small, tmp_path):
     assert sorted(os.listdir(tmp_path)) == ["3.png", "6.png"]
     plain = lpa.ADMM(psf)
     plain.set_data(y)
-    assert np.array_equal(plain.apply(n_iter=6, disp_iter=None), out[0])  # display never perturbs the iterates
+    # displaying after iteration 3 clamps the state in place, in the reference (recon.py:580-583 ->
+    # admm.py:331-338) and here alike: the result equals apply(3) + apply(3, reset=False), not apply(6)
+    staged = lpa.ADMM(psf)
+    staged.set_data(y)
+    staged.apply(n_iter=3, disp_iter=None)
+    assert np.array_equal(staged.apply(n_iter=3, disp_iter=None, reset=False), out[0])
 
 
 def test_background_subtraction_is_cumulative_like_reference(backend, small):
