@@ -92,6 +92,12 @@ int lpc_reset(lpc_handle h, void* stream);
  * FISTA: overrides tk like FISTA.reset(tk) gd.py:227-233.  Call after lpc_reset. */
 int lpc_set_momentum(lpc_handle h, double p, double mu, double tk);
 
+/* Unrolled ADMM (lensless/recon/unrolled_admm.py:133-234): iteration i (counted from the last reset)
+ * uses mu1[i], mu2[i], mu3[i], tau[i]; the last entry is held beyond n.  n <= 0 clears the schedule and
+ * returns to the constructor's constants. */
+int lpc_set_admm_schedule(lpc_handle h, int n, const double* mu1, const double* mu2, const double* mu3,
+                          const double* tau);
+
 /* ---- the hot loop: `for i in range(n_iter): self._update(i)`  recon.py:575-576 ------ */
 /* exactly n_iter iterations, asynchronous on `stream`; no early exit exists on this path */
 int lpc_iterate(lpc_handle h, int n_iter, void* stream);

@@ -11,7 +11,8 @@ from .gd import (FISTA, GradientDescent, GradientDescentUpdate, NesterovGradient
                  apply_gradient_descent, non_neg)
 from .recon import ReconstructionAlgorithm
 from .rfft_convolve import RealFFTConvolve2D
+from .unrolled_admm import UnrolledADMM
 
 __all__ = ["ADMM", "FISTA", "GradientDescent", "GradientDescentUpdate", "NesterovGradientDescent",
-           "RealFFTConvolve2D", "ReconstructionAlgorithm", "apply_admm", "apply_gradient_descent", "non_neg"]
+           "RealFFTConvolve2D", "ReconstructionAlgorithm", "UnrolledADMM", "apply_admm", "apply_gradient_descent", "non_neg"]
 __version__ = "0.1.0"

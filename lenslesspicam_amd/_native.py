@@ -70,6 +70,8 @@ class Lib:
             "lpc_reset": [vp, vp],
             "lpc_set_momentum": [vp, C.c_double, C.c_double, C.c_double],
             "lpc_iterate": [vp, C.c_int, vp],
+            "lpc_set_admm_schedule": [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_double)],
             "lpc_form_image": [vp, fp, vp],
             "lpc_get_state": [vp, C.c_char_p, fp, vp],
             "lpc_profile_enable": [vp, C.c_int],
@@ -146,6 +148,14 @@ class Handle:
     def set_momentum(self, p=0.0, mu=0.9, tk=0.0):
         self._c(self.lib.dll.lpc_set_momentum(self.h, p, mu, tk))
 
+    def set_admm_schedule(self, mu1, mu2, mu3, tau):
+        n = len(mu1)
+        arr = [(C.c_double * n)(*[float(v) for v in a]) for a in (mu1, mu2, mu3, tau)]
+        self._c(self.lib.dll.lpc_set_admm_schedule(self.h, n, *arr))
+
+    def clear_admm_schedule(self):
+        self._c(self.lib.dll.lpc_set_admm_schedule(self.h, 0, None, None, None, None))
+
     def iterate(self, n, stream=0):
         self._c(self.lib.dll.lpc_iterate(self.h, int(n), stream))
 
@@ -190,6 +200,12 @@ def default_lib() -> Lib:
                 "lenslesspicam_amd needs a HIP device (MI355X); none is visible and there is no CPU path."
             )
         torch.cuda.init()
+        if not os.path.exists(DEFAULT_LIB):
+            # fresh checkout on a GPU box (the .so is git-ignored): compile the HIP sources once, in-tree.
+            # This builds the product library itself -- there still is no other execution path.
+            from . import build as _build
+
+            _build.build_hip(force=True, verbose=False)
         _default = Lib(DEFAULT_LIB)
         if not _default.backend().startswith("hip"):
             raise NativeError(f"refusing non-HIP backend {_default.backend()!r} in the product path")

@@ -86,7 +86,9 @@ struct lpc_engine {
 
   // spectral constants
   float2* Hs = nullptr;     // [Ppsf] PSF spectrum, permuted row order, norm applied
-  float* Rdiv = nullptr;    // ADMM [Ppsf]
+  float* Gabs = nullptr;    // ADMM: |PsiT Psi| spectrum, ONE plane (identical for every channel)
+  std::vector<double> sched[4];  // optional per-iteration mu1, mu2, mu3, tau (unrolled ADMM)
+  double last_par[4] = {0, 0, 0, 0};  // parameters of the most recent iteration
   float2* phr = nullptr;    // [Hp] ifftshift phase, stored row order
   float2* phc = nullptr;    // [Wc]
   float2* twH = nullptr;
@@ -475,14 +477,26 @@ static int planar_to_hwc(Engine* e, float* src, float* dst, int nimg, int rows, 
 }
 
 // ------------------------------------------------------------------------------ ADMM --
-static AdmmScalars admm_scalars(const Engine* e) {
+// parameters of iteration `it` (since reset): the schedule if one is set, else the constructor's
+static void admm_params(const Engine* e, long it, double out[4]) {
   const lpc_config& c = e->cfg;
+  const double dflt[4] = {c.mu1, c.mu2, c.mu3, c.tau};
+  for (int k = 0; k < 4; ++k) {
+    const std::vector<double>& v = e->sched[k];
+    out[k] = v.empty() ? dflt[k] : v[(size_t)std::min<long>(it, (long)v.size() - 1)];
+  }
+}
+
+static AdmmScalars admm_scalars(const Engine* e, const double cur[4]) {
   AdmmScalars p;
-  p.mu1 = (float)c.mu1; p.mu2 = (float)c.mu2; p.mu3 = (float)c.mu3;
-  p.thr = (float)(c.tau / c.mu2);                 // admm.py:246: python-double division, then float32
+  p.mu1 = (float)cur[0]; p.mu2 = (float)cur[1]; p.mu3 = (float)cur[2];
+  p.thr = (float)(cur[3] / cur[1]);               // admm.py:246: python-double division, then float32
   p.m_in = 1.0f / (1.0f + p.mu1);                 // admm.py:193 in float32
   p.m_out = 1.0f / (0.0f + p.mu1);
   p.first = e->first ? 1 : 0;
+  const double* prev = e->first ? cur : e->last_par;
+  p.mu1p = (float)prev[0]; p.mu2p = (float)prev[1]; p.mu3p = (float)prev[2];
+  p.thrp = (float)(prev[3] / prev[1]);
   return p;
 }
 
@@ -492,13 +506,13 @@ static int admm_alloc(Engine* e) {
   float** bufs[] = {&e->V[0], &e->V[1], &e->HV, &e->X, &e->xi, &e->eta0[0], &e->eta0[1], &e->eta1[0],
                     &e->eta1[1], &e->rho, &e->Rsp, &e->Aarr};
   for (float** b : bufs) LPC_OK(dev_alloc(e, b, rp));
-  LPC_OK(dev_alloc(e, &e->Rdiv, (size_t)g.cplane * e->Ppsf));
+  LPC_OK(dev_alloc(e, &e->Gabs, (size_t)g.cplane));
   return 0;
 }
 
 static int admm_setup_constants(Engine* e) {
-  // R_divmat = 1/(mu1 |H* H| + mu2 |PsiT Psi| + mu3)  (admm.py:186-190), with the inverse
-  // FFT's 1/(Hp*Wp) folded in.  The gram spectrum is produced by the engine's own forward
+  // R_divmat = 1/(mu1 |H* H| + mu2 |PsiT Psi| + mu3)  (admm.py:186-190) is formed inside the middle
+  // kernel; here only |PsiT Psi| is prepared.  The gram spectrum is produced by the engine's own forward
   // transform of the 5-point stencil (admm.py:385-397) so that it lands in the permuted row order.
   const PlaneGeom& g = e->g;
   float* stencil = e->Rsp;  // scratch: one padded plane
@@ -513,10 +527,8 @@ static int admm_setup_constants(Engine* e) {
   LPC_OK(upload(e, stencil, host.data(), host.size() * sizeof(float)));
   float2* Gs = e->S;  // scratch spectrum plane
   LPC_OK(fft2_forward_setup(e, src_padded(e, stencil), Gs, 1));
-  const float scale = 1.0f / ((float)g.Hp * (float)g.Wp);
-  LPC_OK(launch_k(e, -1, k_admm_rdiv<256>, grid1d((long)g.Hp * g.cpitch, 256, e->Ppsf), 256, 0, g,
-                  (const float2*)e->Hs, (const float2*)Gs, e->Rdiv, (float)e->cfg.mu1, (float)e->cfg.mu2,
-                  (float)e->cfg.mu3, scale));
+  LPC_OK(launch_k(e, -1, k_abs_complex<256>, grid1d((long)g.cplane, 256), 256, 0, (const float2*)Gs, e->Gabs,
+                  (long)g.cplane));
   return 0;
 }
 
@@ -560,7 +572,9 @@ static int admm_iterate(Engine* e, int n_iter) {
   for (int it = 0; it < n_iter; ++it) {
     float* Vc = e->V[e->vcur];
     float* Vo = e->V[e->vcur ^ 1];
-    AdmmScalars sc = admm_scalars(e);
+    double par[4];
+    admm_params(e, e->iters_done, par);
+    AdmmScalars sc = admm_scalars(e, par);
     if (vec4)
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT>, k1_grid4, NT, k1_smem4, g, sc, (const float*)Vc,
                       (const float*)Vo, (const float*)e->HV, e->X, e->xi, (const float*)e->eta0[e->ecur],
@@ -593,7 +607,8 @@ static int admm_iterate(Engine* e, int n_iter) {
         constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
         return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<nt, em>, grid, nt,
                         (size_t)cp.N * cp.T * 2 * sizeof(float2), g, e->planB, cp, SA, SB, (const float2*)e->Hs,
-                        (const float*)e->Rdiv, (const float2*)e->phr, (const float2*)e->phc, t2);
+                        (const float*)e->Gabs, (const float2*)e->phr, (const float2*)e->phc, t2, sc.mu1, sc.mu2,
+                        sc.mu3, 1.0f / ((float)g.Hp * (float)g.Wp));
       }));
     }
     if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, true, 0, g.Hp, LPC_K_COL_A_INV));
@@ -604,6 +619,7 @@ static int admm_iterate(Engine* e, int n_iter) {
                       LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const float2*)SA, (const float2*)SB, Vo, e->HV);
     }));
     e->vcur ^= 1;  // Vo now holds the new image estimate
+    for (int k = 0; k < 4; ++k) e->last_par[k] = par[k];
     ++e->iters_done;
   }
   return 0;
@@ -768,6 +784,21 @@ int lpc_set_momentum(lpc_handle e, double p, double mu, double tk) {
   return gd_apply_momentum_reset(e);
 }
 
+int lpc_set_admm_schedule(lpc_handle e, int n, const double* mu1, const double* mu2, const double* mu3,
+                          const double* tau) {
+  if (!e) return fail("null handle");
+  if (e->cfg.algo != LPC_ALGO_ADMM) return fail("lpc_set_admm_schedule: not an ADMM handle");
+  for (auto& v : e->sched) v.clear();
+  if (n <= 0) return 0;
+  if (!mu1 || !mu2 || !mu3 || !tau) return fail("lpc_set_admm_schedule: null array");
+  for (int i = 0; i < n; ++i) {
+    if (!(mu1[i] > 0) || !(mu2[i] > 0) || !(mu3[i] > 0)) return fail("lpc_set_admm_schedule: step sizes must be > 0");
+    e->sched[0].push_back(mu1[i]); e->sched[1].push_back(mu2[i]);
+    e->sched[2].push_back(mu3[i]); e->sched[3].push_back(tau[i]);
+  }
+  return 0;
+}
+
 int lpc_iterate(lpc_handle e, int n_iter, void* stream) {
   if (!e) return fail("null handle");
   if (n_iter < 0) return fail("lpc_iterate: negative iteration count");
@@ -821,7 +852,9 @@ int lpc_get_state(lpc_handle e, const char* name, float* dev_out, void* stream) 
   const long ostride = (long)g.rplane * e->P;
   float* scratch = nullptr;
   LPC_RT(rt::dev_malloc((void**)&scratch, (size_t)ostride * 7 * sizeof(float)));
-  AdmmScalars sc = admm_scalars(e);
+  double par[4];
+  admm_params(e, e->iters_done, par);
+  AdmmScalars sc = admm_scalars(e, par);
   int rc = launch_k(e, -1, k_admm_flush<256>, grid1d((long)g.Hp * g.Wp, 256, e->P), 256, 0, g, sc,
                     (const float*)e->V[e->vcur], (const float*)e->V[e->vcur ^ 1], (const float*)e->HV,
                     (const float*)e->X, (const float*)e->xi, (const float*)e->eta0[e->ecur],
@@ -885,7 +918,7 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
       case LPC_K_SPATIAL: b = 15.0 * R + R0; break;            // reads 8R+R0, writes 7R
       case LPC_K_ROW_FWD: b = 2.0 * R + 2.0 * S; break;
       case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
-      case LPC_K_COL_MID: b = 4.0 * S + 1.5 * Sc; break;       // + H (complex) + Rdiv (real)
+      case LPC_K_COL_MID: b = 4.0 * S + Sc + 4.0 * g.Hp * g.Wc; break;  // + H (complex) + |G| (real, one plane)
       case LPC_K_COL_A_INV: b = split ? 4.0 * S : 0.0; break;
       case LPC_K_ROW_INV: b = 2.0 * S + 2.0 * R; break;
       default: return fail("bad kernel id");

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_mul(PlaneGeom g, Fft1dPlan plan
 
 // fused middle of one ADMM iteration (4-FFT form).  In: SA = rows+colsA transform of
 // r_sp, SB = same of a = mu1 X - xi.  After forward pass B:
-//   Vh  = Rdiv * (Rh + s * conj(H) * Ah)        (Rdiv already holds 1/(Hp*Wp))
+//   Vh  = Rdiv * (Rh + s * conj(H) * Ah)        (Rdiv formed in-kernel, includes 1/(Hp*Wp))
 //   HVh = s * H * Vh                             (s = spectral phase of ifftshift)
 // then inverse pass B; SA <- Vh path, SB <- HVh path.
 // Tile: [N][2T] -- columns 0..T-1 belong to SA, T..2T-1 to SB.
@@ -319,10 +319,11 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
                                                        float2* LPC_RESTRICT SA,
                                                        float2* LPC_RESTRICT SB,
                                                        const float2* LPC_RESTRICT Hs,
-                                                       const float* LPC_RESTRICT Rdiv,
+                                                       const float* LPC_RESTRICT Gabs,
                                                        const float2* LPC_RESTRICT phr,
                                                        const float2* LPC_RESTRICT phc,
-                                                       FastDiv t2div) {
+                                                       FastDiv t2div, float mu1, float mu2, float mu3,
+                                                       float rscale) {
   LPC_DYN_SMEM(smem);
   float2* s = (float2*)smem;
   const int tid = threadIdx.x;
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
   float2* bb = SB + (long)blockIdx.y * g.cplane + rowoff;
   const int pp = (int)blockIdx.y % g.DC;
   const float2* hb = Hs + (long)pp * g.cplane + rowoff;
-  const float* rb = Rdiv + (long)pp * g.cplane + rowoff;
+  const float* rb = Gabs + rowoff;  // |PsiT Psi| spectrum: one plane, the same for every channel
   const int npair = cp.N * T;
   const long rstep = (long)cp.istride * g.cpitch;
   constexpr int EP = (EMAX + 1) / 2;
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
     if (e < npair) {
       const int i = (int)fd_div((unsigned)e, cp.tdiv);
       const int j = e - i * T;
-      if (c0 + j < g.Wc) { h[k] = hb[i * rstep + j]; rd[k] = rb[i * rstep + j]; }
+      if (c0 + j < g.Wc) { h[k] = hb[i * rstep + j]; rd[k] = rb[i * rstep + j]; }   // rd: |G| for now
     }
   }
   auto in = [&](int i, int c) {
@@ -364,11 +365,14 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
       const int j = e - i * T;
       if (c0 + j < g.Wc) {
         const float2 hh = h[k];
+        // R_divmat = 1 / (mu1 |H* H| + mu2 |PsiT Psi| + mu3)  (admm.py:186-190), formed on the fly so
+        // that per-iteration step sizes cost nothing; rscale folds the inverse FFT's 1/(Hp*Wp)
+        const float rdiv = rscale * (1.0f / (mu1 * fabsf(hh.x * hh.x + hh.y * hh.y) + mu2 * rd[k] + mu3));
         const float2 ph = cmul(phr[grp * cp.gstride + i * cp.istride], phc[c0 + j]);
         const float2 rh = s[i * T2 + j];
         const float2 ah = s[i * T2 + T + j];
         float2 t = cmul(cmul_conj(ah, hh), ph);          // s * conj(H) * Ah
-        float2 vh = cscale(cadd(rh, t), rd[k]);
+        float2 vh = cscale(cadd(rh, t), rdiv);
         float2 hv = cmul(cmul(vh, hh), ph);
         s[i * T2 + j] = vh;
         s[i * T2 + T + j] = hv;
@@ -394,10 +398,13 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
 // eta is read at halo pixels owned by neighbouring workgroups, so its update is written to a
 // second buffer (ping-pong, no extra traffic); every other array is touched only at owned pixels.
 struct AdmmScalars {
-  float mu1, mu2, mu3;
+  float mu1, mu2, mu3;  // this iteration's step sizes
   float thr;            // (float)(tau / mu2)
   float m_in, m_out;    // X_divmat inside / outside the sensor window
   int first;            // 1: no pending dual update (first iteration after reset)
+  // the PREVIOUS iteration's values: its dual updates are still pending and its U, W are recomputed.
+  // Equal to the current ones for plain ADMM; differ for unrolled ADMM (unrolled_admm.py:171-211)
+  float mu1p, mu2p, mu3p, thrp;
 };
 
 static __device__ __forceinline__ float soft_thresh_dev(float a, float thr) {
@@ -467,8 +474,8 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
       const float psi = sV[li - VW] - vc;
       if (!p.first) {
         const float psio = sO[li - VW] - oc;
-        const float uo = soft_thresh_dev(psio + e0 / p.mu2, p.thr);
-        e0 = e0 + p.mu2 * (psi - uo);
+        const float uo = soft_thresh_dev(psio + e0 / p.mu2p, p.thrp);
+        e0 = e0 + p.mu2p * (psi - uo);
       }
       const float un = soft_thresh_dev(psi + e0 / p.mu2, p.thr);
       sQ0[ly * TW + lx] = p.mu2 * un - e0;
@@ -479,8 +486,8 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
       const float psi = sV[li - 1] - vc;
       if (!p.first) {
         const float psio = sO[li - 1] - oc;
-        const float uo = soft_thresh_dev(psio + e1 / p.mu2, p.thr);
-        e1 = e1 + p.mu2 * (psi - uo);
+        const float uo = soft_thresh_dev(psio + e1 / p.mu2p, p.thrp);
+        e1 = e1 + p.mu2p * (psi - uo);
       }
       const float un = soft_thresh_dev(psi + e1 / p.mu2, p.thr);
       sQ1[ly * (TW + 1) + lx] = p.mu2 * un - e1;
@@ -503,9 +510,9 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
     float xiv = xi[o], rhov = rho[o];
     if (!p.first) {
       const float xo = X[o];
-      xiv = xiv + p.mu1 * (hv - xo);
-      const float wo = fmaxf(rhov / p.mu3 + (VWo ? VWo[o] : sO[li]), 0.f);
-      rhov = rhov + p.mu3 * (vc - wo);
+      xiv = xiv + p.mu1p * (hv - xo);
+      const float wo = fmaxf(rhov / p.mu3p + (VWo ? VWo[o] : sO[li]), 0.f);
+      rhov = rhov + p.mu3p * (vc - wo);
     }
     const bool inside = (gr >= g.sh) && (gr < g.sh + g.H) && (gc >= g.sw) && (gc < g.sw + g.W);
     const float yv = inside ? y[(long)(gr - g.sh) * g.W + (gc - g.sw)] : 0.f;
@@ -535,8 +542,8 @@ static __device__ __forceinline__ void tv_component(const AdmmScalars& p, float 
                                                      float eta, float& eta_new, float& q) {
   const float psi = vn - vc;                       // finite_diff: roll(+1) - x   (admm.py:349-359)
   if (!p.first) {
-    const float uo = soft_thresh_dev((on - oc) + eta / p.mu2, p.thr);
-    eta = eta + p.mu2 * (psi - uo);                // pending eta update of the previous iteration
+    const float uo = soft_thresh_dev((on - oc) + eta / p.mu2p, p.thrp);
+    eta = eta + p.mu2p * (psi - uo);               // pending eta update of the previous iteration
   }
   const float un = soft_thresh_dev(psi + eta / p.mu2, p.thr);
   eta_new = eta;
@@ -647,9 +654,9 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
       const float vc = vcs[i + 1], hv = hvs[i];
       float xiv = xis[i], rhov = rhs[i];
       if (!p.first) {
-        xiv = xiv + p.mu1 * (hv - xos[i]);
-        const float wo = fmaxf(rhov / p.mu3 + (VWo ? vwos[i] : ocs[i + 1]), 0.f);
-        rhov = rhov + p.mu3 * (vc - wo);
+        xiv = xiv + p.mu1p * (hv - xos[i]);
+        const float wo = fmaxf(rhov / p.mu3p + (VWo ? vwos[i] : ocs[i + 1]), 0.f);
+        rhov = rhov + p.mu3p * (vc - wo);
       }
       const int cc = gc + i;
       const bool inside = row_in && (cc >= g.sw) && (cc < g.sw + g.W);
@@ -696,13 +703,13 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
     float u0 = 0.f, u1 = 0.f, w = 0.f;
     if (!p.first) {
       const float oc = Vold[o], vc = V[o];
-      u0 = soft_thresh_dev((Vold[ou] - oc) + e0 / p.mu2, p.thr);
-      u1 = soft_thresh_dev((Vold[ol] - oc) + e1 / p.mu2, p.thr);
-      w = fmaxf(rh / p.mu3 + (VWo ? VWo[o] : oc), 0.f);
-      xiv = xiv + p.mu1 * (HV[o] - X[o]);
-      e0 = e0 + p.mu2 * ((V[ou] - vc) - u0);
-      e1 = e1 + p.mu2 * ((V[ol] - vc) - u1);
-      rh = rh + p.mu3 * (vc - w);
+      u0 = soft_thresh_dev((Vold[ou] - oc) + e0 / p.mu2p, p.thrp);
+      u1 = soft_thresh_dev((Vold[ol] - oc) + e1 / p.mu2p, p.thrp);
+      w = fmaxf(rh / p.mu3p + (VWo ? VWo[o] : oc), 0.f);
+      xiv = xiv + p.mu1p * (HV[o] - X[o]);
+      e0 = e0 + p.mu2p * ((V[ou] - vc) - u0);
+      e1 = e1 + p.mu2p * ((V[ol] - vc) - u1);
+      rh = rh + p.mu3p * (vc - w);
     }
     out[0 * ostride + o] = xiv;
     out[1 * ostride + o] = e0;
@@ -768,20 +775,12 @@ __global__ __launch_bounds__(NT) void k_clamp_window_copy(PlaneGeom g, const flo
   }
 }
 
-// Rdiv = scale / (mu1 |H* H| + mu2 |G| + mu3)      (admm.py:186-190, real part only)
+// |G| of the TV gram spectrum (admm.py:188 takes torch.abs of it), one plane
 template <int NT>
-__global__ __launch_bounds__(NT) void k_admm_rdiv(PlaneGeom g, const float2* LPC_RESTRICT Hs,
-                                                   const float2* LPC_RESTRICT Gs, float* LPC_RESTRICT Rdiv,
-                                                   float mu1, float mu2, float mu3, float scale) {
-  const long n = (long)g.Hp * g.cpitch;
-  const long pl = blockIdx.y;
+__global__ __launch_bounds__(NT) void k_abs_complex(const float2* LPC_RESTRICT Gs, float* LPC_RESTRICT out, long n) {
   for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
-    const float2 h = Hs[pl * g.cplane + e];
-    const float2 hh = cmul_conj(h, h);                       // Hadj * H
     const float2 gg = Gs[e];
-    const float a = sqrtf(hh.x * hh.x + hh.y * hh.y);        // |.|
-    const float b = sqrtf(gg.x * gg.x + gg.y * gg.y);
-    Rdiv[pl * g.cplane + e] = scale * (1.0f / (mu1 * a + mu2 * b + mu3));
+    out[e] = sqrtf(gg.x * gg.x + gg.y * gg.y);
   }
 }
 

@@ -167,7 +167,10 @@ class ADMMOracle:
     """
 
     def __init__(self, psf, dtype=torch.float32, mu1=1e-6, mu2=1e-5, mu3=4e-5, tau=1e-4,
-                 initial_est=None):
+                 initial_est=None, schedule=None):
+        """``schedule``: optional dict of per-iteration sequences mu1/mu2/mu3/tau -- the arithmetic of
+        ``lensless/recon/unrolled_admm.py:133-234`` (UnrolledADMM inference, no pre/post processors):
+        iteration i uses the i-th entries everywhere, R_divmat and X_divmat included."""
         psf = _as_tensor(psf, dtype)
         assert psf.dim() == 4 and psf.shape[0] == 1, "reference refuses D>1 (admm.py:92-96)"
         self.dtype = dtype
@@ -181,6 +184,7 @@ class ADMMOracle:
         self.psf = psf
         self.gram = finite_diff_gram(self.padded_shape, dtype)  # admm.py:107
         self.initial_est = None if initial_est is None else _as_tensor(initial_est, dtype)
+        self.schedule = schedule
         self.data = None
         self.reset()
 
@@ -190,8 +194,21 @@ class ADMMOracle:
             data = data[None]
         self.data = data
 
+    def _set_params(self, it):
+        """unrolled_admm.py:147-168: per-iteration parameters as float32 tensors (abs of the learnt values)."""
+        if self.schedule is None:
+            return
+        t = lambda k: torch.abs(torch.tensor(self.schedule[k][it], dtype=self.dtype))  # noqa: E731
+        self.mu1, self.mu2, self.mu3, self.tau = t("mu1"), t("mu2"), t("mu3"), t("tau")
+        H, Hadj = self.conv.H, self.conv.Hadj
+        self.R_divmat = 1.0 / (
+            self.mu1 * torch.abs(Hadj * H) + self.mu2 * torch.abs(self.gram) + self.mu3
+        ).type(self.cdtype)
+        self.X_divmat = 1.0 / (self.geom.pad(torch.ones_like(self.psf)) + self.mu1)
+
     def reset(self):
         """admm.py:150-195."""
+        self.it = 0
         if self.initial_est is not None:
             V = self.initial_est
             if V.dim() == 4:
@@ -222,6 +239,8 @@ class ADMMOracle:
     def step(self):
         """One iteration, admm.py:313-329 with the sub-updates at :232-311."""
         g = self.geom
+        self._set_params(self.it)
+        self.it += 1
         mu1, mu2, mu3 = self.mu1, self.mu2, self.mu3
         self.U = soft_thresh(self.PsiV + self.eta / mu2, self.tau / mu2)          # :245-247
         self.X = self.X_divmat * (self.xi + mu1 * self.HV + g.pad(self.data))     # :252-254
@@ -240,8 +259,11 @@ class ADMMOracle:
         self.rho = self.rho + mu3 * (self.V - self.W)                             # :310-311
 
     def form_image(self):
-        """admm.py:331-338: crop is a view, clamp happens IN PLACE on V."""
+        """admm.py:331-338: crop is a view, clamp happens IN PLACE on V.  (UnrolledADMM clips out of
+        place instead, unrolled_admm.py:236-240.)"""
         img = self.geom.crop(self.V)
+        if self.schedule is not None:
+            return torch.clip(img, min=0.0)
         img[img < 0] = 0
         return img
 

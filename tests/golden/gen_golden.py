@@ -123,6 +123,30 @@ def gd_case(name, cls, h, w, c, seed, iters, d=1, dtype="float32", **kw):
     print("wrote", name)
 
 
+def unrolled_admm_case(name, h, w, c, seed, n_iter, batch):
+    """UnrolledADMM inference with DIFFERENT parameters per iteration on a batch (forward())."""
+    from lensless.recon.unrolled_admm import UnrolledADMM
+
+    psf, _ = make_inputs(h, w, c, seed)
+    rng = np.random.default_rng(seed + 50)
+    data = rng.random((batch, 1, h, w, c)).astype(np.float32)
+    rec = UnrolledADMM(t(psf), n_iter=n_iter, mu1=1e-6, mu2=1e-4, mu3=4e-5, tau=2e-6, skip_unrolled=False)
+    sched = {
+        "mu1": (1e-6 * (1 + 0.5 * rng.random(n_iter))).astype(np.float32),
+        "mu2": (1e-4 * (1 + 0.5 * rng.random(n_iter))).astype(np.float32),
+        "mu3": (4e-5 * (1 + 0.5 * rng.random(n_iter))).astype(np.float32),
+        "tau": (2e-6 * (1 + 0.5 * rng.random(n_iter))).astype(np.float32),
+    }
+    with torch.no_grad():
+        rec._mu1_p.copy_(t(sched["mu1"]))
+        rec._mu2_p.copy_(t(sched["mu2"]))
+        rec._mu3_p.copy_(t(sched["mu3"]))
+        rec._tau_p.copy_(t(sched["tau"]))
+        out = rec.forward(t(data)).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), psf=psf, data=data, out=out, n_iter=n_iter, **sched)
+    print("wrote", name, out.shape)
+
+
 def operator_case():
     rng = np.random.default_rng(5)
     out = {}
@@ -166,6 +190,9 @@ def operator_case():
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "unrolled":
+        unrolled_admm_case("unrolled_admm_24x32x3_b3", 24, 32, 3, seed=21, n_iter=6, batch=3)
+        sys.exit(0)
     operator_case()
     # default hyper-parameters (U stays 0: tau/mu2 = 10, SURVEY section 7 caveat)
     admm_case("admm_24x32x3_default", 24, 32, 3, seed=1, iters=[1, 2, 5, 20])
@@ -191,3 +218,4 @@ if __name__ == "__main__":
     gd_case("fista_24x32x3_tk", FISTA, 24, 32, 3, seed=15, iters=[5, 20], tk=2.5)
     gd_case("nesterov_24x32x3_mu", NesterovGradientDescent, 24, 32, 3, seed=16, iters=[5, 20], mu=0.7)
     gd_case("fista_24x32x1_f64", FISTA, 24, 32, 1, seed=17, iters=[5, 20], dtype="float64")
+    unrolled_admm_case("unrolled_admm_24x32x3_b3", 24, 32, 3, seed=21, n_iter=6, batch=3)

@@ -143,3 +143,13 @@ def test_gd_family_trajectory(name):
             r = rel(o.x, g[f"it{i + 1}_x"])
             assert r <= (2e-6 if i < 5 else 5e-5), (i + 1, r)
     assert rel(o.form_image()[0], g["final"]) <= 5e-5
+
+
+def test_unrolled_admm_schedule_matches_reference():
+    """UnrolledADMM.forward on a batch of 3 with different parameters in every iteration."""
+    g = np.load(os.path.join(GOLDEN, "unrolled_admm_24x32x3_b3.npz"))
+    sched = {k: g[k] for k in ("mu1", "mu2", "mu3", "tau")}
+    for b in range(g["data"].shape[0]):
+        o = orc.ADMMOracle(g["psf"], schedule=sched)
+        o.set_data(g["data"][b, 0])
+        assert rel(o.apply(int(g["n_iter"])), g["out"][b]) <= 2e-6

@@ -173,6 +173,23 @@ def test_admm_depth_planes_are_independent(backend):
         assert rel(res[d], o.apply(10)[0]) <= 1e-5
 
 
+def test_unrolled_admm_matches_reference_golden(backend):
+    """Row N1: UnrolledADMM.forward (reference: lensless/recon/unrolled_admm.py) on a batch of 3 with a
+    different (mu1, mu2, mu3, tau) in each of the 6 iterations."""
+    g = np.load(os.path.join(GOLDEN, "unrolled_admm_24x32x3_b3.npz"))
+    n = int(g["n_iter"])
+    rec = lpa.UnrolledADMM(torch.from_numpy(g["psf"]), n_iter=n, mu1=1e-6, mu2=1e-4, mu3=4e-5, tau=2e-6)
+    rec.set_parameters(mu1=g["mu1"], mu2=g["mu2"], mu3=g["mu3"], tau=g["tau"])
+    out = rec.forward(torch.from_numpy(g["data"]))
+    assert out.shape == g["out"].shape
+    assert rel(out, g["out"]) <= 5e-6
+    # constant schedule == plain ADMM
+    const = lpa.UnrolledADMM(torch.from_numpy(g["psf"]), n_iter=n, mu1=1e-6, mu2=1e-4, mu3=4e-5, tau=2e-6)
+    plain = lpa.ADMM(torch.from_numpy(g["psf"]), mu1=1e-6, mu2=1e-4, mu3=4e-5, tau=2e-6)
+    plain.set_data(torch.from_numpy(g["data"]))
+    torch.testing.assert_close(const.forward(torch.from_numpy(g["data"])), plain.apply_batch(n_iter=n), rtol=0, atol=0)
+
+
 # --------------------------------------------------------------------------- GD family --
 GD_CLASSES = {"gd": lpa.GradientDescent, "nesterov": lpa.NesterovGradientDescent, "fista": lpa.FISTA}
 GD_CASES = sorted(
