@@ -199,3 +199,37 @@ def test_c5_depth_planes_match_single_plane_runs():
         single = lpa.ADMM(psf[d:d + 1].contiguous(), tau=2e-6, mu2=1e-4)
         single.set_data(y)
         assert torch.equal(single.apply(n_iter=3, disp_iter=None)[0], full[d])
+
+
+@pytest.mark.parametrize("shape", [(64, 8100, 1), (1000, 37, 3), (500, 500, 1), (333, 1025, 1)])
+def test_unusual_shapes_against_oracle(shape):
+    """Row length at the LDS limit (8100 -> 16200-point rows, 130 KB of LDS), odd padded widths (37 -> 75)
+    with a four-step column split (1000 -> 2000 = 50 x 40), and non-power-of-two everything."""
+    torch.set_num_threads(16)
+    H, W, C = shape
+    rng = np.random.default_rng(H + W)
+    psf = orc.synthetic_psf(1, H, W, C, seed=H)
+    y = rng.random((H, W, C), dtype=np.float32)
+    x = torch.from_numpy(rng.standard_normal((1, 1, H, W, C)).astype(np.float32))
+    cv = lpa.RealFFTConvolve2D(torch.from_numpy(psf).cuda(), pad=True)
+    oc = orc.ConvolverOracle(psf, pad=True)
+    assert cv._padded_shape[1:3] == [oc.geom.hp, oc.geom.wp]
+    assert rel(cv.convolve(x.cuda()), oc.convolve(x)) <= 5e-6
+    assert rel(cv.deconvolve(x.cuda()), oc.deconvolve(x)) <= 5e-6
+    rec = lpa.ADMM(torch.from_numpy(psf).cuda(), tau=2e-6, mu2=1e-4)
+    rec.set_data(torch.from_numpy(y).cuda())
+    o64 = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
+    o64.set_data(y)
+    assert rel(rec.apply(n_iter=4, disp_iter=None), o64.apply(4)) <= 1e-5
+    f = lpa.FISTA(torch.from_numpy(psf).cuda())
+    f.set_data(torch.from_numpy(y).cuda())
+    of = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
+    of.set_data(y)
+    assert rel(f.apply(n_iter=6, disp_iter=None), of.apply(6)) <= 1e-5
+
+
+def test_too_wide_frame_is_rejected_cleanly():
+    from lenslesspicam_amd._native import NativeError
+
+    with pytest.raises(NativeError, match="16384"):
+        lpa.RealFFTConvolve2D(torch.zeros((1, 8, 9000, 1), device="cuda"), pad=True)
