@@ -98,6 +98,11 @@ int lpc_set_momentum(lpc_handle h, double p, double mu, double tk);
 int lpc_set_admm_schedule(lpc_handle h, int n, const double* mu1, const double* mu2, const double* mu3,
                           const double* tau);
 
+/* Unrolled FISTA (lensless/recon/unrolled_fista.py:60-106): iteration i uses the step alpha[i*C + c] and
+ * the momentum factor coef[i] = (t_i - 1) / t_{i+1}; x_k starts as the initial image.  alpha, coef are
+ * HOST arrays of n*C and n floats.  n <= 0 returns to the plain FISTA recursion. */
+int lpc_set_fista_schedule(lpc_handle h, int n, const float* alpha, const float* coef, void* stream);
+
 /* ---- the hot loop: `for i in range(n_iter): self._update(i)`  recon.py:575-576 ------ */
 /* exactly n_iter iterations, asynchronous on `stream`; no early exit exists on this path */
 int lpc_iterate(lpc_handle h, int n_iter, void* stream);

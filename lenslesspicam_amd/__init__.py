@@ -12,7 +12,8 @@ from .gd import (FISTA, GradientDescent, GradientDescentUpdate, NesterovGradient
 from .recon import ReconstructionAlgorithm
 from .rfft_convolve import RealFFTConvolve2D
 from .unrolled_admm import UnrolledADMM
+from .unrolled_fista import UnrolledFISTA
 
 __all__ = ["ADMM", "FISTA", "GradientDescent", "GradientDescentUpdate", "NesterovGradientDescent",
-           "RealFFTConvolve2D", "ReconstructionAlgorithm", "UnrolledADMM", "apply_admm", "apply_gradient_descent", "non_neg"]
+           "RealFFTConvolve2D", "ReconstructionAlgorithm", "UnrolledADMM", "UnrolledFISTA", "apply_admm", "apply_gradient_descent", "non_neg"]
 __version__ = "0.1.0"

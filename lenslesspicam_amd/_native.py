@@ -72,6 +72,7 @@ class Lib:
             "lpc_iterate": [vp, C.c_int, vp],
             "lpc_set_admm_schedule": [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)],
+            "lpc_set_fista_schedule": [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp],
             "lpc_form_image": [vp, fp, vp],
             "lpc_get_state": [vp, C.c_char_p, fp, vp],
             "lpc_profile_enable": [vp, C.c_int],
@@ -152,6 +153,14 @@ class Handle:
         n = len(mu1)
         arr = [(C.c_double * n)(*[float(v) for v in a]) for a in (mu1, mu2, mu3, tau)]
         self._c(self.lib.dll.lpc_set_admm_schedule(self.h, n, *arr))
+
+    def set_fista_schedule(self, alpha, coef, stream=0):
+        """alpha: (n, C) floats, coef: (n,) floats (host)"""
+        n = len(coef)
+        flat = [float(v) for row in alpha for v in row]
+        a = (C.c_float * len(flat))(*flat)
+        c = (C.c_float * n)(*[float(v) for v in coef])
+        self._c(self.lib.dll.lpc_set_fista_schedule(self.h, n, a, c, stream))
 
     def clear_admm_schedule(self):
         self._c(self.lib.dll.lpc_set_admm_schedule(self.h, 0, None, None, None, None))

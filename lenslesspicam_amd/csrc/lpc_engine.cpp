@@ -110,6 +110,10 @@ struct lpc_engine {
   float* gx0 = nullptr;                  // [C] default start value per channel
   float2* S2 = nullptr;                  // second spectrum buffer (row-inverse+forward is out of place)
   double tk = 1.0, nest_mu = 0.9, nest_p = 0.0;
+  // unrolled FISTA (unrolled_fista.py:91-106): per-iteration step alpha[i][c] and momentum factor coef[i]
+  std::vector<float> fista_coef;
+  float* galpha_sched = nullptr;  // device [n][C]
+  int fista_sched_n = 0;
   // common
   float* Y = nullptr;         // data planes, un-padded [Pdata][H][W]
   float* init_est = nullptr;  // planar copy of the initial estimate (or null)
@@ -796,6 +800,22 @@ int lpc_set_admm_schedule(lpc_handle e, int n, const double* mu1, const double* 
     e->sched[0].push_back(mu1[i]); e->sched[1].push_back(mu2[i]);
     e->sched[2].push_back(mu3[i]); e->sched[3].push_back(tau[i]);
   }
+  return 0;
+}
+
+int lpc_set_fista_schedule(lpc_handle e, int n, const float* alpha, const float* coef, void* stream) {
+  if (!e) return fail("null handle");
+  if (e->cfg.algo != LPC_ALGO_FISTA) return fail("lpc_set_fista_schedule: not a FISTA handle");
+  e->stream = (lpcStream_t)stream;
+  e->fista_coef.clear();
+  e->fista_sched_n = 0;
+  if (n <= 0) return 0;
+  if (!alpha || !coef) return fail("lpc_set_fista_schedule: null array");
+  const int C = e->cfg.channels;
+  LPC_OK(dev_alloc(e, &e->galpha_sched, (size_t)n * C));
+  LPC_OK(upload(e, e->galpha_sched, alpha, (size_t)n * C * sizeof(float)));
+  e->fista_coef.assign(coef, coef + n);
+  e->fista_sched_n = n;
   return 0;
 }
 

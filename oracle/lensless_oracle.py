@@ -376,6 +376,28 @@ class GDOracle:
         return self.form_image()[0]
 
 
+def unrolled_fista_oracle(psf, data, alpha, tk, dtype=torch.float32):
+    """UnrolledFISTA inference, lensless/recon/unrolled_fista.py:60-106 (no pre/post processors).
+
+    alpha: (n_iter, C) per-iteration steps, tk: (n_iter + 1,) momentum sequence; both enter through
+    torch.abs() as float32 (:98-100).  x_k starts as the initial image (:91-96, no aliasing here because
+    the update is out of place).  data: (H,W,C) or (1,H,W,C); returns (1,D,H,W,C).
+    """
+    g = GDOracle(psf, kind="fista", dtype=dtype)
+    g.set_data(data)
+    alpha = torch.abs(torch.as_tensor(np.asarray(alpha), dtype=dtype))
+    tk = torch.abs(torch.as_tensor(np.asarray(tk), dtype=dtype))
+    x = g.x
+    xk_prev = x
+    for i in range(alpha.shape[0]):
+        g.x = x
+        x = x - alpha[i] * g.grad()                                     # :103
+        xk = torch.maximum(x, torch.zeros_like(x))                      # proj = non_neg
+        x = xk + (tk[i] - 1) / tk[i + 1] * (xk - xk_prev)               # :105
+        xk_prev = xk
+    return torch.maximum(x, torch.zeros_like(x))                        # _form_image, :80-81
+
+
 # --------------------------------------------------------------------------
 # metrics used by the harness
 # --------------------------------------------------------------------------

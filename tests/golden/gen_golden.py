@@ -147,6 +147,24 @@ def unrolled_admm_case(name, h, w, c, seed, n_iter, batch):
     print("wrote", name, out.shape)
 
 
+def unrolled_fista_case(name, h, w, c, seed, n_iter, batch):
+    from lensless.recon.unrolled_fista import UnrolledFISTA
+
+    psf, _ = make_inputs(h, w, c, seed)
+    rng = np.random.default_rng(seed + 50)
+    data = rng.random((batch, 1, h, w, c)).astype(np.float32)
+    rec = UnrolledFISTA(t(psf), n_iter=n_iter, tk=1)
+    with torch.no_grad():
+        alpha = (rec._alpha_p.detach().numpy() * (0.6 + 0.4 * rng.random((n_iter, c)))).astype(np.float32)
+        tk = (rec._tk_p.detach().numpy() * (1 + 0.2 * rng.random(n_iter + 1))).astype(np.float32)
+        rec._alpha_p.copy_(t(alpha))
+        rec._tk_p.copy_(t(tk))
+        out = rec.forward(t(data)).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), psf=psf, data=data, out=out, n_iter=n_iter, alpha=alpha,
+                        tk=tk)
+    print("wrote", name, out.shape)
+
+
 def operator_case():
     rng = np.random.default_rng(5)
     out = {}
@@ -192,6 +210,7 @@ if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1 and sys.argv[1] == "unrolled":
         unrolled_admm_case("unrolled_admm_24x32x3_b3", 24, 32, 3, seed=21, n_iter=6, batch=3)
+        unrolled_fista_case("unrolled_fista_24x32x3_b3", 24, 32, 3, seed=22, n_iter=7, batch=3)
         sys.exit(0)
     operator_case()
     # default hyper-parameters (U stays 0: tau/mu2 = 10, SURVEY section 7 caveat)
@@ -219,3 +238,4 @@ if __name__ == "__main__":
     gd_case("nesterov_24x32x3_mu", NesterovGradientDescent, 24, 32, 3, seed=16, iters=[5, 20], mu=0.7)
     gd_case("fista_24x32x1_f64", FISTA, 24, 32, 1, seed=17, iters=[5, 20], dtype="float64")
     unrolled_admm_case("unrolled_admm_24x32x3_b3", 24, 32, 3, seed=21, n_iter=6, batch=3)
+    unrolled_fista_case("unrolled_fista_24x32x3_b3", 24, 32, 3, seed=22, n_iter=7, batch=3)

@@ -153,3 +153,10 @@ def test_unrolled_admm_schedule_matches_reference():
         o = orc.ADMMOracle(g["psf"], schedule=sched)
         o.set_data(g["data"][b, 0])
         assert rel(o.apply(int(g["n_iter"])), g["out"][b]) <= 2e-6
+
+
+def test_unrolled_fista_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "unrolled_fista_24x32x3_b3.npz"))
+    for b in range(g["data"].shape[0]):
+        out = orc.unrolled_fista_oracle(g["psf"], g["data"][b, 0], g["alpha"], g["tk"])
+        assert rel(out[0], g["out"][b]) <= 2e-6

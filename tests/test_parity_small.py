@@ -190,6 +190,19 @@ def test_unrolled_admm_matches_reference_golden(backend):
     torch.testing.assert_close(const.forward(torch.from_numpy(g["data"])), plain.apply_batch(n_iter=n), rtol=0, atol=0)
 
 
+def test_unrolled_fista_matches_reference_golden(backend):
+    """Row N1: UnrolledFISTA.forward (lensless/recon/unrolled_fista.py) with per-iteration, per-channel
+    steps and a perturbed t_k sequence on a batch of 3."""
+    g = np.load(os.path.join(GOLDEN, "unrolled_fista_24x32x3_b3.npz"))
+    n = int(g["n_iter"])
+    rec = lpa.UnrolledFISTA(torch.from_numpy(g["psf"]), n_iter=n)
+    assert rel(rec._alpha_p[0], lpa.FISTA(torch.from_numpy(g["psf"]))._alpha) <= 1e-7
+    rec.set_parameters(alpha=g["alpha"], tk=g["tk"])
+    out = rec.forward(torch.from_numpy(g["data"]))
+    assert out.shape == g["out"].shape
+    assert rel(out, g["out"]) <= 5e-6
+
+
 # --------------------------------------------------------------------------- GD family --
 GD_CLASSES = {"gd": lpa.GradientDescent, "nesterov": lpa.NesterovGradientDescent, "fista": lpa.FISTA}
 GD_CASES = sorted(
