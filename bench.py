@@ -252,11 +252,10 @@ def main():
         if not args.no_parity:
             parity = {}
             if (bH, bW) == (H, W):
-                rec.apply(n_iter=args.cpu_iters, disp_iter=None)
-                Vg = rec._image_est
-                ref = o.V
+                got = rec.apply(n_iter=args.cpu_iters, disp_iter=None)       # (D,H,W,C), formed image
+                ref = o.form_image()[0]                                      # same _form_image on the oracle
                 parity["full_size_rel_err_after_sample"] = float(
-                    (Vg.cpu() - ref).abs().max() / ref.abs().max())
+                    (got.cpu() - ref).abs().max() / ref.abs().max())
                 parity["full_size_iters"] = args.cpu_iters
             del o
             # PSNR delta after the full iteration count on the DiffuserCam-sized frame
