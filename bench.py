@@ -92,6 +92,9 @@ def main():
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC (see task environment notes)
         dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        warm = torch.ones(1, device=dev)
+        dist.all_reduce(warm)                            # create the communicator outside any timed region
+        torch.cuda.synchronize()
     assert world == args.gpus or world == 1, "launch with torchrun --nproc-per-node == --gpus"
 
     import lenslesspicam_amd as lpa
