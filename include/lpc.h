@@ -12,7 +12,7 @@
  *
  * Conventions
  *  - plain C, no torch types.  Every pointer named dev_* is a DEVICE pointer (HBM) that the
- *    library only borrows for the duration of the call; images are float32, channels-last,
+ *    library only borrows for the duration of the call; images are lpc_real, channels-last,
  *    exactly the reference's layouts: psf (D,H,W,C), data (B,H,W,C), image estimate
  *    (B,D,H,W,C) for the gradient-descent family and (B,D,Hp,Wp,C) for ADMM (which iterates
  *    on the padded frame, admm.py:101 pad=False).
@@ -32,6 +32,15 @@ extern "C" {
 #endif
 
 typedef struct lpc_engine* lpc_handle;
+
+/* The library is built twice from the same sources: liblpc.so computes in float32 (the reference's
+ * default dtype), liblpc_f64.so (-DLPC_DOUBLE) in float64 (dtype="float64", lensless/utils/io.py:645-674).
+ * Every image / state buffer of a library is an array of its lpc_real. */
+#ifdef LPC_DOUBLE
+typedef double lpc_real;
+#else
+typedef float lpc_real;
+#endif
 
 enum lpc_algo {
   LPC_ALGO_CONV = 0,     /* operator only: RealFFTConvolve2D            rfft_convolve.py:26  */
@@ -65,6 +74,7 @@ int lpc_create(const lpc_config* cfg, lpc_handle* out);
 int lpc_destroy(lpc_handle h);
 const char* lpc_last_error(void);
 const char* lpc_backend(void);        /* "hip-gfx950" for the product library */
+const char* lpc_real_name(void);      /* "float32" or "float64": the arithmetic type of this build */
 
 /* padded frame chosen by the engine: next 5-smooth length >= 2*dim-1 (rfft_convolve.py:110-117) */
 int lpc_padded_shape(lpc_handle h, int* Hp, int* Wp, int* start_h, int* start_w);
@@ -73,19 +83,19 @@ int lpc_padded_shape(lpc_handle h, int* Hp, int* Wp, int* start_h, int* start_w)
 /* dev_psf: (D,H,W,C).  Computes the PSF spectrum (and for ADMM R_divmat, for the GD family
  * the step alpha and the default initial estimate).  rfft_convolve.py:102-131,
  * admm.py:186-193, gd.py:94-126.  Implies lpc_reset(). */
-int lpc_set_psf(lpc_handle h, const float* dev_psf, void* stream);
+int lpc_set_psf(lpc_handle h, const lpc_real* dev_psf, void* stream);
 
 /* out = ifftshift(irfft2(rfft2(pad?(x)) * H or conj(H))) cropped if cfg.pad.
  * x, out: (n, D, Hx, Wx, C) with (Hx,Wx) = (H,W) if cfg.pad else (Hp,Wp); n <= cfg.batch.
  * adjoint = 0: convolve (rfft_convolve.py:133-176); 1: deconvolve (:178-223). */
-int lpc_convolve(lpc_handle h, const float* dev_x, float* dev_out, int n, int adjoint, void* stream);
+int lpc_convolve(lpc_handle h, const lpc_real* dev_x, lpc_real* dev_out, int n, int adjoint, void* stream);
 
 /* ---- solver state: set_data / _set_initial_estimate / reset ------------------------ */
 /* dev_data: (B,H,W,C) with B == cfg.batch.  recon.py:352-381 */
-int lpc_set_data(lpc_handle h, const float* dev_data, void* stream);
+int lpc_set_data(lpc_handle h, const lpc_real* dev_data, void* stream);
 /* dev_est: image-estimate shape (see top) or NULL to clear.  Takes effect at the next
  * lpc_reset(), like recon.py:383-413. */
-int lpc_set_initial_estimate(lpc_handle h, const float* dev_est, void* stream);
+int lpc_set_initial_estimate(lpc_handle h, const lpc_real* dev_est, void* stream);
 /* admm.py:150-230 / gd.py:94-126,178-181,227-233 */
 int lpc_reset(lpc_handle h, void* stream);
 /* Nesterov: overrides (p, mu) like NesterovGradientDescent.reset(p, mu) gd.py:178-181;
@@ -101,7 +111,7 @@ int lpc_set_admm_schedule(lpc_handle h, int n, const double* mu1, const double* 
 /* Unrolled FISTA (lensless/recon/unrolled_fista.py:60-106): iteration i uses the step alpha[i*C + c] and
  * the momentum factor coef[i] = (t_i - 1) / t_{i+1}; x_k starts as the initial image.  alpha, coef are
  * HOST arrays of n*C and n floats.  n <= 0 returns to the plain FISTA recursion. */
-int lpc_set_fista_schedule(lpc_handle h, int n, const float* alpha, const float* coef, void* stream);
+int lpc_set_fista_schedule(lpc_handle h, int n, const lpc_real* alpha, const lpc_real* coef, void* stream);
 
 /* ---- the hot loop: `for i in range(n_iter): self._update(i)`  recon.py:575-576 ------ */
 /* exactly n_iter iterations, asynchronous on `stream`; no early exit exists on this path */
@@ -110,13 +120,13 @@ int lpc_iterate(lpc_handle h, int n_iter, void* stream);
 /* _form_image(): ADMM crop + clamp (admm.py:331-338), GD family projection (gd.py:136-140).
  * dev_out: (B,D,H,W,C).  Like the reference, the ADMM clamp is an in-place side effect on the image
  * estimate: it is visible to the W-update of the following iterations (and to "image_est"). */
-int lpc_form_image(lpc_handle h, float* dev_out, void* stream);
+int lpc_form_image(lpc_handle h, lpc_real* dev_out, void* stream);
 
 /* inspection (tests, warm starts).  name: "image_est" (solver state shape), and for ADMM
  * "X","xi","rho","forward_out","W" as (B,D,Hp,Wp,C), "U","eta" as (B,D,Hp,Wp,C,2)
  * [values as the reference holds them after the same number of iterations].
  * GD family: "alpha" writes C floats. */
-int lpc_get_state(lpc_handle h, const char* name, float* dev_out, void* stream);
+int lpc_get_state(lpc_handle h, const char* name, lpc_real* dev_out, void* stream);
 
 /* ---- measurement support (bench.py roofline leg) ----------------------------------- */
 enum lpc_kernel_id {

@@ -13,7 +13,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "_lib", "liblpc.so")
+DEFAULT_LIB = os.path.join(_HERE, "_lib", "liblpc.so")          # float32 build
+DEFAULT_LIB_F64 = os.path.join(_HERE, "_lib", "liblpc_f64.so")  # same sources, -DLPC_DOUBLE
 
 ALGO_CONV, ALGO_ADMM, ALGO_GD, ALGO_NESTEROV, ALGO_FISTA = range(5)
 NORM = {"backward": 0, "ortho": 1, "forward": 2}
@@ -72,7 +73,7 @@ class Lib:
             "lpc_iterate": [vp, C.c_int, vp],
             "lpc_set_admm_schedule": [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)],
-            "lpc_set_fista_schedule": [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float), vp],
+            "lpc_set_fista_schedule": [vp, C.c_int, vp, vp, vp],
             "lpc_form_image": [vp, fp, vp],
             "lpc_get_state": [vp, C.c_char_p, fp, vp],
             "lpc_profile_enable": [vp, C.c_int],
@@ -86,6 +87,9 @@ class Lib:
             fn.restype = C.c_int
         d.lpc_last_error.restype = C.c_char_p
         d.lpc_backend.restype = C.c_char_p
+        d.lpc_real_name.restype = C.c_char_p
+        self.real = d.lpc_real_name().decode()            # "float32" | "float64"
+        self.c_real = C.c_double if self.real == "float64" else C.c_float
 
     # -- plumbing -------------------------------------------------------------------
     def backend(self) -> str:
@@ -158,9 +162,9 @@ class Handle:
         """alpha: (n, C) floats, coef: (n,) floats (host)"""
         n = len(coef)
         flat = [float(v) for row in alpha for v in row]
-        a = (C.c_float * len(flat))(*flat)
-        c = (C.c_float * n)(*[float(v) for v in coef])
-        self._c(self.lib.dll.lpc_set_fista_schedule(self.h, n, a, c, stream))
+        a = (self.lib.c_real * len(flat))(*flat)
+        c = (self.lib.c_real * n)(*[float(v) for v in coef])
+        self._c(self.lib.dll.lpc_set_fista_schedule(self.h, n, C.cast(a, C.c_void_p), C.cast(c, C.c_void_p), stream))
 
     def clear_admm_schedule(self):
         self._c(self.lib.dll.lpc_set_admm_schedule(self.h, 0, None, None, None, None))
@@ -194,14 +198,13 @@ class Handle:
         return b.value
 
 
-_default = None
+_default = {}
 
 
-def default_lib() -> Lib:
-    """The product library (HIP).  Imports torch first so that the HIP runtime the extension
-    binds to is the one torch already loaded (same soname), then refuses to run without a GPU."""
-    global _default
-    if _default is None:
+def default_lib(dtype: str = "float32") -> Lib:
+    """The product library (HIP) for ``dtype``.  Imports torch first so that the HIP runtime the
+    extension binds to is the one torch already loaded (same soname), then refuses to run without a GPU."""
+    if dtype not in _default:
         import torch
 
         if not torch.cuda.is_available():
@@ -209,13 +212,16 @@ def default_lib() -> Lib:
                 "lenslesspicam_amd needs a HIP device (MI355X); none is visible and there is no CPU path."
             )
         torch.cuda.init()
-        if not os.path.exists(DEFAULT_LIB):
+        path = DEFAULT_LIB_F64 if dtype == "float64" else DEFAULT_LIB
+        if not os.path.exists(path):
             # fresh checkout on a GPU box (the .so is git-ignored): compile the HIP sources once, in-tree.
             # This builds the product library itself -- there still is no other execution path.
             from . import build as _build
 
             _build.build_hip(force=True, verbose=False)
-        _default = Lib(DEFAULT_LIB)
-        if not _default.backend().startswith("hip"):
-            raise NativeError(f"refusing non-HIP backend {_default.backend()!r} in the product path")
-    return _default
+        lib = Lib(path)
+        if not lib.backend().startswith("hip"):
+            raise NativeError(f"refusing non-HIP backend {lib.backend()!r} in the product path")
+        assert lib.real == dtype, (lib.real, dtype)
+        _default[dtype] = lib
+    return _default[dtype]

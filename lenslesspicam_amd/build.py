@@ -7,7 +7,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 SRC = os.path.join(HERE, "csrc", "lpc_engine.cpp")
-OUT = os.path.join(HERE, "_lib", "liblpc.so")
+OUT = os.path.join(HERE, "_lib", "liblpc.so")            # float32
+OUT_F64 = os.path.join(HERE, "_lib", "liblpc_f64.so")    # same translation unit with -DLPC_DOUBLE
 
 
 def sources():
@@ -16,7 +17,8 @@ def sources():
 
 
 def is_stale():
-    return not os.path.exists(OUT) or any(os.path.getmtime(f) > os.path.getmtime(OUT) for f in sources())
+    return any(not os.path.exists(o) or any(os.path.getmtime(f) > os.path.getmtime(o) for f in sources())
+               for o in (OUT, OUT_F64))
 
 
 def build_hip(force=False, verbose=True):
@@ -24,11 +26,17 @@ def build_hip(force=False, verbose=True):
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = [hipcc, "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-x", "hip", SRC,
-           "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc"), "-o", OUT]
-    if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    base = [hipcc, "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared", "-x", "hip", SRC,
+            "-I", os.path.join(ROOT, "include"), "-I", os.path.join(HERE, "csrc")]
+    procs = []
+    for out, extra in ((OUT, []), (OUT_F64, ["-DLPC_DOUBLE"])):
+        cmd = base + extra + ["-o", out]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        procs.append((cmd, subprocess.Popen(cmd)))     # the two builds run side by side
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
     return OUT
 
 

@@ -45,6 +45,8 @@ static int next_5smooth(int n) {  // scipy.fftpack.next_fast_len (rfft_convolve.
 // the fewest threads that hold the tile with <= 16 points per thread.  Measured on MI355X
 // (profiles/r01b_notes.md): the alternatives "twice the threads, half the points" (same LDS, twice
 // the waves) and "half the threads, 32 points" are both slower.
+// LDS holds 160 KiB per workgroup: 16384 complex64 points (128 KiB) or 8192 complex128 points
+static constexpr int kMaxTilePoints = (int)(131072 / sizeof(real2));
 template <class F>
 static int dispatch_cfg(int nelem, F&& f) {
   using std::integral_constant;
@@ -52,8 +54,9 @@ static int dispatch_cfg(int nelem, F&& f) {
   if (nelem <= 2048) return f(integral_constant<int, 256>{}, integral_constant<int, 8>{});
   if (nelem <= 4096) return f(integral_constant<int, 256>{}, integral_constant<int, 16>{});
   if (nelem <= 8192) return f(integral_constant<int, 512>{}, integral_constant<int, 16>{});
-  if (nelem <= 16384) return f(integral_constant<int, 1024>{}, integral_constant<int, 16>{});
-  return fail("FFT tile of " + std::to_string(nelem) + " points exceeds the LDS budget (16384)");
+  if (nelem <= kMaxTilePoints) return f(integral_constant<int, 1024>{}, integral_constant<int, 16>{});
+  return fail("FFT tile of " + std::to_string(nelem) + " points exceeds the LDS budget (" +
+              std::to_string(kMaxTilePoints) + ")");
 }
 
 // row kernels: (NT, EMAX) by row length, plus the LDS-skew flag of the plan
@@ -85,39 +88,39 @@ struct lpc_engine {
   size_t total_bytes = 0;
 
   // spectral constants
-  float2* Hs = nullptr;     // [Ppsf] PSF spectrum, permuted row order, norm applied
-  float* Gabs = nullptr;    // ADMM: |PsiT Psi| spectrum, ONE plane (identical for every channel)
+  real2* Hs = nullptr;     // [Ppsf] PSF spectrum, permuted row order, norm applied
+  real* Gabs = nullptr;    // ADMM: |PsiT Psi| spectrum, ONE plane (identical for every channel)
   std::vector<double> sched[4];  // optional per-iteration mu1, mu2, mu3, tau (unrolled ADMM)
   double last_par[4] = {0, 0, 0, 0};  // parameters of the most recent iteration
-  float2* phr = nullptr;    // [Hp] ifftshift phase, stored row order
-  float2* phc = nullptr;    // [Wc]
-  float2* twH = nullptr;
+  real2* phr = nullptr;    // [Hp] ifftshift phase, stored row order
+  real2* phc = nullptr;    // [Wc]
+  real2* twH = nullptr;
   // work spectra: [2][P] planes (ADMM uses both halves, others the first)
-  float2* S = nullptr;
+  real2* S = nullptr;
   // ADMM state (padded real planes)
-  float *V[2] = {nullptr, nullptr}, *HV = nullptr, *X = nullptr, *xi = nullptr, *rho = nullptr,
+  real *V[2] = {nullptr, nullptr}, *HV = nullptr, *X = nullptr, *xi = nullptr, *rho = nullptr,
         *Rsp = nullptr, *Aarr = nullptr;
-  float *eta0[2] = {nullptr, nullptr}, *eta1[2] = {nullptr, nullptr};  // ping-pong (halo reads)
+  real *eta0[2] = {nullptr, nullptr}, *eta1[2] = {nullptr, nullptr};  // ping-pong (halo reads)
   int vcur = 0, ecur = 0;
   // the reference clamps the image estimate IN PLACE whenever _form_image runs (admm.py:331-338);
   // only the W-update ever sees that clamped copy: Vw[0] = V as seen by the next iteration's W,
   // Vw[1] = V as seen by the previous iteration's W (needed to recompute W_old).  Null = same as V.
-  float* Vw[2] = {nullptr, nullptr};
+  real* Vw[2] = {nullptr, nullptr};
   bool vw_cur = false, vw_old = false;
   // GD family state (un-padded planes)
-  float *gx = nullptr, *gaux = nullptr;  // x and (p | xk_prev)
-  float* galpha = nullptr;               // [C] device
-  float* gx0 = nullptr;                  // [C] default start value per channel
-  float2* S2 = nullptr;                  // second spectrum buffer (row-inverse+forward is out of place)
+  real *gx = nullptr, *gaux = nullptr;  // x and (p | xk_prev)
+  real* galpha = nullptr;               // [C] device
+  real* gx0 = nullptr;                  // [C] default start value per channel
+  real2* S2 = nullptr;                  // second spectrum buffer (row-inverse+forward is out of place)
   double tk = 1.0, nest_mu = 0.9, nest_p = 0.0;
   // unrolled FISTA (unrolled_fista.py:91-106): per-iteration step alpha[i][c] and momentum factor coef[i]
-  std::vector<float> fista_coef;
-  float* galpha_sched = nullptr;  // device [n][C]
+  std::vector<real> fista_coef;
+  real* galpha_sched = nullptr;  // device [n][C]
   int fista_sched_n = 0;
   // common
-  float* Y = nullptr;         // data planes, un-padded [Pdata][H][W]
-  float* init_est = nullptr;  // planar copy of the initial estimate (or null)
-  float* psf_planar = nullptr;
+  real* Y = nullptr;         // data planes, un-padded [Pdata][H][W]
+  real* init_est = nullptr;  // planar copy of the initial estimate (or null)
+  real* psf_planar = nullptr;
   bool has_init = false, psf_set = false, data_set = false, first = true;
   long iters_done = 0;
   KernelTimer timer;
@@ -185,14 +188,14 @@ static int upload(Engine* e, void* dst, const void* src, size_t bytes) {
   return 0;
 }
 
-static int make_twiddles(Engine* e, int n, float2** out) {
-  std::vector<float2> h((size_t)std::max(n, 1));
+static int make_twiddles(Engine* e, int n, real2** out) {
+  std::vector<real2> h((size_t)std::max(n, 1));
   for (int q = 0; q < n; ++q) {
     const double a = -2.0 * M_PI * (double)q / (double)n;
-    h[q] = make_float2((float)std::cos(a), (float)std::sin(a));
+    h[q] = make_real2((real)std::cos(a), (real)std::sin(a));
   }
   LPC_OK(dev_alloc(e, out, h.size()));
-  return upload(e, *out, h.data(), h.size() * sizeof(float2));
+  return upload(e, *out, h.data(), h.size() * sizeof(real2));
 }
 
 static int build_plan(Engine* e, Fft1dPlan& p, int n) {
@@ -253,7 +256,7 @@ static int build_plan(Engine* e, Fft1dPlan& p, int n) {
     if (!(p.ns[st] % 8 == 0 || (p.ns[st] == 1 && p.radix[st] % 8 == 0))) p.skew_ok = 0;
   }
   if (std::getenv("LPC_NO_SKEW")) p.skew_ok = 0;
-  float2* tw = nullptr;
+  real2* tw = nullptr;
   LPC_OK(make_twiddles(e, n, &tw));
   p.tw = tw;
   return 0;
@@ -264,7 +267,7 @@ static void choose_split(int Hp, int Wc, int* N1, int* N2, int* T) {
   int t = 16;
   if (const char* env = std::getenv("LPC_COL_T")) t = std::max(1, atoi(env));  // tuning knob
   while (t > 1 && t / 2 >= Wc) t /= 2;  // tiny images: do not waste lanes on empty columns
-  int budget = 16384;                   // points per LDS tile, worst case two arrays (ADMM middle)
+  int budget = kMaxTilePoints;          // points per LDS tile, worst case two arrays (ADMM middle)
   if (const char* env = std::getenv("LPC_TILE_BUDGET")) budget = std::max(64, atoi(env));  // test knob
   for (int tt = t; tt >= (t >= 8 ? 8 : t); tt /= 2) {
     if ((long)Hp * 2 * tt <= budget) { *N1 = 1; *N2 = Hp; *T = tt; return; }
@@ -303,7 +306,8 @@ static int setup_geometry(Engine* e) {
   e->Ppsf = g.DC;
   e->P = c.batch * g.DC;
   e->Pdata = c.batch * c.channels;
-  if (g.Wp > 16384) return fail("padded width " + std::to_string(g.Wp) + " > 16384 is not supported");
+  if (g.Wp > kMaxTilePoints)
+    return fail("padded width " + std::to_string(g.Wp) + " > " + std::to_string(kMaxTilePoints) + " is not supported");
   choose_split(g.Hp, g.Wc, &e->N1, &e->N2, &e->T);
   LPC_OK(build_plan(e, e->planW, g.Wp));
   LPC_OK(build_plan(e, e->planB, e->N2));
@@ -318,26 +322,26 @@ static int setup_geometry(Engine* e) {
   B = A;
   B.N = e->N2; B.G = e->N1; B.istride = 1; B.gstride = e->N2;
   // ifftshift phases: out[i] = in[(i + n/2) mod n]  <=>  multiply bin k by exp(+2 pi i k (n/2) / n)
-  std::vector<float2> pr((size_t)g.Hp), pc((size_t)g.Wc);
+  std::vector<real2> pr((size_t)g.Hp), pc((size_t)g.Wc);
   for (int p = 0; p < g.Hp; ++p) {
     const long k = stored_row_freq(e, p);
     const double a = 2.0 * M_PI * (double)((k * (g.Hp / 2)) % g.Hp) / (double)g.Hp;
-    pr[p] = make_float2((float)std::cos(a), (float)std::sin(a));
+    pr[p] = make_real2((real)std::cos(a), (real)std::sin(a));
   }
   for (int k = 0; k < g.Wc; ++k) {
     const double a = 2.0 * M_PI * (double)(((long)k * (g.Wp / 2)) % g.Wp) / (double)g.Wp;
-    pc[k] = make_float2((float)std::cos(a), (float)std::sin(a));
+    pc[k] = make_real2((real)std::cos(a), (real)std::sin(a));
   }
   LPC_OK(dev_alloc(e, &e->phr, pr.size()));
   LPC_OK(dev_alloc(e, &e->phc, pc.size()));
-  LPC_OK(upload(e, e->phr, pr.data(), pr.size() * sizeof(float2)));
-  LPC_OK(upload(e, e->phc, pc.data(), pc.size() * sizeof(float2)));
+  LPC_OK(upload(e, e->phr, pr.data(), pr.size() * sizeof(real2)));
+  LPC_OK(upload(e, e->phc, pc.data(), pc.size() * sizeof(real2)));
   return 0;
 }
 
 // ------------------------------------------------------------- 2-D transform pieces --
 // forward rows of ONE real source (pairs of rows) into spectrum S (planes = nplanes)
-static int rows_fwd_single(Engine* e, const RealSrc& src, float2* S, int nplanes, int kid) {
+static int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
   const int nblk = (src.nrows + 1) / 2;
   return dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NT, auto EM, auto SK) {
@@ -349,7 +353,7 @@ static int rows_fwd_single(Engine* e, const RealSrc& src, float2* S, int nplanes
 }
 
 // column pass A (only when split) over nplanes planes; inverse => conj twiddles before FFT
-static int cols_passA(Engine* e, float2* S, int nplanes, bool inverse, int zr0, int zr1, int kid) {
+static int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1, int kid) {
   if (e->N1 == 1) return 0;
   const PlaneGeom& g = e->g;
   ColPass cp = e->passA;
@@ -358,14 +362,14 @@ static int cols_passA(Engine* e, float2* S, int nplanes, bool inverse, int zr0, 
   const dim3 grid(cp.G * cp.ntile_c, nplanes);
   return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    const size_t smem = (size_t)cp.N * cp.T * sizeof(float2);
+    const size_t smem = (size_t)cp.N * cp.T * sizeof(real2);
     if (inverse) return launch_k(e, kid, k_cols<nt, em, true>, grid, nt, smem, g, e->planA, cp, S);
     return launch_k(e, kid, k_cols<nt, em, false>, grid, nt, smem, g, e->planA, cp, S);
   });
 }
 
 // plain forward pass B (setup transforms only)
-static int cols_passB_fwd(Engine* e, float2* S, int nplanes, int zr0, int zr1) {
+static int cols_passB_fwd(Engine* e, real2* S, int nplanes, int zr0, int zr1) {
   const PlaneGeom& g = e->g;
   ColPass cp = e->passB;
   cp.tw_mode = 0;
@@ -373,13 +377,13 @@ static int cols_passB_fwd(Engine* e, float2* S, int nplanes, int zr0, int zr1) {
   const dim3 grid(cp.G * cp.ntile_c, nplanes);
   return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    return launch_k(e, -1, k_cols<nt, em, false>, grid, nt, (size_t)cp.N * cp.T * sizeof(float2), g, e->planB,
+    return launch_k(e, -1, k_cols<nt, em, false>, grid, nt, (size_t)cp.N * cp.T * sizeof(real2), g, e->planB,
                     cp, S);
   });
 }
 
 // full forward 2-D transform of a real source into S (used for the PSF and the TV gram)
-static int fft2_forward_setup(Engine* e, const RealSrc& src, float2* S, int nplanes) {
+static int fft2_forward_setup(Engine* e, const RealSrc& src, real2* S, int nplanes) {
   const PlaneGeom& g = e->g;
   const int zr0 = src.out_row0, zr1 = src.out_row0 + src.nrows;
   LPC_OK(rows_fwd_single(e, src, S, nplanes, -1));
@@ -393,7 +397,7 @@ static int fft2_forward_setup(Engine* e, const RealSrc& src, float2* S, int npla
 }
 
 // middle of a convolution on S (nplanes): [A] -> B fwd * H * B inv -> [A inv]
-static int conv_middle(Engine* e, float2* S, int nplanes, bool adjoint, int zr0, int zr1) {
+static int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, int zr1) {
   const PlaneGeom& g = e->g;
   const bool split = e->N1 > 1;
   if (split) LPC_OK(cols_passA(e, S, nplanes, false, zr0, zr1, LPC_K_COL_A_FWD));
@@ -401,17 +405,17 @@ static int conv_middle(Engine* e, float2* S, int nplanes, bool adjoint, int zr0,
   cp.zr0 = split ? 0 : zr0;
   cp.zr1 = split ? g.Hp : zr1;
   const dim3 grid(cp.G * cp.ntile_c, nplanes);
-  const float hscale = 1.0f / ((float)g.Hp * (float)g.Wp);
+  const real hscale = (real)1.0 / ((real)g.Hp * (real)g.Wp);
   LPC_OK(dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    return launch_k(e, LPC_K_COL_MID, k_cols_mid_mul<nt, em>, grid, nt, (size_t)cp.N * cp.T * sizeof(float2), g,
-                    e->planB, cp, S, (const float2*)e->Hs, adjoint ? 1 : 0, hscale, e->Ppsf);
+    return launch_k(e, LPC_K_COL_MID, k_cols_mid_mul<nt, em>, grid, nt, (size_t)cp.N * cp.T * sizeof(real2), g,
+                    e->planB, cp, S, (const real2*)e->Hs, adjoint ? 1 : 0, hscale, e->Ppsf);
   }));
   if (split) LPC_OK(cols_passA(e, S, nplanes, true, 0, g.Hp, LPC_K_COL_A_INV));
   return 0;
 }
 
-static int rows_inv_single(Engine* e, const float2* S, const RealDst& dst, int nplanes, int kid) {
+static int rows_inv_single(Engine* e, const real2* S, const RealDst& dst, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
   const int nblk = (dst.nrows + 1) / 2;
   return dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NT, auto EM, auto SK) {
@@ -422,28 +426,28 @@ static int rows_inv_single(Engine* e, const float2* S, const RealDst& dst, int n
   });
 }
 
-static RealSrc src_unpadded(const Engine* e, const float* base) {
+static RealSrc src_unpadded(const Engine* e, const real* base) {
   const PlaneGeom& g = e->g;
   RealSrc s;
   s.base = base; s.plane_stride = g.uplane; s.pitch = g.W; s.nrows = g.H; s.ncols = g.W; s.col0 = g.sw;
   s.out_row0 = g.sh;
   return s;
 }
-static RealSrc src_padded(const Engine* e, const float* base) {
+static RealSrc src_padded(const Engine* e, const real* base) {
   const PlaneGeom& g = e->g;
   RealSrc s;
   s.base = base; s.plane_stride = g.rplane; s.pitch = g.rpitch; s.nrows = g.Hp; s.ncols = g.Wp; s.col0 = 0;
   s.out_row0 = 0;
   return s;
 }
-static RealDst dst_padded(const Engine* e, float* base) {
+static RealDst dst_padded(const Engine* e, real* base) {
   const PlaneGeom& g = e->g;
   RealDst d;
   d.base = base; d.plane_stride = g.rplane; d.pitch = g.rpitch; d.nrows = g.Hp; d.row0 = 0; d.col0 = 0;
   d.ncols = g.Wp;
   return d;
 }
-static RealDst dst_cropped(const Engine* e, float* base) {
+static RealDst dst_cropped(const Engine* e, real* base) {
   const PlaneGeom& g = e->g;
   RealDst d;
   d.base = base; d.plane_stride = g.uplane; d.pitch = g.W; d.nrows = g.H; d.row0 = g.sh; d.col0 = g.sw;
@@ -452,7 +456,7 @@ static RealDst dst_cropped(const Engine* e, float* base) {
 }
 
 // planar real (padded or not) -> convolution with H / H* -> planar real, same kind
-static int convolve_planar(Engine* e, const float* xin, float* xout, int nplanes, bool padded_io, bool adjoint) {
+static int convolve_planar(Engine* e, const real* xin, real* xout, int nplanes, bool padded_io, bool adjoint) {
   const PlaneGeom& g = e->g;
   if (padded_io) {
     LPC_OK(rows_fwd_single(e, src_padded(e, xin), e->S, nplanes, LPC_K_ROW_FWD));
@@ -467,13 +471,13 @@ static int convolve_planar(Engine* e, const float* xin, float* xout, int nplanes
 }
 
 // ------------------------------------------------------------------ layout helpers --
-static int hwc_to_planar(Engine* e, const float* src, float* dst, int nimg, int rows, int cols, int pitch,
+static int hwc_to_planar(Engine* e, const real* src, real* dst, int nimg, int rows, int cols, int pitch,
                          long dplane) {
   const long n = (long)rows * cols * e->cfg.channels;
   return launch_k(e, -1, k_hwc_to_planar<256>, grid1d(n, 256, nimg), 256, 0, src, dst, rows, cols,
                   e->cfg.channels, pitch, dplane);
 }
-static int planar_to_hwc(Engine* e, float* src, float* dst, int nimg, int rows, int cols, int pitch, long splane,
+static int planar_to_hwc(Engine* e, real* src, real* dst, int nimg, int rows, int cols, int pitch, long splane,
                          int row0, int col0, int clamp) {
   const long n = (long)rows * cols * e->cfg.channels;
   return launch_k(e, -1, k_planar_to_hwc<256>, grid1d(n, 256, nimg), 256, 0, src, dst, rows, cols,
@@ -493,23 +497,23 @@ static void admm_params(const Engine* e, long it, double out[4]) {
 
 static AdmmScalars admm_scalars(const Engine* e, const double cur[4]) {
   AdmmScalars p;
-  p.mu1 = (float)cur[0]; p.mu2 = (float)cur[1]; p.mu3 = (float)cur[2];
-  p.thr = (float)(cur[3] / cur[1]);               // admm.py:246: python-double division, then float32
-  p.m_in = 1.0f / (1.0f + p.mu1);                 // admm.py:193 in float32
-  p.m_out = 1.0f / (0.0f + p.mu1);
+  p.mu1 = (real)cur[0]; p.mu2 = (real)cur[1]; p.mu3 = (real)cur[2];
+  p.thr = (real)(cur[3] / cur[1]);               // admm.py:246: python-double division, then float32
+  p.m_in = (real)1.0 / ((real)1.0 + p.mu1);                 // admm.py:193 in float32
+  p.m_out = (real)1.0 / ((real)0.0 + p.mu1);
   p.first = e->first ? 1 : 0;
   const double* prev = e->first ? cur : e->last_par;
-  p.mu1p = (float)prev[0]; p.mu2p = (float)prev[1]; p.mu3p = (float)prev[2];
-  p.thrp = (float)(prev[3] / prev[1]);
+  p.mu1p = (real)prev[0]; p.mu2p = (real)prev[1]; p.mu3p = (real)prev[2];
+  p.thrp = (real)(prev[3] / prev[1]);
   return p;
 }
 
 static int admm_alloc(Engine* e) {
   const PlaneGeom& g = e->g;
   const size_t rp = (size_t)g.rplane * e->P;
-  float** bufs[] = {&e->V[0], &e->V[1], &e->HV, &e->X, &e->xi, &e->eta0[0], &e->eta0[1], &e->eta1[0],
+  real** bufs[] = {&e->V[0], &e->V[1], &e->HV, &e->X, &e->xi, &e->eta0[0], &e->eta0[1], &e->eta1[0],
                     &e->eta1[1], &e->rho, &e->Rsp, &e->Aarr};
-  for (float** b : bufs) LPC_OK(dev_alloc(e, b, rp));
+  for (real** b : bufs) LPC_OK(dev_alloc(e, b, rp));
   LPC_OK(dev_alloc(e, &e->Gabs, (size_t)g.cplane));
   return 0;
 }
@@ -519,28 +523,28 @@ static int admm_setup_constants(Engine* e) {
   // kernel; here only |PsiT Psi| is prepared.  The gram spectrum is produced by the engine's own forward
   // transform of the 5-point stencil (admm.py:385-397) so that it lands in the permuted row order.
   const PlaneGeom& g = e->g;
-  float* stencil = e->Rsp;  // scratch: one padded plane
-  LPC_RT(rt::memset_async(stencil, 0, (size_t)g.rplane * sizeof(float), e->stream));
-  std::vector<float> host((size_t)g.rplane, 0.f);
+  real* stencil = e->Rsp;  // scratch: one padded plane
+  LPC_RT(rt::memset_async(stencil, 0, (size_t)g.rplane * sizeof(real), e->stream));
+  std::vector<real> host((size_t)g.rplane, (real)0.);
   // gram[0,0]=4; [0,1]=[0,-1]=[1,0]=[-1,0]=-1 with python negative indexing (later writes win)
-  host[0] = 4.f;
-  host[(size_t)(1 % g.Wp)] = -1.f;
-  host[(size_t)(g.Wp - 1)] = -1.f;
-  host[(size_t)(1 % g.Hp) * g.rpitch] = -1.f;
-  host[(size_t)(g.Hp - 1) * g.rpitch] = -1.f;
-  LPC_OK(upload(e, stencil, host.data(), host.size() * sizeof(float)));
-  float2* Gs = e->S;  // scratch spectrum plane
+  host[0] = (real)4.;
+  host[(size_t)(1 % g.Wp)] = -(real)1.;
+  host[(size_t)(g.Wp - 1)] = -(real)1.;
+  host[(size_t)(1 % g.Hp) * g.rpitch] = -(real)1.;
+  host[(size_t)(g.Hp - 1) * g.rpitch] = -(real)1.;
+  LPC_OK(upload(e, stencil, host.data(), host.size() * sizeof(real)));
+  real2* Gs = e->S;  // scratch spectrum plane
   LPC_OK(fft2_forward_setup(e, src_padded(e, stencil), Gs, 1));
-  LPC_OK(launch_k(e, -1, k_abs_complex<256>, grid1d((long)g.cplane, 256), 256, 0, (const float2*)Gs, e->Gabs,
+  LPC_OK(launch_k(e, -1, k_abs_complex<256>, grid1d((long)g.cplane, 256), 256, 0, (const real2*)Gs, e->Gabs,
                   (long)g.cplane));
   return 0;
 }
 
 static int admm_reset(Engine* e) {
   const PlaneGeom& g = e->g;
-  const size_t rb = (size_t)g.rplane * e->P * sizeof(float);
-  float* zero[] = {e->V[1], e->X, e->xi, e->eta0[0], e->eta1[0], e->rho, e->HV};
-  for (float* z : zero) LPC_RT(rt::memset_async(z, 0, rb, e->stream));
+  const size_t rb = (size_t)g.rplane * e->P * sizeof(real);
+  real* zero[] = {e->V[1], e->X, e->xi, e->eta0[0], e->eta1[0], e->rho, e->HV};
+  for (real* z : zero) LPC_RT(rt::memset_async(z, 0, rb, e->stream));
   e->vcur = 0;
   e->ecur = 0;
   e->vw_cur = e->vw_old = false;
@@ -559,38 +563,44 @@ static int admm_reset(Engine* e) {
 static int admm_iterate(Engine* e, int n_iter) {
   const PlaneGeom& g = e->g;
   constexpr int TH = 16, TW = 64, NT = 256;
-  const size_t k1_smem = (size_t)(2 * (TH + 2) * (TW + 2) + (TH + 1) * TW + TH * (TW + 1)) * sizeof(float);
+  const size_t k1_smem = (size_t)(2 * (TH + 2) * (TW + 2) + (TH + 1) * TW + TH * (TW + 1)) * sizeof(real);
   const unsigned tiles_x = (g.Wp + TW - 1) / TW, tiles_y = (g.Hp + TH - 1) / TH;
   const dim3 k1_grid(tiles_x * tiles_y, e->P, 1);
-  float2* SA = e->S;
-  float2* SB = e->S + (size_t)e->P * g.cplane;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
   const bool split = e->N1 > 1;
   // 16-byte-lane kernel whenever the padded width allows aligned float4 rows (every BASELINE size does)
   static int force_scalar = -1;
   if (force_scalar < 0) force_scalar = std::getenv("LPC_K1_SCALAR") ? 1 : 0;
+#ifdef LPC_DOUBLE
+  const bool vec4 = false;  // the 16-byte-lane kernel is float-only
+#else
   const bool vec4 = (g.Wp % 4 == 0) && !force_scalar;
+#endif
   constexpr int TH4 = 8, TW4 = 256;
   const unsigned tiles_x4 = (g.Wp + TW4 - 1) / TW4, tiles_y4 = (g.Hp + TH4 - 1) / TH4;
   const dim3 k1_grid4(tiles_x4 * tiles_y4, e->P, 1);
-  const size_t k1_smem4 = (size_t)2 * (TH4 + 2) * (TW4 + 8) * sizeof(float);
+  const size_t k1_smem4 = (size_t)2 * (TH4 + 2) * (TW4 + 8) * sizeof(real);
   for (int it = 0; it < n_iter; ++it) {
-    float* Vc = e->V[e->vcur];
-    float* Vo = e->V[e->vcur ^ 1];
+    real* Vc = e->V[e->vcur];
+    real* Vo = e->V[e->vcur ^ 1];
     double par[4];
     admm_params(e, e->iters_done, par);
     AdmmScalars sc = admm_scalars(e, par);
+#ifndef LPC_DOUBLE
     if (vec4)
-      LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT>, k1_grid4, NT, k1_smem4, g, sc, (const float*)Vc,
-                      (const float*)Vo, (const float*)e->HV, e->X, e->xi, (const float*)e->eta0[e->ecur],
-                      (const float*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
-                      (const float*)e->Y, e->Rsp, e->Aarr, tiles_x4,
-                      (const float*)(e->vw_cur ? e->Vw[0] : nullptr), (const float*)(e->vw_old ? e->Vw[1] : nullptr)));
+      LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT>, k1_grid4, NT, k1_smem4, g, sc, (const real*)Vc,
+                      (const real*)Vo, (const real*)e->HV, e->X, e->xi, (const real*)e->eta0[e->ecur],
+                      (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
+                      (const real*)e->Y, e->Rsp, e->Aarr, tiles_x4,
+                      (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
     else
-    LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial<TH, TW, NT>, k1_grid, NT, k1_smem, g, sc, (const float*)Vc,
-                    (const float*)Vo, (const float*)e->HV, e->X, e->xi, (const float*)e->eta0[e->ecur],
-                    (const float*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
-                    (const float*)e->Y, e->Rsp, e->Aarr, tiles_x,
-                    (const float*)(e->vw_cur ? e->Vw[0] : nullptr), (const float*)(e->vw_old ? e->Vw[1] : nullptr)));
+#endif
+    LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial<TH, TW, NT>, k1_grid, NT, k1_smem, g, sc, (const real*)Vc,
+                    (const real*)Vo, (const real*)e->HV, e->X, e->xi, (const real*)e->eta0[e->ecur],
+                    (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
+                    (const real*)e->Y, e->Rsp, e->Aarr, tiles_x,
+                    (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
     std::swap(e->Vw[0], e->Vw[1]);  // this iteration's "V for W" becomes the next one's "V_old for W_old"
     e->vw_old = e->vw_cur;
     e->vw_cur = false;
@@ -600,7 +610,7 @@ static int admm_iterate(Engine* e, int n_iter) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
       constexpr bool sk = decltype(SK)::value;
       return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<nt, em, sk>, dim3(g.Hp, e->P), nt,
-                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const float*)e->Rsp, (const float*)e->Aarr, SA, SB);
+                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
     }));
     if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, false, 0, g.Hp, LPC_K_COL_A_FWD));
     {
@@ -610,9 +620,9 @@ static int admm_iterate(Engine* e, int n_iter) {
       LPC_OK(dispatch_cfg(cp.N * cp.T * 2, [&](auto NTc, auto EM) {
         constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
         return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<nt, em>, grid, nt,
-                        (size_t)cp.N * cp.T * 2 * sizeof(float2), g, e->planB, cp, SA, SB, (const float2*)e->Hs,
-                        (const float*)e->Gabs, (const float2*)e->phr, (const float2*)e->phc, t2, sc.mu1, sc.mu2,
-                        sc.mu3, 1.0f / ((float)g.Hp * (float)g.Wp));
+                        (size_t)cp.N * cp.T * 2 * sizeof(real2), g, e->planB, cp, SA, SB, (const real2*)e->Hs,
+                        (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2, sc.mu1, sc.mu2,
+                        sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp));
       }));
     }
     if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, true, 0, g.Hp, LPC_K_COL_A_INV));
@@ -620,7 +630,7 @@ static int admm_iterate(Engine* e, int n_iter) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
       constexpr bool sk = decltype(SK)::value;
       return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em, sk>, dim3(g.Hp, e->P), nt,
-                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const float2*)SA, (const float2*)SB, Vo, e->HV);
+                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const real2*)SA, (const real2*)SB, Vo, e->HV);
     }));
     e->vcur ^= 1;  // Vo now holds the new image estimate
     for (int k = 0; k < 4; ++k) e->last_par[k] = par[k];
@@ -636,6 +646,7 @@ extern "C" {
 
 const char* lpc_last_error(void) { return g_last_error.c_str(); }
 const char* lpc_backend(void) { return rt::backend_name(); }
+const char* lpc_real_name(void) { return LPC_REAL_NAME; }
 
 int lpc_create(const lpc_config* cfg, lpc_handle* out) {
   if (!cfg || !out) return fail("lpc_create: null argument");
@@ -700,7 +711,7 @@ int lpc_workspace_bytes(lpc_handle e, size_t* bytes) {
   return 0;
 }
 
-int lpc_set_psf(lpc_handle e, const float* dev_psf, void* stream) {
+int lpc_set_psf(lpc_handle e, const real* dev_psf, void* stream) {
   if (!e || !dev_psf) return fail("lpc_set_psf: null argument");
   e->stream = (lpcStream_t)stream;
   const PlaneGeom& g = e->g;
@@ -712,7 +723,7 @@ int lpc_set_psf(lpc_handle e, const float* dev_psf, void* stream) {
   if (e->cfg.norm == LPC_NORM_FORWARD) sc = 1.0 / ((double)g.Hp * (double)g.Wp);
   if (sc != 1.0) {
     const long n = (long)g.cplane * e->Ppsf;
-    LPC_OK(launch_k(e, -1, k_scale_complex<256>, grid1d(n, 256), 256, 0, e->Hs, n, (float)sc));
+    LPC_OK(launch_k(e, -1, k_scale_complex<256>, grid1d(n, 256), 256, 0, e->Hs, n, (real)sc));
   }
   e->psf_set = true;
   if (e->cfg.algo == LPC_ALGO_ADMM) LPC_OK(admm_setup_constants(e));
@@ -721,7 +732,7 @@ int lpc_set_psf(lpc_handle e, const float* dev_psf, void* stream) {
   return 0;
 }
 
-int lpc_convolve(lpc_handle e, const float* dev_x, float* dev_out, int n, int adjoint, void* stream) {
+int lpc_convolve(lpc_handle e, const real* dev_x, real* dev_out, int n, int adjoint, void* stream) {
   if (!e || !dev_x || !dev_out) return fail("lpc_convolve: null argument");
   if (!e->psf_set) return fail("lpc_convolve: PSF not set");
   if (n < 1 || n > e->cfg.batch) return fail("lpc_convolve: n exceeds the configured batch");
@@ -731,8 +742,8 @@ int lpc_convolve(lpc_handle e, const float* dev_x, float* dev_out, int n, int ad
   const int nplanes = n * g.DC;
   const bool padded_io = !e->cfg.pad;
   // staging planes live in the tail of the handle's scratch
-  float* xin = (float*)e->gaux;
-  float* xout = (float*)e->gx;
+  real* xin = (real*)e->gaux;
+  real* xout = (real*)e->gx;
   const int nimg = n * e->cfg.depth;
   if (padded_io) {
     LPC_OK(hwc_to_planar(e, dev_x, xin, nimg, g.Hp, g.Wp, g.rpitch, g.rplane));
@@ -746,7 +757,7 @@ int lpc_convolve(lpc_handle e, const float* dev_x, float* dev_out, int n, int ad
   return 0;
 }
 
-int lpc_set_data(lpc_handle e, const float* dev_data, void* stream) {
+int lpc_set_data(lpc_handle e, const real* dev_data, void* stream) {
   if (!e || !dev_data) return fail("lpc_set_data: null argument");
   if (e->cfg.algo == LPC_ALGO_CONV) return fail("lpc_set_data: operator-only handle");
   e->stream = (lpcStream_t)stream;
@@ -756,7 +767,7 @@ int lpc_set_data(lpc_handle e, const float* dev_data, void* stream) {
   return 0;
 }
 
-int lpc_set_initial_estimate(lpc_handle e, const float* dev_est, void* stream) {
+int lpc_set_initial_estimate(lpc_handle e, const real* dev_est, void* stream) {
   if (!e) return fail("null handle");
   if (e->cfg.algo == LPC_ALGO_CONV) return fail("lpc_set_initial_estimate: operator-only handle");
   e->stream = (lpcStream_t)stream;
@@ -803,7 +814,7 @@ int lpc_set_admm_schedule(lpc_handle e, int n, const double* mu1, const double* 
   return 0;
 }
 
-int lpc_set_fista_schedule(lpc_handle e, int n, const float* alpha, const float* coef, void* stream) {
+int lpc_set_fista_schedule(lpc_handle e, int n, const real* alpha, const real* coef, void* stream) {
   if (!e) return fail("null handle");
   if (e->cfg.algo != LPC_ALGO_FISTA) return fail("lpc_set_fista_schedule: not a FISTA handle");
   e->stream = (lpcStream_t)stream;
@@ -813,7 +824,7 @@ int lpc_set_fista_schedule(lpc_handle e, int n, const float* alpha, const float*
   if (!alpha || !coef) return fail("lpc_set_fista_schedule: null array");
   const int C = e->cfg.channels;
   LPC_OK(dev_alloc(e, &e->galpha_sched, (size_t)n * C));
-  LPC_OK(upload(e, e->galpha_sched, alpha, (size_t)n * C * sizeof(float)));
+  LPC_OK(upload(e, e->galpha_sched, alpha, (size_t)n * C * sizeof(real)));
   e->fista_coef.assign(coef, coef + n);
   e->fista_sched_n = n;
   return 0;
@@ -830,7 +841,7 @@ int lpc_iterate(lpc_handle e, int n_iter, void* stream) {
   return fail("lpc_iterate: operator-only handle");
 }
 
-int lpc_form_image(lpc_handle e, float* dev_out, void* stream) {
+int lpc_form_image(lpc_handle e, real* dev_out, void* stream) {
   if (!e || !dev_out) return fail("lpc_form_image: null argument");
   e->stream = (lpcStream_t)stream;
   const PlaneGeom& g = e->g;
@@ -845,7 +856,7 @@ int lpc_form_image(lpc_handle e, float* dev_out, void* stream) {
       LPC_OK(dev_alloc(e, &e->Vw[1], (size_t)g.rplane * e->P));
     }
     LPC_OK(launch_k(e, -1, k_clamp_window_copy<256>, grid1d((long)g.Hp * g.rpitch, 256, e->P), 256, 0, g,
-                    (const float*)e->V[e->vcur], e->Vw[0]));
+                    (const real*)e->V[e->vcur], e->Vw[0]));
     e->vw_cur = true;
     return 0;
   }
@@ -854,7 +865,7 @@ int lpc_form_image(lpc_handle e, float* dev_out, void* stream) {
   return fail("lpc_form_image: operator-only handle");
 }
 
-int lpc_get_state(lpc_handle e, const char* name, float* dev_out, void* stream) {
+int lpc_get_state(lpc_handle e, const char* name, real* dev_out, void* stream) {
   if (!e || !name || !dev_out) return fail("lpc_get_state: null argument");
   e->stream = (lpcStream_t)stream;
   const PlaneGeom& g = e->g;
@@ -862,7 +873,7 @@ int lpc_get_state(lpc_handle e, const char* name, float* dev_out, void* stream) 
   const int nimg = e->cfg.batch * e->cfg.depth;
   if (e->cfg.algo >= LPC_ALGO_GD) return gd_get_state(e, nm, dev_out);
   if (e->cfg.algo != LPC_ALGO_ADMM) return fail("lpc_get_state: operator-only handle");
-  auto out_padded = [&](float* src) {
+  auto out_padded = [&](real* src) {
     return planar_to_hwc(e, src, dev_out, nimg, g.Hp, g.Wp, g.rpitch, g.rplane, 0, 0, 0);
   };
   if (nm == "image_est") return out_padded(e->vw_cur ? e->Vw[0] : e->V[e->vcur]);
@@ -870,25 +881,25 @@ int lpc_get_state(lpc_handle e, const char* name, float* dev_out, void* stream) 
   if (nm == "X") return out_padded(e->X);
   // the rest needs the pending dual update applied: materialise into scratch
   const long ostride = (long)g.rplane * e->P;
-  float* scratch = nullptr;
-  LPC_RT(rt::dev_malloc((void**)&scratch, (size_t)ostride * 7 * sizeof(float)));
+  real* scratch = nullptr;
+  LPC_RT(rt::dev_malloc((void**)&scratch, (size_t)ostride * 7 * sizeof(real)));
   double par[4];
   admm_params(e, e->iters_done, par);
   AdmmScalars sc = admm_scalars(e, par);
   int rc = launch_k(e, -1, k_admm_flush<256>, grid1d((long)g.Hp * g.Wp, 256, e->P), 256, 0, g, sc,
-                    (const float*)e->V[e->vcur], (const float*)e->V[e->vcur ^ 1], (const float*)e->HV,
-                    (const float*)e->X, (const float*)e->xi, (const float*)e->eta0[e->ecur],
-                    (const float*)e->eta1[e->ecur], (const float*)e->rho, scratch, ostride,
-                    (const float*)(e->vw_old ? e->Vw[1] : nullptr));
+                    (const real*)e->V[e->vcur], (const real*)e->V[e->vcur ^ 1], (const real*)e->HV,
+                    (const real*)e->X, (const real*)e->xi, (const real*)e->eta0[e->ecur],
+                    (const real*)e->eta1[e->ecur], (const real*)e->rho, scratch, ostride,
+                    (const real*)(e->vw_old ? e->Vw[1] : nullptr));
   if (!rc) {
     if (nm == "xi") rc = out_padded(scratch + 0 * ostride);
     else if (nm == "rho") rc = out_padded(scratch + 3 * ostride);
     else if (nm == "W") rc = out_padded(scratch + 6 * ostride);
     else if (nm == "eta" || nm == "U") {
-      float* a = scratch + (nm == "eta" ? 1 : 4) * ostride;
+      real* a = scratch + (nm == "eta" ? 1 : 4) * ostride;
       const long n = (long)g.Hp * g.Wp * e->cfg.channels;
-      rc = launch_k(e, -1, k_planar2_to_hwc2<256>, grid1d(n, 256, nimg), 256, 0, (const float*)a,
-                    (const float*)(a + ostride), dev_out, g.Hp, g.Wp, e->cfg.channels, g.rpitch, g.rplane);
+      rc = launch_k(e, -1, k_planar2_to_hwc2<256>, grid1d(n, 256, nimg), 256, 0, (const real*)a,
+                    (const real*)(a + ostride), dev_out, g.Hp, g.Wp, e->cfg.channels, g.rpitch, g.rplane);
     } else rc = fail("lpc_get_state: unknown name '" + nm + "'");
   }
   (void)rt::stream_sync(e->stream);
@@ -913,7 +924,7 @@ int lpc_profile_read(lpc_handle e, double* avg_ms, long* launches) {
   for (int k = 0; k < LPC_K_COUNT; ++k) {
     double tot = 0.0;
     for (size_t i = 0; i < e->timer.used[k]; ++i) {
-      float ms = 0.f;
+      float ms = 0.f;  // HIP API type, not the engine's arithmetic type
       LPC_RT(hipEventElapsedTime(&ms, e->timer.ev[k][i].first, e->timer.ev[k][i].second));
       tot += ms;
     }

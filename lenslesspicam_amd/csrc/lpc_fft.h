@@ -3,7 +3,7 @@
 // Design (MI355X-first, not a rocFFT/cuFFT translation):
 //  * one workgroup owns a tile of BT transforms of length n.  Between stages the tile lives in
 //    LDS as s[i*BT + b] (element i of transform b) -- for column passes b runs over adjacent
-//    image columns, so consecutive lanes touch consecutive float2 (ds_read/write_b64,
+//    image columns, so consecutive lanes touch consecutive real2 (ds_read/write_b64,
 //    conflict-free) and the global accesses that fill / drain the tile are 128-byte segments;
 //  * a tile is filled from a caller-supplied SOURCE functor (global loads, padding, residuals)
 //    with all of a thread's loads issued back-to-back into VGPRs before the first LDS write, and
@@ -30,25 +30,25 @@ struct Fft1dPlan {
   int ns[LPC_MAX_STAGES];      // product of the radices of the stages before s
   int twstep[LPC_MAX_STAGES];  // n / (ns*radix)
   FastDiv nsdiv[LPC_MAX_STAGES];
-  const float2* tw;            // device table, n entries: exp(-2 pi i q / n)
+  const real2* tw;            // device table, n entries: exp(-2 pi i q / n)
   int skew_ok;                 // row mode: the i + i/8 LDS skew stays affine in every stage
 };
 
 // multiply by -i (forward) / +i (inverse)
 template <bool INV>
-static __device__ __forceinline__ float2 rot90(float2 a) {
-  return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+static __device__ __forceinline__ real2 rot90(real2 a) {
+  return INV ? make_real2(-a.y, a.x) : make_real2(a.y, -a.x);
 }
 // multiply by exp(-+ 2 pi i q / 16) for the constants a radix-16 butterfly needs
 template <bool INV, int Q>
-static __device__ __forceinline__ float2 mul_w16(float2 a) {
-  constexpr float C8 = 0.70710678118654752440f;   // cos(pi/4)
-  constexpr float C1 = 0.92387953251128675613f;   // cos(pi/8)
-  constexpr float S1 = 0.38268343236508977173f;   // sin(pi/8)
-  constexpr float wr = Q == 1 ? C1 : Q == 2 ? C8 : Q == 3 ? S1 : Q == 6 ? -C8 : -C1;   // Q in {1,2,3,6,9}
-  constexpr float wf = Q == 1 ? -S1 : Q == 2 ? -C8 : Q == 3 ? -C1 : Q == 6 ? -C8 : S1;  // forward imag part
-  constexpr float wi = INV ? -wf : wf;
-  return make_float2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
+static __device__ __forceinline__ real2 mul_w16(real2 a) {
+  constexpr real C8 = (real)0.70710678118654752440;   // cos(pi/4)
+  constexpr real C1 = (real)0.92387953251128675613;   // cos(pi/8)
+  constexpr real S1 = (real)0.38268343236508977173;   // sin(pi/8)
+  constexpr real wr = Q == 1 ? C1 : Q == 2 ? C8 : Q == 3 ? S1 : Q == 6 ? -C8 : -C1;   // Q in {1,2,3,6,9}
+  constexpr real wf = Q == 1 ? -S1 : Q == 2 ? -C8 : Q == 3 ? -C1 : Q == 6 ? -C8 : S1;  // forward imag part
+  constexpr real wi = INV ? -wf : wf;
+  return make_real2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
 }
 
 template <int R, bool INV>
@@ -56,8 +56,8 @@ struct Dft;
 
 template <bool INV>
 struct Dft<2, INV> {
-  static __device__ __forceinline__ void run(float2* v) {
-    float2 a = v[0], b = v[1];
+  static __device__ __forceinline__ void run(real2* v) {
+    real2 a = v[0], b = v[1];
     v[0] = cadd(a, b);
     v[1] = csub(a, b);
   }
@@ -65,9 +65,9 @@ struct Dft<2, INV> {
 
 template <bool INV>
 struct Dft<4, INV> {
-  static __device__ __forceinline__ void run(float2* v) {
-    float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
-    float2 t2 = cadd(v[1], v[3]), t3 = rot90<INV>(csub(v[1], v[3]));
+  static __device__ __forceinline__ void run(real2* v) {
+    real2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+    real2 t2 = cadd(v[1], v[3]), t3 = rot90<INV>(csub(v[1], v[3]));
     v[0] = cadd(t0, t2);
     v[1] = cadd(t1, t3);
     v[2] = csub(t0, t2);
@@ -77,15 +77,15 @@ struct Dft<4, INV> {
 
 template <bool INV>
 struct Dft<3, INV> {
-  static __device__ __forceinline__ void run(float2* v) {
-    const float S = 0.86602540378443864676f;  // sin(2 pi / 3)
-    float2 t = cadd(v[1], v[2]);
-    float2 m = make_float2(v[0].x - 0.5f * t.x, v[0].y - 0.5f * t.y);
-    float2 d = cscale(csub(v[1], v[2]), S);
+  static __device__ __forceinline__ void run(real2* v) {
+    const real S = (real)0.86602540378443864676;  // sin(2 pi / 3)
+    real2 t = cadd(v[1], v[2]);
+    real2 m = make_real2(v[0].x - (real)0.5 * t.x, v[0].y - (real)0.5 * t.y);
+    real2 d = cscale(csub(v[1], v[2]), S);
     v[0] = cadd(v[0], t);
     // forward: X1 = m - i d, X2 = m + i d ; inverse swaps them
-    float2 p = make_float2(m.x + d.y, m.y - d.x);
-    float2 q = make_float2(m.x - d.y, m.y + d.x);
+    real2 p = make_real2(m.x + d.y, m.y - d.x);
+    real2 q = make_real2(m.x - d.y, m.y + d.x);
     v[1] = INV ? q : p;
     v[2] = INV ? p : q;
   }
@@ -93,24 +93,24 @@ struct Dft<3, INV> {
 
 template <bool INV>
 struct Dft<5, INV> {
-  static __device__ __forceinline__ void run(float2* v) {
-    const float C1 = 0.30901699437494742410f;   // cos(2 pi/5)
-    const float C2 = -0.80901699437494742410f;  // cos(4 pi/5)
-    const float S1 = 0.95105651629515357212f;   // sin(2 pi/5)
-    const float S2 = 0.58778525229247312917f;   // sin(4 pi/5)
-    float2 a0 = v[0];
-    float2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
-    float2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
-    float2 m1 = make_float2(a0.x + C1 * t1.x + C2 * t2.x, a0.y + C1 * t1.y + C2 * t2.y);
-    float2 m2 = make_float2(a0.x + C2 * t1.x + C1 * t2.x, a0.y + C2 * t1.y + C1 * t2.y);
-    float2 n1 = make_float2(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y);
-    float2 n2 = make_float2(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y);
-    v[0] = make_float2(a0.x + t1.x + t2.x, a0.y + t1.y + t2.y);
+  static __device__ __forceinline__ void run(real2* v) {
+    const real C1 = (real)0.30901699437494742410;   // cos(2 pi/5)
+    const real C2 = -(real)0.80901699437494742410;  // cos(4 pi/5)
+    const real S1 = (real)0.95105651629515357212;   // sin(2 pi/5)
+    const real S2 = (real)0.58778525229247312917;   // sin(4 pi/5)
+    real2 a0 = v[0];
+    real2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
+    real2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
+    real2 m1 = make_real2(a0.x + C1 * t1.x + C2 * t2.x, a0.y + C1 * t1.y + C2 * t2.y);
+    real2 m2 = make_real2(a0.x + C2 * t1.x + C1 * t2.x, a0.y + C2 * t1.y + C1 * t2.y);
+    real2 n1 = make_real2(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y);
+    real2 n2 = make_real2(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y);
+    v[0] = make_real2(a0.x + t1.x + t2.x, a0.y + t1.y + t2.y);
     // forward: X1 = m1 - i n1, X4 = m1 + i n1, X2 = m2 - i n2, X3 = m2 + i n2
-    float2 x1 = make_float2(m1.x + n1.y, m1.y - n1.x);
-    float2 x4 = make_float2(m1.x - n1.y, m1.y + n1.x);
-    float2 x2 = make_float2(m2.x + n2.y, m2.y - n2.x);
-    float2 x3 = make_float2(m2.x - n2.y, m2.y + n2.x);
+    real2 x1 = make_real2(m1.x + n1.y, m1.y - n1.x);
+    real2 x4 = make_real2(m1.x - n1.y, m1.y + n1.x);
+    real2 x2 = make_real2(m2.x + n2.y, m2.y - n2.x);
+    real2 x3 = make_real2(m2.x - n2.y, m2.y + n2.x);
     v[1] = INV ? x4 : x1;
     v[4] = INV ? x1 : x4;
     v[2] = INV ? x3 : x2;
@@ -120,16 +120,16 @@ struct Dft<5, INV> {
 
 template <bool INV>
 struct Dft<6, INV> {  // 6 = 2 x 3 (decimation in time over the even / odd inputs)
-  static __device__ __forceinline__ void run(float2* v) {
-    const float S = 0.86602540378443864676f;
-    float2 e[3] = {v[0], v[2], v[4]};
-    float2 o[3] = {v[1], v[3], v[5]};
+  static __device__ __forceinline__ void run(real2* v) {
+    const real S = (real)0.86602540378443864676;
+    real2 e[3] = {v[0], v[2], v[4]};
+    real2 o[3] = {v[1], v[3], v[5]};
     Dft<3, INV>::run(e);
     Dft<3, INV>::run(o);
     // w6^1 = (1/2, -+ S), w6^2 = (-1/2, -+ S)
-    const float si = INV ? S : -S;
-    float2 o1 = make_float2(0.5f * o[1].x - si * o[1].y, 0.5f * o[1].y + si * o[1].x);
-    float2 o2 = make_float2(-0.5f * o[2].x - si * o[2].y, -0.5f * o[2].y + si * o[2].x);
+    const real si = INV ? S : -S;
+    real2 o1 = make_real2((real)0.5 * o[1].x - si * o[1].y, (real)0.5 * o[1].y + si * o[1].x);
+    real2 o2 = make_real2(-(real)0.5 * o[2].x - si * o[2].y, -(real)0.5 * o[2].y + si * o[2].x);
     v[0] = cadd(e[0], o[0]); v[3] = csub(e[0], o[0]);
     v[1] = cadd(e[1], o1);   v[4] = csub(e[1], o1);
     v[2] = cadd(e[2], o2);   v[5] = csub(e[2], o2);
@@ -138,20 +138,20 @@ struct Dft<6, INV> {  // 6 = 2 x 3 (decimation in time over the even / odd input
 
 template <bool INV>
 struct Dft<8, INV> {
-  static __device__ __forceinline__ void run(float2* v) {
-    const float C = 0.70710678118654752440f;
-    float2 b0 = cadd(v[0], v[4]), b4 = csub(v[0], v[4]);
-    float2 b1 = cadd(v[1], v[5]), b5 = csub(v[1], v[5]);
-    float2 b2 = cadd(v[2], v[6]), b6 = csub(v[2], v[6]);
-    float2 b3 = cadd(v[3], v[7]), b7 = csub(v[3], v[7]);
+  static __device__ __forceinline__ void run(real2* v) {
+    const real C = (real)0.70710678118654752440;
+    real2 b0 = cadd(v[0], v[4]), b4 = csub(v[0], v[4]);
+    real2 b1 = cadd(v[1], v[5]), b5 = csub(v[1], v[5]);
+    real2 b2 = cadd(v[2], v[6]), b6 = csub(v[2], v[6]);
+    real2 b3 = cadd(v[3], v[7]), b7 = csub(v[3], v[7]);
     // b5 *= w8, b6 *= w8^2, b7 *= w8^3   (w8 = exp(-+ i pi/4))
-    b5 = INV ? make_float2(C * (b5.x - b5.y), C * (b5.x + b5.y))
-             : make_float2(C * (b5.x + b5.y), C * (b5.y - b5.x));
+    b5 = INV ? make_real2(C * (b5.x - b5.y), C * (b5.x + b5.y))
+             : make_real2(C * (b5.x + b5.y), C * (b5.y - b5.x));
     b6 = rot90<INV>(b6);
-    b7 = INV ? make_float2(-C * (b7.x + b7.y), C * (b7.x - b7.y))
-             : make_float2(C * (b7.y - b7.x), -C * (b7.x + b7.y));
-    float2 e[4] = {b0, b1, b2, b3};
-    float2 o[4] = {b4, b5, b6, b7};
+    b7 = INV ? make_real2(-C * (b7.x + b7.y), C * (b7.x - b7.y))
+             : make_real2(C * (b7.y - b7.x), -C * (b7.x + b7.y));
+    real2 e[4] = {b0, b1, b2, b3};
+    real2 o[4] = {b4, b5, b6, b7};
     Dft<4, INV>::run(e);
     Dft<4, INV>::run(o);
     v[0] = e[0]; v[1] = o[0]; v[2] = e[1]; v[3] = o[1];
@@ -161,11 +161,11 @@ struct Dft<8, INV> {
 
 template <bool INV>
 struct Dft<16, INV> {  // 16 = 4 x 4: X[k1 + 4 k2] = sum_n2 w16^(n2 k1) [sum_n1 x[4 n1 + n2] w4^(n1 k1)] w4^(n2 k2)
-  static __device__ __forceinline__ void run(float2* v) {
-    float2 y[4][4];
+  static __device__ __forceinline__ void run(real2* v) {
+    real2 y[4][4];
 #pragma unroll
     for (int n2 = 0; n2 < 4; ++n2) {
-      float2 t[4] = {v[n2], v[4 + n2], v[8 + n2], v[12 + n2]};
+      real2 t[4] = {v[n2], v[4 + n2], v[8 + n2], v[12 + n2]};
       Dft<4, INV>::run(t);
 #pragma unroll
       for (int k1 = 0; k1 < 4; ++k1) y[n2][k1] = t[k1];
@@ -176,7 +176,7 @@ struct Dft<16, INV> {  // 16 = 4 x 4: X[k1 + 4 k2] = sum_n2 w16^(n2 k1) [sum_n1 
     y[3][1] = mul_w16<INV, 3>(y[3][1]); y[3][2] = mul_w16<INV, 6>(y[3][2]); y[3][3] = mul_w16<INV, 9>(y[3][3]);
 #pragma unroll
     for (int k1 = 0; k1 < 4; ++k1) {
-      float2 t[4] = {y[0][k1], y[1][k1], y[2][k1], y[3][k1]};
+      real2 t[4] = {y[0][k1], y[1][k1], y[2][k1], y[3][k1]};
       Dft<4, INV>::run(t);
 #pragma unroll
       for (int k2 = 0; k2 < 4; ++k2) v[k1 + 4 * k2] = t[k2];
@@ -186,15 +186,15 @@ struct Dft<16, INV> {  // 16 = 4 x 4: X[k1 + 4 k2] = sum_n2 w16^(n2 k1) [sum_n1 
 
 // v[m] *= w^m (m = 1..R-1), w = exp(-+ 2 pi i q1 / n) = tw[q1] (conjugated for the inverse).
 template <int R, bool INV>
-static __device__ __forceinline__ void twiddle_mul(float2* v, const float2* LPC_RESTRICT tw, int q1) {
+static __device__ __forceinline__ void twiddle_mul(real2* v, const real2* LPC_RESTRICT tw, int q1) {
   if (R <= 6) {  // exact table entries for every power
 #pragma unroll
     for (int m = 1; m < R; ++m) {
-      float2 t = tw[q1 * m];
+      real2 t = tw[q1 * m];
       v[m] = INV ? cmul_conj(v[m], t) : cmul(v[m], t);
     }
   } else {
-    float2 w[16];
+    real2 w[16];
     w[1] = tw[q1]; w[2] = tw[2 * q1]; w[4] = tw[4 * q1];
     if (R == 16) w[8] = tw[8 * q1];
     w[3] = cmul(w[1], w[2]); w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]);
@@ -208,7 +208,7 @@ static __device__ __forceinline__ void twiddle_mul(float2* v, const float2* LPC_
 }
 
 // Row mode (one transform per workgroup, BT == 1) may store element i at LDS slot i + i/8: the
-// early Stockham stages write with a lane stride of R float2 (an 8- or 16-way conflict on the
+// early Stockham stages write with a lane stride of R real2 (an 8- or 16-way conflict on the
 // 32 x 4-byte banks of ds_write_b64).  Only used when it stays AFFINE inside every stage
 // (plan.skew_ok, checked on the host) so that a butterfly's R accesses are base + m*stride'.
 template <bool SKEW>
@@ -219,9 +219,9 @@ static __host__ __device__ __forceinline__ int lds_slots_skewed(int n) { return 
 
 // One Stockham stage over a tile of BT transforms held in LDS (in place).  Ends with a barrier.
 template <int R, int NT, int EMAX, bool INV, bool SKEW>
-static __device__ __forceinline__ void fft_stage(float2* s, int n, int BT, FastDiv btdiv, int ns,
+static __device__ __forceinline__ void fft_stage(real2* s, int n, int BT, FastDiv btdiv, int ns,
                                                   FastDiv nsdiv, int twstep,
-                                                  const float2* LPC_RESTRICT tw, int tid) {
+                                                  const real2* LPC_RESTRICT tw, int tid) {
   constexpr int MAXB = (EMAX + R - 1) / R;
   const int nb = n / R;
   const int nwork = nb * BT;
@@ -229,7 +229,7 @@ static __device__ __forceinline__ void fft_stage(float2* s, int n, int BT, FastD
   const int ostride = ns * BT;   // tile distance between its R outputs
   const int rs = SKEW ? istride + (istride >> 3) : istride;   // same, in (skewed) LDS slots
   const int ws = SKEW ? ostride + (ostride >> 3) : ostride;
-  float2 v[MAXB][R];
+  real2 v[MAXB][R];
   int obase[MAXB];
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
@@ -268,7 +268,7 @@ static __device__ __forceinline__ void fft_stage(float2* s, int n, int BT, FastD
 // element (i, c) at slot(i*BT + c)).  Precondition: tile written and a barrier passed.
 // Postcondition: result in natural order, barrier passed.  Unnormalised in both directions.
 template <int NT, int EMAX, bool INV, bool SKEW = false>
-static __device__ __forceinline__ void lds_fft(float2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
+static __device__ __forceinline__ void lds_fft(real2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
                                                 int tid, int first_stage = 0, int skip_last = 0) {
   for (int st = first_stage; st < p.nst - skip_last; ++st) {
     const int ns = p.ns[st];
@@ -294,7 +294,7 @@ static __device__ __forceinline__ void lds_fft(float2* s, const Fft1dPlan& p, in
 struct LdsNatural {};
 
 // Tile transform with pluggable source and sink:
-//   src(i, c) -> float2   element i of transform c (global loads, padding, residuals, ...)
+//   src(i, c) -> real2   element i of transform c (global loads, padding, residuals, ...)
 //   dst(i, c, v)          receives output element i of transform c (natural order)
 // All of a thread's src() calls are issued before the first LDS write (loops unrolled to the
 // compile-time bound EMAX): with a run-time trip count the compiler emits load / wait / ds_write
@@ -305,12 +305,12 @@ struct LdsNatural {};
 // in the staging registers and writes the stage OUTPUT to LDS -- one LDS round trip and two barriers
 // less per transform.  Register need = the EMAX staging registers the plain fill uses anyway.
 template <int R, int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, class Src, class Fix>
-static __device__ __forceinline__ void fft_first_stage_fused(float2* s, int n, int BT, FastDiv btdiv, int tid,
+static __device__ __forceinline__ void fft_first_stage_fused(real2* s, int n, int BT, FastDiv btdiv, int tid,
                                                               Src& src, Fix& fix) {
   constexpr int MAXB = (EMAX + R - 1) / R;
   const int nb = n / R;
   const int nwork = nb * BT;
-  float2 v[MAXB][R];
+  real2 v[MAXB][R];
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
     const int w = tid + b * NT;
@@ -348,15 +348,15 @@ static __device__ __forceinline__ void fft_first_stage_fused(float2* s, int n, i
 // (coalesced: consecutive lanes hold consecutive output elements) -- again one LDS round trip and two
 // barriers less.  The tile must have passed a barrier after the previous stage's writes.
 template <int R, int NT, int EMAX, bool INV, bool SKEW, class Dst>
-static __device__ __forceinline__ void fft_last_stage_fused(float2* s, int n, int BT, FastDiv btdiv, int ns,
+static __device__ __forceinline__ void fft_last_stage_fused(real2* s, int n, int BT, FastDiv btdiv, int ns,
                                                              FastDiv nsdiv, int twstep,
-                                                             const float2* LPC_RESTRICT tw, int tid, Dst& dst) {
+                                                             const real2* LPC_RESTRICT tw, int tid, Dst& dst) {
   constexpr int MAXB = (EMAX + R - 1) / R;
   const int nb = n / R;
   const int nwork = nb * BT;
   const int istride = nb * BT;
   const int rs = SKEW ? istride + (istride >> 3) : istride;
-  float2 v[MAXB][R];
+  real2 v[MAXB][R];
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
     const int w = tid + b * NT;
@@ -384,7 +384,7 @@ static __device__ __forceinline__ void fft_last_stage_fused(float2* s, int n, in
 }
 
 struct NoFix {
-  __device__ __forceinline__ float2 operator()(int, int, float2 v) const { return v; }
+  __device__ __forceinline__ real2 operator()(int, int, real2 v) const { return v; }
 };
 
 // fix(i, c, v): optional per-element transform applied AFTER the batched loads have landed (e.g. the
@@ -395,7 +395,7 @@ struct NoFix {
 // FUSEL: fuse the last stage into the drain (fft_last_stage_fused); same per-call-site rule.
 template <int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, bool FUSE1 = false, bool FUSEL = false, class Src,
           class Dst, class Fix = NoFix>
-static __device__ __forceinline__ void fft_tile(float2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
+static __device__ __forceinline__ void fft_tile(real2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
                                                  int tid, Src src, Dst dst, Fix fix = Fix()) {
   const int nelem = p.n * BT;
   int first_stage = 0;
@@ -416,7 +416,7 @@ static __device__ __forceinline__ void fft_tile(float2* s, const Fft1dPlan& p, i
   }
   if (first_stage == 0)
   if constexpr (!std::is_same<Src, LdsNatural>::value) {
-    float2 v[EMAX];
+    real2 v[EMAX];
 #pragma unroll
     for (int k = 0; k < EMAX; ++k) {
       const int e = tid + k * NT;

@@ -16,11 +16,11 @@
 // ---- inverse rows -> residual -> forward rows, all inside the workgroup -------------------------
 template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan,
-                                                     const float2* LPC_RESTRICT Sin,
-                                                     float2* LPC_RESTRICT Sout,
-                                                     const float* LPC_RESTRICT Y) {
+                                                     const real2* LPC_RESTRICT Sin,
+                                                     real2* LPC_RESTRICT Sout,
+                                                     const real* LPC_RESTRICT Y) {
   LPC_DYN_SMEM(smem);
-  float2* s = (float2*)smem;
+  real2* s = (real2*)smem;
   const int tid = threadIdx.x;
   const int u0 = 2 * blockIdx.x, u1 = u0 + 1;
   const long pl = blockIdx.y;
@@ -28,51 +28,51 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan,
   const int hh = g.Hp / 2, hw = g.Wp / 2;
   const int sr0 = wrap_add(g.sh + u0, hh, g.Hp);
   const int sr1 = wrap_add(g.sh + (v1 ? u1 : u0), hh, g.Hp);
-  const float2* sp = Sin + pl * g.cplane;
+  const real2* sp = Sin + pl * g.cplane;
   tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
   __syncthreads();
   fft_tile<NT, EMAX, true, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
   // residual, re-padded: sample i of the new row = (i in window) ? conv[(i + Wp/2) mod Wp] - y[i - sw] : 0,
   // evaluated on the fly as the source of the forward transform's first stage
   const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
-  const float* y0 = Y + (long)dpl * g.uplane + (long)u0 * g.W;
-  const float* y1 = y0 + g.W;
+  const real* y0 = Y + (long)dpl * g.uplane + (long)u0 * g.W;
+  const real* y1 = y0 + g.W;
   auto resid = [&](int i, int) {
     const int c = i - g.sw;
-    if (c < 0 || c >= g.W) return make_float2(0.f, 0.f);
-    const float2 z = s[lds_slot<SK>(wrap_add(i, hw, g.Wp))];
-    return make_float2(z.x - y0[c], v1 ? z.y - y1[c] : 0.f);
+    if (c < 0 || c >= g.W) return make_real2((real)0., (real)0.);
+    const real2 z = s[lds_slot<SK>(wrap_add(i, hw, g.Wp))];
+    return make_real2(z.x - y0[c], v1 ? z.y - y1[c] : (real)0.);
   };
   fft_tile<NT, EMAX, false, SK, true, true>(s, plan, 1, make_fastdiv_dev1(), tid, resid, LdsNatural{});
-  float2* o = Sout + pl * g.cplane + (long)(g.sh + u0) * g.cpitch;
+  real2* o = Sout + pl * g.cplane + (long)(g.sh + u0) * g.cpitch;
   untangle_store<NT, SK>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
 }
 
 // ---- inverse rows -> gradient -> fused update --------------------------------------------
 struct GdScalars {
   int kind;        // 0 vanilla, 1 nesterov, 2 fista
-  float mu;        // nesterov: float32(mu)
-  float negmu;     // nesterov: float32(-mu)
-  float onepmu;    // nesterov: float32(1 + mu)
-  float coef;      // fista: float32((t_k - 1) / t_{k+1})
+  real mu;        // nesterov: float32(mu)
+  real negmu;     // nesterov: float32(-mu)
+  real onepmu;    // nesterov: float32(1 + mu)
+  real coef;      // fista: float32((t_k - 1) / t_{k+1})
   int first;       // fista: x_k aliases the iterate during the first update (gd.py:233,236)
 };
 
-static __device__ __forceinline__ void gd_update_one(float* LPC_RESTRICT X, float* LPC_RESTRICT AUX, long o,
-                                                      float gr, float al, const GdScalars& p) {
-  const float x = X[o];
+static __device__ __forceinline__ void gd_update_one(real* LPC_RESTRICT X, real* LPC_RESTRICT AUX, long o,
+                                                      real gr, real al, const GdScalars& p) {
+  const real x = X[o];
   if (p.kind == 0) {                       // gd.py:132-134
-    X[o] = fmaxf(x - al * gr, 0.f);
+    X[o] = rmax(x - al * gr, (real)0.);
   } else if (p.kind == 1) {                // gd.py:183-188
-    const float pp = AUX[o];
-    const float pn = p.mu * pp - al * gr;
-    const float xn = x + (p.negmu * pp + p.onepmu * pn);
+    const real pp = AUX[o];
+    const real pn = p.mu * pp - al * gr;
+    const real xn = x + (p.negmu * pp + p.onepmu * pn);
     AUX[o] = pn;
-    X[o] = fmaxf(xn, 0.f);
+    X[o] = rmax(xn, (real)0.);
   } else {                                 // gd.py:235-241
-    const float x1 = x - al * gr;
-    const float xk = fmaxf(x1, 0.f);
-    const float xp = p.first ? x1 : AUX[o];
+    const real x1 = x - al * gr;
+    const real xk = rmax(x1, (real)0.);
+    const real xp = p.first ? x1 : AUX[o];
     X[o] = xk + p.coef * (xk - xp);
     AUX[o] = xk;
   }
@@ -80,11 +80,11 @@ static __device__ __forceinline__ void gd_update_one(float* LPC_RESTRICT X, floa
 
 template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan plan,
-                                                        const float2* LPC_RESTRICT Sin,
-                                                        float* LPC_RESTRICT X, float* LPC_RESTRICT AUX,
-                                                        const float* LPC_RESTRICT alpha, GdScalars p) {
+                                                        const real2* LPC_RESTRICT Sin,
+                                                        real* LPC_RESTRICT X, real* LPC_RESTRICT AUX,
+                                                        const real* LPC_RESTRICT alpha, GdScalars p) {
   LPC_DYN_SMEM(smem);
-  float2* s = (float2*)smem;
+  real2* s = (real2*)smem;
   const int tid = threadIdx.x;
   const int u0 = 2 * blockIdx.x, u1 = u0 + 1;
   const long pl = blockIdx.y;
@@ -92,13 +92,13 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan pl
   const int hh = g.Hp / 2, hw = g.Wp / 2;
   const int sr0 = wrap_add(g.sh + u0, hh, g.Hp);
   const int sr1 = wrap_add(g.sh + (v1 ? u1 : u0), hh, g.Hp);
-  const float2* sp = Sin + pl * g.cplane;
+  const real2* sp = Sin + pl * g.cplane;
   tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
   __syncthreads();
-  const float al = alpha[pl % g.C];
+  const real al = alpha[pl % g.C];
   const long base = pl * g.uplane + (long)u0 * g.W;
   // the drain of the inverse transform hands each gradient sample straight to the fused update (shift + crop)
-  auto upd = [&](int i, int, float2 z) {
+  auto upd = [&](int i, int, real2 z) {
     const int c = shifted_col(i, hw, g.sw, g.Wp);
     if (c < g.W) {
       gd_update_one(X, AUX, base + c, z.x, al, p);
@@ -110,51 +110,51 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan pl
 
 // ---- reductions (set-up only): per-plane max/min with wavefront shuffles ---------------------
 template <int NT>
-static __device__ __forceinline__ void block_minmax(float& mx, float& mn, float* scratch, int tid) {
+static __device__ __forceinline__ void block_minmax(real& mx, real& mn, real* scratch, int tid) {
 #if !defined(LPC_SIMT_EMU)
   for (int off = 32; off > 0; off >>= 1) {  // 64-lane wavefront
-    mx = fmaxf(mx, __shfl_down(mx, off, 64));
-    mn = fminf(mn, __shfl_down(mn, off, 64));
+    mx = rmax(mx, __shfl_down(mx, off, 64));
+    mn = rmin(mn, __shfl_down(mn, off, 64));
   }
   const int wave = tid >> 6, lane = tid & 63;
   if (lane == 0) { scratch[2 * wave] = mx; scratch[2 * wave + 1] = mn; }
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < NT / 64; ++w) { mx = fmaxf(mx, scratch[2 * w]); mn = fminf(mn, scratch[2 * w + 1]); }
+    for (int w = 1; w < NT / 64; ++w) { mx = rmax(mx, scratch[2 * w]); mn = rmin(mn, scratch[2 * w + 1]); }
   }
 #else
   scratch[2 * tid] = mx; scratch[2 * tid + 1] = mn;
   __syncthreads();
   if (tid == 0) {
-    for (int w = 1; w < NT; ++w) { mx = fmaxf(mx, scratch[2 * w]); mn = fminf(mn, scratch[2 * w + 1]); }
+    for (int w = 1; w < NT; ++w) { mx = rmax(mx, scratch[2 * w]); mn = rmin(mn, scratch[2 * w + 1]); }
   }
 #endif
 }
 
 // mode 0: values are |H* H| of a spectrum plane (pitch cpitch, Wc valid columns);
-// mode 1: values are a real un-padded plane.  Writes (max, min) per (plane, block).
+// mode 1: values are an un-padded image plane.  Writes (max, min) per (plane, block).
 template <int NT>
-__global__ __launch_bounds__(NT) void k_plane_minmax(PlaneGeom g, const float2* LPC_RESTRICT Hs,
-                                                      const float* LPC_RESTRICT real, int mode,
-                                                      float* LPC_RESTRICT partial) {
+__global__ __launch_bounds__(NT) void k_plane_minmax(PlaneGeom g, const real2* LPC_RESTRICT Hs,
+                                                      const real* LPC_RESTRICT plane, int mode,
+                                                      real* LPC_RESTRICT partial) {
   LPC_DYN_SMEM(smem);
-  float* scratch = (float*)smem;
+  real* scratch = (real*)smem;
   const int tid = threadIdx.x;
   const long pl = blockIdx.y;
-  float mx = -INFINITY, mn = INFINITY;
+  real mx = -INFINITY, mn = INFINITY;
   if (mode == 0) {
     const long n = (long)g.Hp * g.Wc;
     for (long e = (long)blockIdx.x * NT + tid; e < n; e += (long)gridDim.x * NT) {
       const int r = (int)(e / g.Wc), c = (int)(e - (long)r * g.Wc);
-      const float2 h = Hs[pl * g.cplane + (long)r * g.cpitch + c];
-      const float a = h.x * h.x + h.y * h.y;
-      mx = fmaxf(mx, a); mn = fminf(mn, a);
+      const real2 h = Hs[pl * g.cplane + (long)r * g.cpitch + c];
+      const real a = h.x * h.x + h.y * h.y;
+      mx = rmax(mx, a); mn = rmin(mn, a);
     }
   } else {
     const long n = g.uplane;
     for (long e = (long)blockIdx.x * NT + tid; e < n; e += (long)gridDim.x * NT) {
-      const float a = real[pl * g.uplane + e];
-      mx = fmaxf(mx, a); mn = fminf(mn, a);
+      const real a = plane[pl * g.uplane + e];
+      mx = rmax(mx, a); mn = rmin(mn, a);
     }
   }
   block_minmax<NT>(mx, mn, scratch, tid);
@@ -166,34 +166,34 @@ __global__ __launch_bounds__(NT) void k_plane_minmax(PlaneGeom g, const float2* 
 
 // final per-channel combine over depth planes and blocks (gd.py:100-112 flatten (D,H,W) per channel):
 // mode 0: out[c] = lip_fact / max;  mode 1: out[c] = (max + min) / 2
-__global__ void k_channel_finish(const float* LPC_RESTRICT partial, int nblk, int D, int C, int mode, float lip,
-                                 float* LPC_RESTRICT out) {
+__global__ void k_channel_finish(const real* LPC_RESTRICT partial, int nblk, int D, int C, int mode, real lip,
+                                 real* LPC_RESTRICT out) {
   const int c = threadIdx.x;
   if (c >= C) return;
-  float mx = -INFINITY, mn = INFINITY;
+  real mx = -INFINITY, mn = INFINITY;
   for (int d = 0; d < D; ++d)
     for (int b = 0; b < nblk; ++b) {
       const long i = 2 * ((long)(d * C + c) * nblk + b);
-      mx = fmaxf(mx, partial[i]);
-      mn = fminf(mn, partial[i + 1]);
+      mx = rmax(mx, partial[i]);
+      mn = rmin(mn, partial[i + 1]);
     }
   out[c] = mode == 0 ? lip / mx : (mx + mn) / 2;
 }
 
 // x[plane][...] = val[plane % C]
 template <int NT>
-__global__ __launch_bounds__(NT) void k_fill_per_channel(float* LPC_RESTRICT x, long plane_elems, int C,
-                                                          const float* LPC_RESTRICT val) {
+__global__ __launch_bounds__(NT) void k_fill_per_channel(real* LPC_RESTRICT x, long plane_elems, int C,
+                                                          const real* LPC_RESTRICT val) {
   const long pl = blockIdx.y;
-  const float v = val[pl % C];
+  const real v = val[pl % C];
   for (long e = (long)blockIdx.x * NT + threadIdx.x; e < plane_elems; e += (long)gridDim.x * NT)
     x[pl * plane_elems + e] = v;
 }
 
 // two planar arrays (component 0 / 1) -> channels-last with a trailing axis of 2
 template <int NT>
-__global__ __launch_bounds__(NT) void k_planar2_to_hwc2(const float* LPC_RESTRICT a0, const float* LPC_RESTRICT a1,
-                                                         float* LPC_RESTRICT dst, int rows, int cols, int C,
+__global__ __launch_bounds__(NT) void k_planar2_to_hwc2(const real* LPC_RESTRICT a0, const real* LPC_RESTRICT a1,
+                                                         real* LPC_RESTRICT dst, int rows, int cols, int C,
                                                          int pitch, long splane) {
   const long n = (long)rows * cols * C;
   const long img = blockIdx.y;

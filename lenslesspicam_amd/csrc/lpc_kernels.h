@@ -4,7 +4,7 @@
 //   * images are PLANAR: plane q = (b*D + d)*C + c, rows contiguous.  The reference keeps
 //     channels innermost (stride-3 FFTs); planar turns B, D and C into one batch index.
 //   * padded real plane:   [Hp][rpitch]  (rpitch >= Wp)
-//   * half spectrum plane: [Hp][cpitch]  float2 (cpitch >= Wc = Wp/2+1, 16-element padded so
+//   * half spectrum plane: [Hp][cpitch]  real2 (cpitch >= Wc = Wp/2+1, 16-element padded so
 //     every tile row is a whole number of 128-byte lines)
 //   * un-padded plane:     [H][W]
 // Column (H-axis) transforms longer than LDS allows are split four-step style,
@@ -21,9 +21,9 @@ struct PlaneGeom {
   int Hp, Wp, Wc;  // padded rows / cols, half-spectrum cols
   int sh, sw;      // origin of the sensor window inside the padded frame
   int rpitch;      // floats per padded real row
-  int cpitch;      // float2 per spectrum row
+  int cpitch;      // real2 per spectrum row
   long rplane;     // floats per padded real plane
-  long cplane;     // float2 per spectrum plane
+  long cplane;     // real2 per spectrum plane
   long uplane;     // floats per un-padded plane
   int DC;          // D*C: number of PSF planes (state plane q uses PSF plane q % DC)
   int C;           // channels (data plane of state plane q = (q / DC) * C + q % C)
@@ -42,17 +42,17 @@ static __device__ __forceinline__ int wrap_add(int i, int d, int n) {  // (i + d
 // The first FFT stage pulls its inputs straight from global memory (source lambda) and the last
 // stage pushes its outputs straight out (sink lambda); LDS only carries the tile between stages
 // and the Hermitian (un)tangling, which pairs bins k and Wp-k held by different lanes.
-#define LPC_ROW_SMEM_BYTES(Wp, skew) ((size_t)((skew) ? lds_slots_skewed(Wp) : (Wp)) * sizeof(float2))
+#define LPC_ROW_SMEM_BYTES(Wp, skew) ((size_t)((skew) ? lds_slots_skewed(Wp) : (Wp)) * sizeof(real2))
 
 // s[] holds Z = FFT(a + i b) in natural order; writes A[k], B[k] for k in [0, Wc)
 template <int NT, bool SK>
-static __device__ __forceinline__ void untangle_store(const float2* s, int Wp, int Wc, float2* outA,
-                                                       float2* outB, bool validB, int tid) {
+static __device__ __forceinline__ void untangle_store(const real2* s, int Wp, int Wc, real2* outA,
+                                                       real2* outB, bool validB, int tid) {
   for (int k = tid; k < Wc; k += NT) {
-    float2 zk = s[lds_slot<SK>(k)];
-    float2 zn = s[lds_slot<SK>(k == 0 ? 0 : Wp - k)];
-    outA[k] = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y - zn.y));
-    if (validB) outB[k] = make_float2(0.5f * (zk.y + zn.y), -0.5f * (zk.x - zn.x));
+    real2 zk = s[lds_slot<SK>(k)];
+    real2 zn = s[lds_slot<SK>(k == 0 ? 0 : Wp - k)];
+    outA[k] = make_real2((real)0.5 * (zk.x + zn.x), (real)0.5 * (zk.y - zn.y));
+    if (validB) outB[k] = make_real2((real)0.5 * (zk.y + zn.y), -(real)0.5 * (zk.x - zn.x));
   }
 }
 
@@ -60,15 +60,15 @@ static __device__ __forceinline__ void untangle_store(const float2* s, int Wp, i
 // imaginary parts of the DC and Nyquist bins are ignored).  All loads are issued before the
 // first LDS write (unrolled to the compile-time bound) so they overlap in flight.
 template <int NT, int EMAX, bool SK>
-static __device__ __forceinline__ void tangle_load(float2* s, int Wp, int Wc, const float2* inA,
-                                                    const float2* inB, bool validB, int tid) {
+static __device__ __forceinline__ void tangle_load(real2* s, int Wp, int Wc, const real2* inA,
+                                                    const real2* inB, bool validB, int tid) {
   constexpr int EH = EMAX / 2 + 1;
-  float2 a[EH], b[EH];
+  real2 a[EH], b[EH];
 #pragma unroll
   for (int q = 0; q < EH; ++q) {
     const int k = tid + q * NT;
-    a[q] = make_float2(0.f, 0.f);
-    b[q] = make_float2(0.f, 0.f);
+    a[q] = make_real2((real)0., (real)0.);
+    b[q] = make_real2((real)0., (real)0.);
     if (k < Wc) {
       a[q] = inA[k];
       if (validB) b[q] = inB[k];
@@ -78,11 +78,11 @@ static __device__ __forceinline__ void tangle_load(float2* s, int Wp, int Wc, co
   for (int q = 0; q < EH; ++q) {
     const int k = tid + q * NT;
     if (k < Wc) {
-      float2 av = a[q], bv = b[q];
+      real2 av = a[q], bv = b[q];
       const bool selfconj = (k == 0) || (2 * k == Wp);
-      if (selfconj) { av.y = 0.f; bv.y = 0.f; }
-      s[lds_slot<SK>(k)] = make_float2(av.x - bv.y, av.y + bv.x);
-      if (!selfconj) s[lds_slot<SK>(Wp - k)] = make_float2(av.x + bv.y, bv.x - av.y);
+      if (selfconj) { av.y = (real)0.; bv.y = (real)0.; }
+      s[lds_slot<SK>(k)] = make_real2(av.x - bv.y, av.y + bv.x);
+      if (!selfconj) s[lds_slot<SK>(Wp - k)] = make_real2(av.x + bv.y, bv.x - av.y);
     }
   }
 }
@@ -90,17 +90,17 @@ static __device__ __forceinline__ void tangle_load(float2* s, int Wp, int Wc, co
 // ---- forward, ADMM: row r of array A and row r of array B -> spectra SA, SB ------------
 template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
-                                                     const float* LPC_RESTRICT A,
-                                                     const float* LPC_RESTRICT B,
-                                                     float2* LPC_RESTRICT SA,
-                                                     float2* LPC_RESTRICT SB) {
+                                                     const real* LPC_RESTRICT A,
+                                                     const real* LPC_RESTRICT B,
+                                                     real2* LPC_RESTRICT SA,
+                                                     real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
-  float2* s = (float2*)smem;
+  real2* s = (real2*)smem;
   const int tid = threadIdx.x, row = blockIdx.x;
   const long pl = blockIdx.y;
-  const float* a = A + pl * g.rplane + (long)row * g.rpitch;
-  const float* b = B + pl * g.rplane + (long)row * g.rpitch;
-  auto src = [&](int i, int) { return make_float2(a[i], b[i]); };
+  const real* a = A + pl * g.rplane + (long)row * g.rpitch;
+  const real* b = B + pl * g.rplane + (long)row * g.rpitch;
+  auto src = [&](int i, int) { return make_real2(a[i], b[i]); };
   fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
   untangle_store<NT, SK>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
                          SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
 
 // ---- forward, generic: rows (2b, 2b+1) of ONE real source -> spectrum rows ------------
 struct RealSrc {
-  const float* base;
+  const real* base;
   long plane_stride;  // floats
   int pitch;          // floats per row
   int nrows;          // rows >= nrows are implicit zeros
@@ -118,41 +118,41 @@ struct RealSrc {
 
 template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, RealSrc src,
-                                                   float2* LPC_RESTRICT S) {
+                                                   real2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
-  float2* s = (float2*)smem;
+  real2* s = (real2*)smem;
   const int tid = threadIdx.x;
   const int r0 = 2 * blockIdx.x, r1 = r0 + 1;
   const long pl = blockIdx.y;
   const bool v1 = r1 < src.nrows;
-  const float* a = src.base + pl * src.plane_stride + (long)r0 * src.pitch;
-  const float* b = src.base + pl * src.plane_stride + (long)r1 * src.pitch;
+  const real* a = src.base + pl * src.plane_stride + (long)r0 * src.pitch;
+  const real* b = src.base + pl * src.plane_stride + (long)r1 * src.pitch;
   auto in = [&](int i, int) {   // pad on load
     const int c = i - src.col0;
     const bool ok = (c >= 0) && (c < src.ncols);
-    return make_float2(ok ? a[c] : 0.f, (ok && v1) ? b[c] : 0.f);
+    return make_real2(ok ? a[c] : (real)0., (ok && v1) ? b[c] : (real)0.);
   };
   fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, in, LdsNatural{});
-  float2* o = S + pl * g.cplane + (long)(src.out_row0 + r0) * g.cpitch;
+  real2* o = S + pl * g.cplane + (long)(src.out_row0 + r0) * g.cpitch;
   untangle_store<NT, SK>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
 }
 
 // ---- inverse, ADMM: spectra SA, SB -> real arrays A, B (no shift, padded) ---------------
 template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, Fft1dPlan plan,
-                                                     const float2* LPC_RESTRICT SA,
-                                                     const float2* LPC_RESTRICT SB,
-                                                     float* LPC_RESTRICT A, float* LPC_RESTRICT B) {
+                                                     const real2* LPC_RESTRICT SA,
+                                                     const real2* LPC_RESTRICT SB,
+                                                     real* LPC_RESTRICT A, real* LPC_RESTRICT B) {
   LPC_DYN_SMEM(smem);
-  float2* s = (float2*)smem;
+  real2* s = (real2*)smem;
   const int tid = threadIdx.x, row = blockIdx.x;
   const long pl = blockIdx.y;
   tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
                             SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
   __syncthreads();
-  float* a = A + pl * g.rplane + (long)row * g.rpitch;
-  float* b = B + pl * g.rplane + (long)row * g.rpitch;
-  auto out = [&](int i, int, float2 v) { a[i] = v.x; b[i] = v.y; };
+  real* a = A + pl * g.rplane + (long)row * g.rpitch;
+  real* b = B + pl * g.rplane + (long)row * g.rpitch;
+  auto out = [&](int i, int, real2 v) { a[i] = v.x; b[i] = v.y; };
   fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
 }
 
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, Fft1dPlan plan,
 // column c from FFT sample (c + Wp/2) mod Wp (fft.ifftshift is a roll by -(n//2)).  That is pure
 // index arithmetic in the sink of the last FFT stage: exact, and no extra pass over HBM.
 struct RealDst {
-  float* base;
+  real* base;
   long plane_stride;
   int pitch;
   int nrows;       // number of output rows (Hp if not cropping, H if cropping)
@@ -179,9 +179,9 @@ static __device__ __forceinline__ int shifted_col(int i, int hw, int col0, int W
 
 template <int NT, int EMAX, bool SK>
 __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
-                                                   const float2* LPC_RESTRICT S, RealDst dst) {
+                                                   const real2* LPC_RESTRICT S, RealDst dst) {
   LPC_DYN_SMEM(smem);
-  float2* s = (float2*)smem;
+  real2* s = (real2*)smem;
   const int tid = threadIdx.x;
   const int r0 = 2 * blockIdx.x, r1 = r0 + 1;
   const long pl = blockIdx.y;
@@ -192,9 +192,9 @@ __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
   tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, S + pl * g.cplane + (long)sr0 * g.cpitch,
                             S + pl * g.cplane + (long)sr1 * g.cpitch, v1, tid);
   __syncthreads();
-  float* a = dst.base + pl * dst.plane_stride + (long)r0 * dst.pitch;
-  float* b = dst.base + pl * dst.plane_stride + (long)r1 * dst.pitch;
-  auto out = [&](int i, int, float2 v) {
+  real* a = dst.base + pl * dst.plane_stride + (long)r0 * dst.pitch;
+  real* b = dst.base + pl * dst.plane_stride + (long)r1 * dst.pitch;
+  auto out = [&](int i, int, real2 v) {
     const int c = shifted_col(i, hw, dst.col0, g.Wp);
     if (c < dst.ncols) {
       a[c] = v.x;
@@ -221,7 +221,7 @@ struct ColPass {
   int tw_mode;      // 0: none; 1: multiply result k by twH[g*k] (forward pass A);
                     // 2: multiply input k by conj(twH[g*k]) (inverse pass A)
   int zr0, zr1;     // forward only: rows outside [zr0,zr1) are implicit zeros on load
-  const float2* twH;  // exp(-2 pi i q / Hp), q in [0, Hp)
+  const real2* twH;  // exp(-2 pi i q / Hp), q in [0, Hp)
   FastDiv tdiv;     // fast divide by T
   FastDiv tcdiv;    // fast divide by ntile_c
 };
@@ -229,25 +229,25 @@ struct ColPass {
 // plain pass over ONE spectrum array, in place (global -> registers -> [LDS] -> registers -> global)
 template <int NT, int EMAX, bool INV>
 __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, Fft1dPlan plan, ColPass cp,
-                                              float2* LPC_RESTRICT S) {
+                                              real2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
-  float2* s = (float2*)smem;
+  real2* s = (real2*)smem;
   const int tid = threadIdx.x;
   const int grp = (int)fd_div(blockIdx.x, cp.tcdiv);
   const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * cp.T;
-  float2* base = S + (long)blockIdx.y * g.cplane + (long)grp * cp.gstride * g.cpitch + c0;
+  real2* base = S + (long)blockIdx.y * g.cplane + (long)grp * cp.gstride * g.cpitch + c0;
   const long rstep = (long)cp.istride * g.cpitch;
   const int row0 = grp * cp.gstride;
   auto in = [&](int i, int c) {
-    float2 x = make_float2(0.f, 0.f);
+    real2 x = make_real2((real)0., (real)0.);
     const int row = row0 + i * cp.istride;
     if (c0 + c < g.Wc && (INV || (row >= cp.zr0 && row < cp.zr1))) x = base[i * rstep + c];
     return x;
   };
-  auto untwiddle = [&](int i, int, float2 x) {   // inverse pass A: conj four-step twiddle on the way in
+  auto untwiddle = [&](int i, int, real2 x) {   // inverse pass A: conj four-step twiddle on the way in
     return (INV && cp.tw_mode == 2) ? cmul_conj(x, cp.twH[grp * i]) : x;
   };
-  auto out = [&](int i, int c, float2 x) {
+  auto out = [&](int i, int c, real2 x) {
     if (c0 + c < g.Wc) {
       if (!INV && cp.tw_mode == 1) x = cmul(x, cp.twH[grp * i]);
       base[i * rstep + c] = x;
@@ -261,26 +261,26 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, Fft1dPlan plan, ColPas
 // conjugate) -> inverse pass B, one trip through HBM.  hscale folds 1/(Hp*Wp).
 template <int NT, int EMAX>
 __global__ __launch_bounds__(NT) void k_cols_mid_mul(PlaneGeom g, Fft1dPlan plan, ColPass cp,
-                                                      float2* LPC_RESTRICT S,
-                                                      const float2* LPC_RESTRICT Hs, int conjH,
-                                                      float hscale, int psf_planes) {
+                                                      real2* LPC_RESTRICT S,
+                                                      const real2* LPC_RESTRICT Hs, int conjH,
+                                                      real hscale, int psf_planes) {
   LPC_DYN_SMEM(smem);
-  float2* s = (float2*)smem;
+  real2* s = (real2*)smem;
   const int tid = threadIdx.x;
   const int T = cp.T;
   const int grp = (int)fd_div(blockIdx.x, cp.tcdiv);
   const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * T;
   const long rowoff = ((long)grp * cp.gstride) * g.cpitch + c0;
-  float2* base = S + (long)blockIdx.y * g.cplane + rowoff;
-  const float2* hb = Hs + (long)((int)blockIdx.y % psf_planes) * g.cplane + rowoff;
+  real2* base = S + (long)blockIdx.y * g.cplane + rowoff;
+  const real2* hb = Hs + (long)((int)blockIdx.y % psf_planes) * g.cplane + rowoff;
   const int nelem = cp.N * T;
   const long rstep = (long)cp.istride * g.cpitch;
   const int row0 = grp * cp.gstride;
-  float2 h[EMAX];
+  real2 h[EMAX];
 #pragma unroll
   for (int k = 0; k < EMAX; ++k) {   // PSF spectrum tile: in flight during the forward transform
     const int e = tid + k * NT;
-    h[k] = make_float2(0.f, 0.f);
+    h[k] = make_real2((real)0., (real)0.);
     if (e < nelem) {
       const int i = (int)fd_div((unsigned)e, cp.tdiv);
       const int j = e - i * T;
@@ -289,20 +289,20 @@ __global__ __launch_bounds__(NT) void k_cols_mid_mul(PlaneGeom g, Fft1dPlan plan
   }
   auto in = [&](int i, int c) {
     const int row = row0 + i * cp.istride;
-    return (c0 + c < g.Wc && row >= cp.zr0 && row < cp.zr1) ? base[i * rstep + c] : make_float2(0.f, 0.f);
+    return (c0 + c < g.Wc && row >= cp.zr0 && row < cp.zr1) ? base[i * rstep + c] : make_real2((real)0., (real)0.);
   };
   fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1>(s, plan, T, cp.tdiv, tid, in, LdsNatural{});
 #pragma unroll
   for (int k = 0; k < EMAX; ++k) {
     const int e = tid + k * NT;
     if (e < nelem) {
-      float2 x = s[e];
+      real2 x = s[e];
       x = conjH ? cmul_conj(x, h[k]) : cmul(x, h[k]);
       s[e] = cscale(x, hscale);
     }
   }
   __syncthreads();
-  auto out = [&](int i, int c, float2 x) {
+  auto out = [&](int i, int c, real2 x) {
     if (c0 + c < g.Wc) base[i * rstep + c] = x;
   };
   fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL>(s, plan, T, cp.tdiv, tid, LdsNatural{}, out);
@@ -316,36 +316,36 @@ __global__ __launch_bounds__(NT) void k_cols_mid_mul(PlaneGeom g, Fft1dPlan plan
 // Tile: [N][2T] -- columns 0..T-1 belong to SA, T..2T-1 to SB.
 template <int NT, int EMAX>
 __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan plan, ColPass cp,
-                                                       float2* LPC_RESTRICT SA,
-                                                       float2* LPC_RESTRICT SB,
-                                                       const float2* LPC_RESTRICT Hs,
-                                                       const float* LPC_RESTRICT Gabs,
-                                                       const float2* LPC_RESTRICT phr,
-                                                       const float2* LPC_RESTRICT phc,
-                                                       FastDiv t2div, float mu1, float mu2, float mu3,
-                                                       float rscale) {
+                                                       real2* LPC_RESTRICT SA,
+                                                       real2* LPC_RESTRICT SB,
+                                                       const real2* LPC_RESTRICT Hs,
+                                                       const real* LPC_RESTRICT Gabs,
+                                                       const real2* LPC_RESTRICT phr,
+                                                       const real2* LPC_RESTRICT phc,
+                                                       FastDiv t2div, real mu1, real mu2, real mu3,
+                                                       real rscale) {
   LPC_DYN_SMEM(smem);
-  float2* s = (float2*)smem;
+  real2* s = (real2*)smem;
   const int tid = threadIdx.x;
   const int T = cp.T, T2 = 2 * cp.T;
   const int grp = (int)fd_div(blockIdx.x, cp.tcdiv);
   const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * T;
   const long rowoff = ((long)grp * cp.gstride) * g.cpitch + c0;
-  float2* ba = SA + (long)blockIdx.y * g.cplane + rowoff;
-  float2* bb = SB + (long)blockIdx.y * g.cplane + rowoff;
+  real2* ba = SA + (long)blockIdx.y * g.cplane + rowoff;
+  real2* bb = SB + (long)blockIdx.y * g.cplane + rowoff;
   const int pp = (int)blockIdx.y % g.DC;
-  const float2* hb = Hs + (long)pp * g.cplane + rowoff;
-  const float* rb = Gabs + rowoff;  // |PsiT Psi| spectrum: one plane, the same for every channel
+  const real2* hb = Hs + (long)pp * g.cplane + rowoff;
+  const real* rb = Gabs + rowoff;  // |PsiT Psi| spectrum: one plane, the same for every channel
   const int npair = cp.N * T;
   const long rstep = (long)cp.istride * g.cpitch;
   constexpr int EP = (EMAX + 1) / 2;
-  float2 h[EP];
-  float rd[EP];
+  real2 h[EP];
+  real rd[EP];
 #pragma unroll
   for (int k = 0; k < EP; ++k) {      // spectral constants: in flight during the forward FFT
     const int e = tid + k * NT;
-    h[k] = make_float2(0.f, 0.f);
-    rd[k] = 0.f;
+    h[k] = make_real2((real)0., (real)0.);
+    rd[k] = (real)0.;
     if (e < npair) {
       const int i = (int)fd_div((unsigned)e, cp.tdiv);
       const int j = e - i * T;
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
   }
   auto in = [&](int i, int c) {
     const int j = c < T ? c : c - T;
-    return (c0 + j < g.Wc) ? (c < T ? ba : bb)[i * rstep + j] : make_float2(0.f, 0.f);
+    return (c0 + j < g.Wc) ? (c < T ? ba : bb)[i * rstep + j] : make_real2((real)0., (real)0.);
   };
   fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1>(s, plan, T2, t2div, tid, in, LdsNatural{});
 #pragma unroll
@@ -364,23 +364,23 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
       const int i = (int)fd_div((unsigned)e, cp.tdiv);
       const int j = e - i * T;
       if (c0 + j < g.Wc) {
-        const float2 hh = h[k];
+        const real2 hh = h[k];
         // R_divmat = 1 / (mu1 |H* H| + mu2 |PsiT Psi| + mu3)  (admm.py:186-190), formed on the fly so
         // that per-iteration step sizes cost nothing; rscale folds the inverse FFT's 1/(Hp*Wp)
-        const float rdiv = rscale * (1.0f / (mu1 * fabsf(hh.x * hh.x + hh.y * hh.y) + mu2 * rd[k] + mu3));
-        const float2 ph = cmul(phr[grp * cp.gstride + i * cp.istride], phc[c0 + j]);
-        const float2 rh = s[i * T2 + j];
-        const float2 ah = s[i * T2 + T + j];
-        float2 t = cmul(cmul_conj(ah, hh), ph);          // s * conj(H) * Ah
-        float2 vh = cscale(cadd(rh, t), rdiv);
-        float2 hv = cmul(cmul(vh, hh), ph);
+        const real rdiv = rscale * ((real)1.0 / (mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * rd[k] + mu3));
+        const real2 ph = cmul(phr[grp * cp.gstride + i * cp.istride], phc[c0 + j]);
+        const real2 rh = s[i * T2 + j];
+        const real2 ah = s[i * T2 + T + j];
+        real2 t = cmul(cmul_conj(ah, hh), ph);          // s * conj(H) * Ah
+        real2 vh = cscale(cadd(rh, t), rdiv);
+        real2 hv = cmul(cmul(vh, hh), ph);
         s[i * T2 + j] = vh;
         s[i * T2 + T + j] = hv;
       }
     }
   }
   __syncthreads();
-  auto out = [&](int i, int c, float2 x) {
+  auto out = [&](int i, int c, real2 x) {
     const int j = c < T ? c : c - T;
     if (c0 + j < g.Wc) (c < T ? ba : bb)[i * rstep + j] = x;
   };
@@ -398,41 +398,41 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
 // eta is read at halo pixels owned by neighbouring workgroups, so its update is written to a
 // second buffer (ping-pong, no extra traffic); every other array is touched only at owned pixels.
 struct AdmmScalars {
-  float mu1, mu2, mu3;  // this iteration's step sizes
-  float thr;            // (float)(tau / mu2)
-  float m_in, m_out;    // X_divmat inside / outside the sensor window
+  real mu1, mu2, mu3;  // this iteration's step sizes
+  real thr;            // (real)(tau / mu2)
+  real m_in, m_out;    // X_divmat inside / outside the sensor window
   int first;            // 1: no pending dual update (first iteration after reset)
   // the PREVIOUS iteration's values: its dual updates are still pending and its U, W are recomputed.
   // Equal to the current ones for plain ADMM; differ for unrolled ADMM (unrolled_admm.py:171-211)
-  float mu1p, mu2p, mu3p, thrp;
+  real mu1p, mu2p, mu3p, thrp;
 };
 
-static __device__ __forceinline__ float soft_thresh_dev(float a, float thr) {
-  const float m = fmaxf(fabsf(a) - thr, 0.f);
-  return a > 0.f ? m : (a < 0.f ? -m : 0.f);
+static __device__ __forceinline__ real soft_thresh_dev(real a, real thr) {
+  const real m = rmax(rabs(a) - thr, (real)0.);
+  return a > (real)0. ? m : (a < (real)0. ? -m : (real)0.);
 }
 
 template <int TH, int TW, int NT>
 __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
-                                                      const float* LPC_RESTRICT V,
-                                                      const float* LPC_RESTRICT Vold,
-                                                      const float* LPC_RESTRICT HV,
-                                                      float* LPC_RESTRICT X, float* LPC_RESTRICT xi,
-                                                      const float* LPC_RESTRICT eta0,
-                                                      const float* LPC_RESTRICT eta1,
-                                                      float* LPC_RESTRICT eta0_out,
-                                                      float* LPC_RESTRICT eta1_out,
-                                                      float* LPC_RESTRICT rho,
-                                                      const float* LPC_RESTRICT Y,
-                                                      float* LPC_RESTRICT Rsp, float* LPC_RESTRICT Aout,
-                                                      unsigned tiles_x, const float* LPC_RESTRICT VWc,
-                                                      const float* LPC_RESTRICT VWo) {
+                                                      const real* LPC_RESTRICT V,
+                                                      const real* LPC_RESTRICT Vold,
+                                                      const real* LPC_RESTRICT HV,
+                                                      real* LPC_RESTRICT X, real* LPC_RESTRICT xi,
+                                                      const real* LPC_RESTRICT eta0,
+                                                      const real* LPC_RESTRICT eta1,
+                                                      real* LPC_RESTRICT eta0_out,
+                                                      real* LPC_RESTRICT eta1_out,
+                                                      real* LPC_RESTRICT rho,
+                                                      const real* LPC_RESTRICT Y,
+                                                      real* LPC_RESTRICT Rsp, real* LPC_RESTRICT Aout,
+                                                      unsigned tiles_x, const real* LPC_RESTRICT VWc,
+                                                      const real* LPC_RESTRICT VWo) {
   LPC_DYN_SMEM(smem);
   constexpr int VW = TW + 2, VH = TH + 2;
-  float* sV = (float*)smem;                 // [VH][VW], local (ly+1, lx+1)
-  float* sO = sV + VH * VW;                 // same for V_old
-  float* sQ0 = sO + VH * VW;                // [TH+1][TW]
-  float* sQ1 = sQ0 + (TH + 1) * TW;         // [TH][TW+1]
+  real* sV = (real*)smem;                 // [VH][VW], local (ly+1, lx+1)
+  real* sO = sV + VH * VW;                 // same for V_old
+  real* sQ0 = sO + VH * VW;                // [TH+1][TW]
+  real* sQ1 = sQ0 + (TH + 1) * TW;         // [TH][TW+1]
   const int tid = threadIdx.x;
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed
   // only).  Give each XCD a contiguous band of tiles so that the halo lines shared by neighbouring
@@ -444,8 +444,8 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
   const int r0 = (int)ty_ * TH, c0 = (int)(tile - ty_ * tiles_x) * TW;
   const long pl = blockIdx.y;
   const long poff = pl * g.rplane;
-  const float* v = V + poff;
-  const float* vo = Vold + poff;
+  const real* v = V + poff;
+  const real* vo = Vold + poff;
 
   // ---- stage V, V_old (+halo, circular) ----
   for (int e = tid; e < VH * VW; e += NT) {
@@ -455,7 +455,7 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
     gc = gc < 0 ? gc + g.Wp : gc; gc = gc >= g.Wp ? gc - g.Wp : gc; gc = gc >= g.Wp ? gc % g.Wp : gc;
     const long o = (long)gr * g.rpitch + gc;
     sV[e] = v[o];
-    sO[e] = p.first ? 0.f : vo[o];
+    sO[e] = p.first ? (real)0. : vo[o];
   }
   __syncthreads();
 
@@ -468,28 +468,28 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
     gc = gc >= g.Wp ? gc % g.Wp : gc;
     const long o = poff + (long)gr * g.rpitch + gc;
     const int li = (ly + 1) * VW + (lx + 1);
-    const float vc = sV[li], oc = sO[li];
+    const real vc = sV[li], oc = sO[li];
     if (lx < TW) {  // component 0 (row difference)
-      float e0 = eta0[o];
-      const float psi = sV[li - VW] - vc;
+      real e0 = eta0[o];
+      const real psi = sV[li - VW] - vc;
       if (!p.first) {
-        const float psio = sO[li - VW] - oc;
-        const float uo = soft_thresh_dev(psio + e0 / p.mu2p, p.thrp);
+        const real psio = sO[li - VW] - oc;
+        const real uo = soft_thresh_dev(psio + e0 / p.mu2p, p.thrp);
         e0 = e0 + p.mu2p * (psi - uo);
       }
-      const float un = soft_thresh_dev(psi + e0 / p.mu2, p.thr);
+      const real un = soft_thresh_dev(psi + e0 / p.mu2, p.thr);
       sQ0[ly * TW + lx] = p.mu2 * un - e0;
       if (own) eta0_out[o] = e0;
     }
     if (ly < TH) {  // component 1 (column difference)
-      float e1 = eta1[o];
-      const float psi = sV[li - 1] - vc;
+      real e1 = eta1[o];
+      const real psi = sV[li - 1] - vc;
       if (!p.first) {
-        const float psio = sO[li - 1] - oc;
-        const float uo = soft_thresh_dev(psio + e1 / p.mu2p, p.thrp);
+        const real psio = sO[li - 1] - oc;
+        const real uo = soft_thresh_dev(psio + e1 / p.mu2p, p.thrp);
         e1 = e1 + p.mu2p * (psi - uo);
       }
-      const float un = soft_thresh_dev(psi + e1 / p.mu2, p.thr);
+      const real un = soft_thresh_dev(psi + e1 / p.mu2, p.thr);
       sQ1[ly * (TW + 1) + lx] = p.mu2 * un - e1;
       if (own) eta1_out[o] = e1;
     }
@@ -498,28 +498,28 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
 
   // ---- owned pixels: xi, rho, X, W, r_sp, a ----
   const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
-  const float* y = Y + (long)dpl * g.uplane;
+  const real* y = Y + (long)dpl * g.uplane;
   for (int e = tid; e < TH * TW; e += NT) {
     const int ly = e / TW, lx = e - ly * TW;
     const int gr = r0 + ly, gc = c0 + lx;
     if (gr >= g.Hp || gc >= g.Wp) continue;
     const long o = poff + (long)gr * g.rpitch + gc;
     const int li = (ly + 1) * VW + (lx + 1);
-    const float vc = sV[li];
-    const float hv = HV[o];
-    float xiv = xi[o], rhov = rho[o];
+    const real vc = sV[li];
+    const real hv = HV[o];
+    real xiv = xi[o], rhov = rho[o];
     if (!p.first) {
-      const float xo = X[o];
+      const real xo = X[o];
       xiv = xiv + p.mu1p * (hv - xo);
-      const float wo = fmaxf(rhov / p.mu3p + (VWo ? VWo[o] : sO[li]), 0.f);
+      const real wo = rmax(rhov / p.mu3p + (VWo ? VWo[o] : sO[li]), (real)0.);
       rhov = rhov + p.mu3p * (vc - wo);
     }
     const bool inside = (gr >= g.sh) && (gr < g.sh + g.H) && (gc >= g.sw) && (gc < g.sw + g.W);
-    const float yv = inside ? y[(long)(gr - g.sh) * g.W + (gc - g.sw)] : 0.f;
-    const float xn = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
-    const float wn = fmaxf(rhov / p.mu3 + (VWc ? VWc[o] : vc), 0.f);
-    const float d1 = sQ0[(ly + 1) * TW + lx] - sQ0[ly * TW + lx];
-    const float d2 = sQ1[ly * (TW + 1) + lx + 1] - sQ1[ly * (TW + 1) + lx];
+    const real yv = inside ? y[(long)(gr - g.sh) * g.W + (gc - g.sw)] : (real)0.;
+    const real xn = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
+    const real wn = rmax(rhov / p.mu3 + (VWc ? VWc[o] : vc), (real)0.);
+    const real d1 = sQ0[(ly + 1) * TW + lx] - sQ0[ly * TW + lx];
+    const real d2 = sQ1[ly * (TW + 1) + lx + 1] - sQ1[ly * (TW + 1) + lx];
     xi[o] = xiv;
     rho[o] = rhov;
     X[o] = xn;
@@ -528,6 +528,7 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
   }
 }
 
+#ifndef LPC_DOUBLE  // float4 lanes: the float64 build uses k_admm_spatial
 // ---- K1, 16-byte-lane version (padded width a multiple of 4) -----------------------------------
 // Same arithmetic as k_admm_spatial, re-shaped for HBM: every lane moves float4 (a wave covers 1 KiB of
 // one image row per array), tiles are 8 rows x 256 columns, only V / V_old are staged in LDS (+1 halo,
@@ -679,18 +680,20 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
   }
 }
 
+#endif  // !LPC_DOUBLE
+
 // materialise U, W and the flushed duals for inspection (tests / get_state); no state change
 template <int NT>
 __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
-                                                    const float* LPC_RESTRICT V,
-                                                    const float* LPC_RESTRICT Vold,
-                                                    const float* LPC_RESTRICT HV,
-                                                    const float* LPC_RESTRICT X,
-                                                    const float* LPC_RESTRICT xi,
-                                                    const float* LPC_RESTRICT eta0,
-                                                    const float* LPC_RESTRICT eta1,
-                                                    const float* LPC_RESTRICT rho, float* LPC_RESTRICT out,
-                                                    long ostride, const float* LPC_RESTRICT VWo) {
+                                                    const real* LPC_RESTRICT V,
+                                                    const real* LPC_RESTRICT Vold,
+                                                    const real* LPC_RESTRICT HV,
+                                                    const real* LPC_RESTRICT X,
+                                                    const real* LPC_RESTRICT xi,
+                                                    const real* LPC_RESTRICT eta0,
+                                                    const real* LPC_RESTRICT eta1,
+                                                    const real* LPC_RESTRICT rho, real* LPC_RESTRICT out,
+                                                    long ostride, const real* LPC_RESTRICT VWo) {
   // out planes of size ostride*: 0 xi', 1 eta0', 2 eta1', 3 rho', 4 U0, 5 U1, 6 W
   const long n = (long)g.Hp * g.Wp;
   const long pl = blockIdx.y;
@@ -699,13 +702,13 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
     const long o = pl * g.rplane + (long)r * g.rpitch + c;
     const long ou = pl * g.rplane + (long)wrap_add(r, -1, g.Hp) * g.rpitch + c;
     const long ol = pl * g.rplane + (long)r * g.rpitch + wrap_add(c, -1, g.Wp);
-    float xiv = xi[o], e0 = eta0[o], e1 = eta1[o], rh = rho[o];
-    float u0 = 0.f, u1 = 0.f, w = 0.f;
+    real xiv = xi[o], e0 = eta0[o], e1 = eta1[o], rh = rho[o];
+    real u0 = (real)0., u1 = (real)0., w = (real)0.;
     if (!p.first) {
-      const float oc = Vold[o], vc = V[o];
+      const real oc = Vold[o], vc = V[o];
       u0 = soft_thresh_dev((Vold[ou] - oc) + e0 / p.mu2p, p.thrp);
       u1 = soft_thresh_dev((Vold[ol] - oc) + e1 / p.mu2p, p.thrp);
-      w = fmaxf(rh / p.mu3p + (VWo ? VWo[o] : oc), 0.f);
+      w = rmax(rh / p.mu3p + (VWo ? VWo[o] : oc), (real)0.);
       xiv = xiv + p.mu1p * (HV[o] - X[o]);
       e0 = e0 + p.mu2p * ((V[ou] - vc) - u0);
       e1 = e1 + p.mu2p * ((V[ol] - vc) - u1);
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
 // ========================================================= layout / setup kernels ==
 // channels-last (n, rows, cols, C) <-> planar (n*C planes)[rows][pitch]
 template <int NT>
-__global__ __launch_bounds__(NT) void k_hwc_to_planar(const float* LPC_RESTRICT src, float* LPC_RESTRICT dst,
+__global__ __launch_bounds__(NT) void k_hwc_to_planar(const real* LPC_RESTRICT src, real* LPC_RESTRICT dst,
                                                        int rows, int cols, int C, int pitch, long dplane) {
   const long n = (long)rows * cols * C;
   const long img = blockIdx.y;
@@ -741,7 +744,7 @@ __global__ __launch_bounds__(NT) void k_hwc_to_planar(const float* LPC_RESTRICT 
 // the clamped value back into the planar source (the reference's ADMM._form_image clamps
 // its state IN PLACE, admm.py:331-338).
 template <int NT>
-__global__ __launch_bounds__(NT) void k_planar_to_hwc(float* LPC_RESTRICT src, float* LPC_RESTRICT dst,
+__global__ __launch_bounds__(NT) void k_planar_to_hwc(real* LPC_RESTRICT src, real* LPC_RESTRICT dst,
                                                        int rows, int cols, int C, int pitch, long splane,
                                                        int row0, int col0, int clamp, int clamp_src) {
   const long n = (long)rows * cols * C;
@@ -752,10 +755,10 @@ __global__ __launch_bounds__(NT) void k_planar_to_hwc(float* LPC_RESTRICT src, f
     const int col = (int)(rc % cols);
     const int row = (int)(rc / cols);
     const long so = (img * C + c) * splane + (long)(row0 + row) * pitch + (col0 + col);
-    float v = src[so];
-    if (clamp && v < 0.f) {
-      v = 0.f;
-      if (clamp_src) src[so] = 0.f;
+    real v = src[so];
+    if (clamp && v < (real)0.) {
+      v = (real)0.;
+      if (clamp_src) src[so] = (real)0.;
     }
     dst[img * n + e] = v;
   }
@@ -763,35 +766,35 @@ __global__ __launch_bounds__(NT) void k_planar_to_hwc(float* LPC_RESTRICT src, f
 
 // dst = src with the sensor window clamped at 0 (the reference's in-place clamp of ADMM._form_image)
 template <int NT>
-__global__ __launch_bounds__(NT) void k_clamp_window_copy(PlaneGeom g, const float* LPC_RESTRICT src,
-                                                           float* LPC_RESTRICT dst) {
+__global__ __launch_bounds__(NT) void k_clamp_window_copy(PlaneGeom g, const real* LPC_RESTRICT src,
+                                                           real* LPC_RESTRICT dst) {
   const long n = (long)g.Hp * g.rpitch;
   const long pl = blockIdx.y;
   for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
     const int r = (int)(e / g.rpitch), c = (int)(e - (long)r * g.rpitch);
-    float v = src[pl * g.rplane + e];
-    if (r >= g.sh && r < g.sh + g.H && c >= g.sw && c < g.sw + g.W && v < 0.f) v = 0.f;
+    real v = src[pl * g.rplane + e];
+    if (r >= g.sh && r < g.sh + g.H && c >= g.sw && c < g.sw + g.W && v < (real)0.) v = (real)0.;
     dst[pl * g.rplane + e] = v;
   }
 }
 
 // |G| of the TV gram spectrum (admm.py:188 takes torch.abs of it), one plane
 template <int NT>
-__global__ __launch_bounds__(NT) void k_abs_complex(const float2* LPC_RESTRICT Gs, float* LPC_RESTRICT out, long n) {
+__global__ __launch_bounds__(NT) void k_abs_complex(const real2* LPC_RESTRICT Gs, real* LPC_RESTRICT out, long n) {
   for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
-    const float2 gg = Gs[e];
-    out[e] = sqrtf(gg.x * gg.x + gg.y * gg.y);
+    const real2 gg = Gs[e];
+    out[e] = rsqrt_of(gg.x * gg.x + gg.y * gg.y);
   }
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_scale_complex(float2* LPC_RESTRICT S, long n, float sc) {
+__global__ __launch_bounds__(NT) void k_scale_complex(real2* LPC_RESTRICT S, long n, real sc) {
   for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
     S[e] = cscale(S[e], sc);
   }
 }
 
 template <int NT>
-__global__ __launch_bounds__(NT) void k_fill(float* LPC_RESTRICT p, long n, float v) {
+__global__ __launch_bounds__(NT) void k_fill(real* LPC_RESTRICT p, long n, real v) {
   for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) p[e] = v;
 }

@@ -29,6 +29,8 @@ struct dim3 {
 };
 struct float2 { float x, y; };
 struct float4 { float x, y, z, w; };
+struct double2 { double x, y; };
+static inline double2 make_double2(double x, double y) { double2 r; r.x = x; r.y = y; return r; }
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
 static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
 
@@ -113,19 +115,40 @@ static inline const char* backend_name() { return "hip-gfx950"; }
 
 #endif
 
-// ------------------------------------------------------------ small helpers --
-struct cfloat { float x, y; };  // POD complex, layout-compatible with float2
+// ------------------------------------------------------------ arithmetic type --
+// The engine is written once over `real`; the SAME translation unit is compiled twice:
+// liblpc.so (float, the reference's default dtype) and liblpc_f64.so (-DLPC_DOUBLE, dtype="float64").
+#ifdef LPC_DOUBLE
+typedef double real;
+typedef double2 real2;
+#define make_real2 make_double2
+#define LPC_REAL_NAME "float64"
+static __host__ __device__ __forceinline__ real rmax(real a, real b) { return fmax(a, b); }
+static __host__ __device__ __forceinline__ real rmin(real a, real b) { return fmin(a, b); }
+static __host__ __device__ __forceinline__ real rabs(real a) { return fabs(a); }
+static __host__ __device__ __forceinline__ real rsqrt_of(real a) { return sqrt(a); }
+#else
+typedef float real;
+typedef float2 real2;
+#define make_real2 make_float2
+#define LPC_REAL_NAME "float32"
+static __host__ __device__ __forceinline__ real rmax(real a, real b) { return fmaxf(a, b); }
+static __host__ __device__ __forceinline__ real rmin(real a, real b) { return fminf(a, b); }
+static __host__ __device__ __forceinline__ real rabs(real a) { return fabsf(a); }
+static __host__ __device__ __forceinline__ real rsqrt_of(real a) { return sqrtf(a); }
+#endif
 
-static __host__ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
-  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+// ------------------------------------------------------------ small helpers --
+static __host__ __device__ __forceinline__ real2 cmul(real2 a, real2 b) {
+  return make_real2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
-static __host__ __device__ __forceinline__ float2 cmul_conj(float2 a, float2 b) {  // a * conj(b)
-  return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+static __host__ __device__ __forceinline__ real2 cmul_conj(real2 a, real2 b) {  // a * conj(b)
+  return make_real2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
 }
-static __host__ __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-static __host__ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-static __host__ __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
-static __host__ __device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x * s, a.y * s); }
+static __host__ __device__ __forceinline__ real2 cadd(real2 a, real2 b) { return make_real2(a.x + b.x, a.y + b.y); }
+static __host__ __device__ __forceinline__ real2 csub(real2 a, real2 b) { return make_real2(a.x - b.x, a.y - b.y); }
+static __host__ __device__ __forceinline__ real2 cconj(real2 a) { return make_real2(a.x, -a.y); }
+static __host__ __device__ __forceinline__ real2 cscale(real2 a, real s) { return make_real2(a.x * s, a.y * s); }
 
 // division of small non-negative ints by a plan-time constant: q = floor(n/d) for
 // n*d < 2^32 (all tile-local indices here are < 2^16).

@@ -35,12 +35,12 @@ def reconstruct_sharded(algo_cls, psf, frames, n_iter, group=None, **algo_kwargs
         local = rec.apply_batch(n_iter=n_iter)
         local = local if is_torch else torch.from_numpy(local)
     else:
-        local = torch.empty((0, D, H, W, C), dtype=torch.float32)
+        local = torch.empty((0, D, H, W, C), dtype=rec._tdtype)
     if world == 1:
         return local if is_torch else local.numpy()
     dev = rec._device if rec._device.type == "cuda" else torch.device("cpu")
     cap = -(-B // world)
-    buf = torch.zeros((cap, D, H, W, C), dtype=torch.float32, device=dev)
+    buf = torch.zeros((cap, D, H, W, C), dtype=rec._tdtype, device=dev)
     buf[: hi - lo] = local.to(dev)
     gathered = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(gathered, buf, group=group)      # the single collective of the path

@@ -18,9 +18,9 @@ import torch
 from . import _native
 
 
-def runtime():
-    """(Lib, torch.device) of the product path.  Fails loudly without a HIP device."""
-    lib = _native.default_lib()
+def runtime(dtype="float32"):
+    """(Lib, torch.device) of the product path for ``dtype``.  Fails loudly without a HIP device."""
+    lib = _native.default_lib(dtype)
     return lib, torch.device("cuda", torch.cuda.current_device())
 
 
@@ -39,25 +39,23 @@ def _check_dtype(dtype, is_torch):
     if not is_torch and dtype in (np.float32, np.float64):
         dtype = np.dtype(dtype).name
     assert dtype == "float32" or dtype == "float64"
-    if dtype == "float64":
-        raise ValueError(
-            "Unsupported dtype : float64 (the MI355X engine computes in float32; see DESIGN.md)"
-        )
     return dtype
 
 
 class _Boundary:
     """Shared input/output plumbing: numpy or torch in, same kind out, float32 on the device."""
 
-    def _init_boundary(self, psf):
+    def _init_boundary(self, psf, dtype="float32"):
         self.is_torch = isinstance(psf, torch.Tensor)
-        self._lib, self._device = runtime()
+        self._real = dtype                                   # "float32" | "float64"
+        self._tdtype = torch.float64 if dtype == "float64" else torch.float32
+        self._lib, self._device = runtime(dtype)
         self._out_device = psf.device if self.is_torch else None
 
     def _to_dev(self, a):
         if isinstance(a, np.ndarray):
             a = torch.from_numpy(np.ascontiguousarray(a))
-        return a.detach().to(device=self._device, dtype=torch.float32).contiguous()
+        return a.detach().to(device=self._device, dtype=self._tdtype).contiguous()
 
     def _to_user(self, t):
         if self.is_torch:
@@ -68,7 +66,7 @@ class _Boundary:
         return _stream_handle(self._device)
 
     def _empty(self, shape):
-        return torch.empty(tuple(int(s) for s in shape), dtype=torch.float32, device=self._device)
+        return torch.empty(tuple(int(s) for s in shape), dtype=self._tdtype, device=self._device)
 
 
 class ReconstructionAlgorithm(_Boundary, abc.ABC):
@@ -79,17 +77,16 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
     def __init__(self, psf, dtype=None, pad=True, n_iter=100, initial_est=None, reset=True,
                  denoiser=None, **kwargs):
         super().__init__()
-        self._init_boundary(psf)
         assert len(psf.shape) == 4, "PSF must be 4D: (depth, height, width, channels)."
         assert psf.shape[3] == 3 or psf.shape[3] == 1, "PSF must either be rgb (3) or grayscale (1)"
-        _check_dtype(dtype, self.is_torch)
+        self._init_boundary(psf, _check_dtype(dtype, isinstance(psf, torch.Tensor)))
         if denoiser is not None:
             raise NotImplementedError(
                 "plug-and-play denoisers are outside the fused hot path (SURVEY.md section 8f, N4)"
             )
         self._psf = psf
         self._psf_dev = self._to_dev(psf)
-        self._dtype = torch.float32 if self.is_torch else np.float32
+        self._dtype = self._tdtype if self.is_torch else (np.float64 if self._real == "float64" else np.float32)
         self._npix = int(np.prod(psf.shape))
         self._n_iter = n_iter
         self._psf_shape = np.array(psf.shape)
@@ -293,7 +290,7 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
             lensless = self._data
         if psfs is None:
             psfs = self._psf
-        conv = RealFFTConvolve2D(psfs, pad=True, norm=self._norm)
+        conv = RealFFTConvolve2D(psfs, dtype=self._real, pad=True, norm=self._norm)
         Hx = conv.convolve(prediction)
         Hx_t = torch.as_tensor(Hx) if not isinstance(Hx, torch.Tensor) else Hx
         y_t = torch.as_tensor(lensless) if not isinstance(lensless, torch.Tensor) else lensless

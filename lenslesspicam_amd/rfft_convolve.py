@@ -18,7 +18,7 @@ from .recon import _Boundary, _check_dtype
 
 class RealFFTConvolve2D(_Boundary):
     def __init__(self, psf, dtype=None, pad=True, norm="ortho", rgb=None, **kwargs):
-        self._init_boundary(psf)
+        self._init_boundary(psf, _check_dtype(dtype, isinstance(psf, torch.Tensor)))
         assert len(psf.shape) >= 4, "Expected 4D PSF of shape ([batch], depth, width, height, channels)"
         if len(psf.shape) != 4:
             raise NotImplementedError("batched PSFs (5-D) are used only by trainable models (out of scope)")
@@ -26,8 +26,7 @@ class RealFFTConvolve2D(_Boundary):
         self._is_rgb = (psf.shape[-1] == 3) if rgb is None else rgb
         assert self._is_rgb or psf.shape[-1] == 1
         self.norm = norm
-        _check_dtype(dtype, self.is_torch)
-        self.dtype = torch.float32 if self.is_torch else np.float32
+        self.dtype = self._tdtype if self.is_torch else (np.float64 if self._real == "float64" else np.float32)
         self.pad = pad
         self._handle = None
         self._handle_batch = 0

@@ -11,6 +11,7 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 EMU_DIR = os.path.join(ROOT, "tests", "simt_emu")
 EMU_LIB = os.path.join(EMU_DIR, "_build", "liblpc_emu.so")
+EMU_LIB_F64 = os.path.join(EMU_DIR, "_build", "liblpc_emu_f64.so")
 
 
 def pytest_configure(config):
@@ -29,12 +30,13 @@ def emu_lib():
     """SIMT-emulator build of the engine's real kernel sources (tests only, see lpc_rt.h)."""
     from lenslesspicam_amd import _native
 
-    stale = not os.path.exists(EMU_LIB) or any(
-        os.path.getmtime(f) > os.path.getmtime(EMU_LIB) for f in _emu_sources()
-    )
+    stale = any(not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in _emu_sources())
+                for lib in (EMU_LIB, EMU_LIB_F64))
     if stale:
         subprocess.check_call(["sh", os.path.join(EMU_DIR, "build_emu.sh")])
-    return _native.Lib(EMU_LIB)
+    lib = _native.Lib(EMU_LIB)
+    lib.f64 = _native.Lib(EMU_LIB_F64)     # the float64 flavour rides along
+    return lib
 
 
 class Backend:
@@ -54,7 +56,7 @@ def backend(request, monkeypatch):
     if request.param == "emu":
         lib = request.getfixturevalue("emu_lib")
         dev = torch.device("cpu")
-        monkeypatch.setattr(recon, "runtime", lambda: (lib, dev))
+        monkeypatch.setattr(recon, "runtime", lambda dtype="float32": (lib.f64 if dtype == "float64" else lib, dev))
         return Backend("emu", lib, dev)
     lib, dev = recon.runtime()  # raises without a GPU / without the HIP library
     assert lib.backend().startswith("hip")

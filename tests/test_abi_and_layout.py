@@ -20,14 +20,16 @@ def _header_symbols():
 def test_hip_library_exports_every_header_symbol():
     from lenslesspicam_amd import build
 
-    path = build.build_hip(force=False, verbose=False)  # hipcc cross-compiles gfx950 without a GPU
-    dll = ctypes.CDLL(path)
+    build.build_hip(force=False, verbose=False)  # hipcc cross-compiles gfx950 without a GPU
     syms = _header_symbols()
-    assert len(syms) >= 18
-    for name in syms:
-        assert hasattr(dll, name), name
-    dll.lpc_backend.restype = ctypes.c_char_p
-    assert dll.lpc_backend() == b"hip-gfx950"
+    assert len(syms) >= 20
+    for path, real in ((build.OUT, b"float32"), (build.OUT_F64, b"float64")):
+        dll = ctypes.CDLL(path)
+        for name in syms:
+            assert hasattr(dll, name), (path, name)
+        dll.lpc_backend.restype = ctypes.c_char_p
+        dll.lpc_real_name.restype = ctypes.c_char_p
+        assert dll.lpc_backend() == b"hip-gfx950" and dll.lpc_real_name() == real
 
 
 def test_emulator_build_exports_the_same_abi(emu_lib):
@@ -95,8 +97,12 @@ def test_reference_api_surface_and_errors(backend):
         lpa.ADMM(psf[0])                                        # PSF must be 4-D
     with pytest.raises(AssertionError):
         lpa.ADMM(np.zeros((1, 8, 8, 2), np.float32))            # C in {1,3}
-    with pytest.raises(ValueError):
-        lpa.ADMM(psf, dtype="float64")
+    for dt in ("float32", "float64"):                           # test/test_algos.py:89-131 loops both dtypes
+        r64 = lpa.GradientDescent(psf.astype(dt), dtype=dt, n_iter=2)
+        r64.set_data(psf[0].astype(dt))
+        assert r64.apply(disp_iter=None, plot=False).dtype == np.dtype(dt)
+    with pytest.raises(AssertionError):
+        lpa.ADMM(psf, dtype="float16")
     with pytest.raises(NotImplementedError):
         lpa.ADMM(psf, denoiser={"network": "DruNet", "noise_level": 10})
     with pytest.raises(NotImplementedError):

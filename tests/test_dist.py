@@ -23,7 +23,7 @@ def _worker(rank, world, port, emu_path, out_dir):
     from lenslesspicam_amd.dist import reconstruct_sharded, shard_bounds
 
     lib = _native.Lib(emu_path)
-    recon.runtime = lambda: (lib, torch.device("cpu"))
+    recon.runtime = lambda dtype="float32": (lib, torch.device("cpu"))
     rng = np.random.default_rng(0)
     psf = rng.random((1, 12, 16, 3), dtype=np.float32) ** 4
     psf /= np.linalg.norm(psf.ravel())
