@@ -316,7 +316,7 @@ static int setup_geometry(Engine* e) {
   const int ntc = (g.Wc + e->T - 1) / e->T;
   ColPass& A = e->passA;
   A.N = e->N1; A.G = e->N2; A.istride = e->N2; A.gstride = 1; A.T = e->T; A.ntile_c = ntc;
-  A.tw_mode = 0; A.zr0 = 0; A.zr1 = g.Hp; A.twH = e->twH;
+  A.tw_mode = 0; A.zr0 = 0; A.zr1 = g.Hp; A.twH = e->twH; A.need0 = 0; A.needn = g.Hp;
   A.tdiv = make_fastdiv((unsigned)e->T); A.tcdiv = make_fastdiv((unsigned)ntc);
   ColPass& B = e->passB;
   B = A;
@@ -353,12 +353,17 @@ static int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes,
 }
 
 // column pass A (only when split) over nplanes planes; inverse => conj twiddles before FFT
-static int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1, int kid) {
+static int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1, int kid,
+                      bool crop_rows_only = false) {
   if (e->N1 == 1) return 0;
   const PlaneGeom& g = e->g;
   ColPass cp = e->passA;
   cp.tw_mode = inverse ? 2 : 1;
   cp.zr0 = zr0; cp.zr1 = zr1;
+  if (inverse && crop_rows_only) {   // the row pass that follows reads spectrum rows (sh + u + Hp/2) mod Hp, u < H
+    cp.need0 = (g.sh + g.Hp / 2) % g.Hp;
+    cp.needn = g.H;
+  }
   const dim3 grid(cp.G * cp.ntile_c, nplanes);
   return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
@@ -397,7 +402,8 @@ static int fft2_forward_setup(Engine* e, const RealSrc& src, real2* S, int nplan
 }
 
 // middle of a convolution on S (nplanes): [A] -> B fwd * H * B inv -> [A inv]
-static int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, int zr1) {
+static int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, int zr1,
+                       bool crop_rows_only = false) {
   const PlaneGeom& g = e->g;
   const bool split = e->N1 > 1;
   if (split) LPC_OK(cols_passA(e, S, nplanes, false, zr0, zr1, LPC_K_COL_A_FWD));
@@ -411,7 +417,7 @@ static int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, 
     return launch_k(e, LPC_K_COL_MID, k_cols_mid_mul<nt, em>, grid, nt, (size_t)cp.N * cp.T * sizeof(real2), g,
                     e->planB, cp, S, (const real2*)e->Hs, adjoint ? 1 : 0, hscale, e->Ppsf);
   }));
-  if (split) LPC_OK(cols_passA(e, S, nplanes, true, 0, g.Hp, LPC_K_COL_A_INV));
+  if (split) LPC_OK(cols_passA(e, S, nplanes, true, 0, g.Hp, LPC_K_COL_A_INV, crop_rows_only));
   return 0;
 }
 
@@ -464,7 +470,7 @@ static int convolve_planar(Engine* e, const real* xin, real* xout, int nplanes, 
     LPC_OK(rows_inv_single(e, e->S, dst_padded(e, xout), nplanes, LPC_K_ROW_INV));
   } else {
     LPC_OK(rows_fwd_single(e, src_unpadded(e, xin), e->S, nplanes, LPC_K_ROW_FWD));
-    LPC_OK(conv_middle(e, e->S, nplanes, adjoint, g.sh, g.sh + g.H));
+    LPC_OK(conv_middle(e, e->S, nplanes, adjoint, g.sh, g.sh + g.H, true));
     LPC_OK(rows_inv_single(e, e->S, dst_cropped(e, xout), nplanes, LPC_K_ROW_INV));
   }
   return 0;

@@ -221,6 +221,8 @@ struct ColPass {
   int tw_mode;      // 0: none; 1: multiply result k by twH[g*k] (forward pass A);
                     // 2: multiply input k by conj(twH[g*k]) (inverse pass A)
   int zr0, zr1;     // forward only: rows outside [zr0,zr1) are implicit zeros on load
+  int need0, needn; // inverse only: rows r with ((r - need0) mod Hp) >= needn are never read again
+                    // (they fall outside the crop window after ifftshift) and are not stored
   const real2* twH;  // exp(-2 pi i q / Hp), q in [0, Hp)
   FastDiv tdiv;     // fast divide by T
   FastDiv tcdiv;    // fast divide by ntile_c
@@ -250,6 +252,11 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, Fft1dPlan plan, ColPas
   auto out = [&](int i, int c, real2 x) {
     if (c0 + c < g.Wc) {
       if (!INV && cp.tw_mode == 1) x = cmul(x, cp.twH[grp * i]);
+      if (INV && cp.needn < g.Hp) {
+        int d = row0 + i * cp.istride - cp.need0;
+        d = d < 0 ? d + g.Hp : d;
+        if (d >= cp.needn) return;
+      }
       base[i * rstep + c] = x;
     }
   };
