@@ -1,7 +1,8 @@
 """
 ctypes binding of the C ABI declared in ``include/lpc.h``.
 
-The product library is ``lenslesspicam_amd/_lib/liblpc.so`` (hipcc, gfx950).  There is no
+The product libraries are ``lenslesspicam_amd/_lib/liblpc.so`` (float32) and ``liblpc_f64.so``
+(float64; the same sources with -DLPC_DOUBLE), built by hipcc for gfx950.  There is no
 CPU fallback: if the library is missing, or no HIP device is visible, the package fails
 loudly.  ``Lib`` takes an explicit path so that the test-suite can drive *other builds of
 the same C ABI* (the SIMT-emulator build under ``tests/simt_emu``) through the identical

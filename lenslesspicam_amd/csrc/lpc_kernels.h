@@ -1,6 +1,6 @@
 // lpc_kernels.h -- device kernels of the MI355X deconvolution engine.
 //
-// Memory layout in HBM (all float32):
+// Memory layout in HBM (every element is `real`: float in liblpc.so, double in liblpc_f64.so):
 //   * images are PLANAR: plane q = (b*D + d)*C + c, rows contiguous.  The reference keeps
 //     channels innermost (stride-3 FFTs); planar turns B, D and C into one batch index.
 //   * padded real plane:   [Hp][rpitch]  (rpitch >= Wp)
@@ -11,7 +11,7 @@
 // Hp = N1*N2: pass A = length-N1 FFTs over rows {n1*N2 + n2} (+ twiddle), pass B =
 // length-N2 FFTs over the contiguous row block {k1*N2 + n2}.  Frequencies therefore stay
 // in a PERMUTED row order (row k1*N2+k2 holds frequency k1 + N1*k2); every spectral
-// constant (H, R_divmat, phase tables) is generated in the same order, so no transpose
+// constant (H, |PsiT Psi|, phase tables) is generated in the same order, so no transpose
 // or reordering pass ever touches HBM.
 #pragma once
 #include "lpc_fft.h"

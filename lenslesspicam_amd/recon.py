@@ -43,7 +43,7 @@ def _check_dtype(dtype, is_torch):
 
 
 class _Boundary:
-    """Shared input/output plumbing: numpy or torch in, same kind out, float32 on the device."""
+    """Shared input/output plumbing: numpy or torch in, same kind out; on the device the requested dtype."""
 
     def _init_boundary(self, psf, dtype="float32"):
         self.is_torch = isinstance(psf, torch.Tensor)
