@@ -98,10 +98,10 @@ struct lpc_engine {
   // work spectra: [2][P] planes (ADMM uses both halves, others the first)
   real2* S = nullptr;
   // ADMM state (padded real planes)
-  real *V[2] = {nullptr, nullptr}, *HV = nullptr, *X = nullptr, *xi = nullptr, *rho = nullptr,
+  real *V[2] = {nullptr, nullptr}, *HVb[2] = {nullptr, nullptr}, *xi = nullptr, *rho = nullptr,
         *Rsp = nullptr, *Aarr = nullptr;
   real *eta0[2] = {nullptr, nullptr}, *eta1[2] = {nullptr, nullptr};  // ping-pong (halo reads)
-  int vcur = 0, ecur = 0;
+  int vcur = 0, ecur = 0, hcur = 0;  // HVb[hcur] = H V of the current estimate, HVb[hcur^1] = of the previous one
   // the reference clamps the image estimate IN PLACE whenever _form_image runs (admm.py:331-338);
   // only the W-update ever sees that clamped copy: Vw[0] = V as seen by the next iteration's W,
   // Vw[1] = V as seen by the previous iteration's W (needed to recompute W_old).  Null = same as V.
@@ -511,13 +511,15 @@ static AdmmScalars admm_scalars(const Engine* e, const double cur[4]) {
   const double* prev = e->first ? cur : e->last_par;
   p.mu1p = (real)prev[0]; p.mu2p = (real)prev[1]; p.mu3p = (real)prev[2];
   p.thrp = (real)(prev[3] / prev[1]);
+  p.m_in_p = (real)1.0 / ((real)1.0 + p.mu1p);
+  p.m_out_p = (real)1.0 / ((real)0.0 + p.mu1p);
   return p;
 }
 
 static int admm_alloc(Engine* e) {
   const PlaneGeom& g = e->g;
   const size_t rp = (size_t)g.rplane * e->P;
-  real** bufs[] = {&e->V[0], &e->V[1], &e->HV, &e->X, &e->xi, &e->eta0[0], &e->eta0[1], &e->eta1[0],
+  real** bufs[] = {&e->V[0], &e->V[1], &e->HVb[0], &e->HVb[1], &e->xi, &e->eta0[0], &e->eta0[1], &e->eta1[0],
                     &e->eta1[1], &e->rho, &e->Rsp, &e->Aarr};
   for (real** b : bufs) LPC_OK(dev_alloc(e, b, rp));
   LPC_OK(dev_alloc(e, &e->Gabs, (size_t)g.cplane));
@@ -549,15 +551,16 @@ static int admm_setup_constants(Engine* e) {
 static int admm_reset(Engine* e) {
   const PlaneGeom& g = e->g;
   const size_t rb = (size_t)g.rplane * e->P * sizeof(real);
-  real* zero[] = {e->V[1], e->X, e->xi, e->eta0[0], e->eta1[0], e->rho, e->HV};
+  real* zero[] = {e->V[1], e->HVb[0], e->HVb[1], e->xi, e->eta0[0], e->eta1[0], e->rho};
   for (real* z : zero) LPC_RT(rt::memset_async(z, 0, rb, e->stream));
   e->vcur = 0;
   e->ecur = 0;
+  e->hcur = 0;
   e->vw_cur = e->vw_old = false;
   if (e->has_init) {
     LPC_RT(rt::copy_d2d_async(e->V[0], e->init_est, rb, e->stream));
     // admm.py:172-176: forward_out = convolve(V0)
-    LPC_OK(convolve_planar(e, e->V[0], e->HV, e->P, true, false));
+    LPC_OK(convolve_planar(e, e->V[0], e->HVb[0], e->P, true, false));
   } else {
     LPC_RT(rt::memset_async(e->V[0], 0, rb, e->stream));
   }
@@ -596,14 +599,14 @@ static int admm_iterate(Engine* e, int n_iter) {
 #ifndef LPC_DOUBLE
     if (vec4)
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT>, k1_grid4, NT, k1_smem4, g, sc, (const real*)Vc,
-                      (const real*)Vo, (const real*)e->HV, e->X, e->xi, (const real*)e->eta0[e->ecur],
+                      (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
                       (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
                       (const real*)e->Y, e->Rsp, e->Aarr, tiles_x4,
                       (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
     else
 #endif
     LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial<TH, TW, NT>, k1_grid, NT, k1_smem, g, sc, (const real*)Vc,
-                    (const real*)Vo, (const real*)e->HV, e->X, e->xi, (const real*)e->eta0[e->ecur],
+                    (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
                     (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
                     (const real*)e->Y, e->Rsp, e->Aarr, tiles_x,
                     (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
@@ -636,9 +639,10 @@ static int admm_iterate(Engine* e, int n_iter) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
       constexpr bool sk = decltype(SK)::value;
       return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em, sk>, dim3(g.Hp, e->P), nt,
-                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const real2*)SA, (const real2*)SB, Vo, e->HV);
+                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const real2*)SA, (const real2*)SB, Vo, e->HVb[e->hcur ^ 1]);
     }));
     e->vcur ^= 1;  // Vo now holds the new image estimate
+    e->hcur ^= 1;  // ... and the other H V buffer its forward model
     for (int k = 0; k < 4; ++k) e->last_par[k] = par[k];
     ++e->iters_done;
   }
@@ -883,24 +887,24 @@ int lpc_get_state(lpc_handle e, const char* name, real* dev_out, void* stream) {
     return planar_to_hwc(e, src, dev_out, nimg, g.Hp, g.Wp, g.rpitch, g.rplane, 0, 0, 0);
   };
   if (nm == "image_est") return out_padded(e->vw_cur ? e->Vw[0] : e->V[e->vcur]);
-  if (nm == "forward_out") return out_padded(e->HV);
-  if (nm == "X") return out_padded(e->X);
+  if (nm == "forward_out") return out_padded(e->HVb[e->hcur]);
   // the rest needs the pending dual update applied: materialise into scratch
   const long ostride = (long)g.rplane * e->P;
   real* scratch = nullptr;
-  LPC_RT(rt::dev_malloc((void**)&scratch, (size_t)ostride * 7 * sizeof(real)));
+  LPC_RT(rt::dev_malloc((void**)&scratch, (size_t)ostride * 8 * sizeof(real)));
   double par[4];
   admm_params(e, e->iters_done, par);
   AdmmScalars sc = admm_scalars(e, par);
   int rc = launch_k(e, -1, k_admm_flush<256>, grid1d((long)g.Hp * g.Wp, 256, e->P), 256, 0, g, sc,
-                    (const real*)e->V[e->vcur], (const real*)e->V[e->vcur ^ 1], (const real*)e->HV,
-                    (const real*)e->X, (const real*)e->xi, (const real*)e->eta0[e->ecur],
+                    (const real*)e->V[e->vcur], (const real*)e->V[e->vcur ^ 1], (const real*)e->HVb[e->hcur],
+                    (const real*)e->HVb[e->hcur ^ 1], (const real*)e->Y, (const real*)e->xi, (const real*)e->eta0[e->ecur],
                     (const real*)e->eta1[e->ecur], (const real*)e->rho, scratch, ostride,
                     (const real*)(e->vw_old ? e->Vw[1] : nullptr));
   if (!rc) {
     if (nm == "xi") rc = out_padded(scratch + 0 * ostride);
     else if (nm == "rho") rc = out_padded(scratch + 3 * ostride);
     else if (nm == "W") rc = out_padded(scratch + 6 * ostride);
+    else if (nm == "X") rc = out_padded(scratch + 7 * ostride);
     else if (nm == "eta" || nm == "U") {
       real* a = scratch + (nm == "eta" ? 1 : 4) * ostride;
       const long n = (long)g.Hp * g.Wp * e->cfg.channels;
@@ -952,7 +956,8 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
   double b = 0.0;
   if (e->cfg.algo == LPC_ALGO_ADMM) {
     switch (kid) {
-      case LPC_K_SPATIAL: b = 15.0 * R + R0; break;            // reads 8R+R0, writes 7R
+      case LPC_K_SPATIAL: b = 15.0 * R + R0; break;  // SURVEY 8(d) figure (reads 8R+R0, writes 7R); the kernel itself
+                                                     // moves 14R + R0: X is recomputed instead of stored
       case LPC_K_ROW_FWD: b = 2.0 * R + 2.0 * S; break;
       case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
       case LPC_K_COL_MID: b = 4.0 * S + Sc + 4.0 * g.Hp * g.Wc; break;  // + H (complex) + |G| (real, one plane)

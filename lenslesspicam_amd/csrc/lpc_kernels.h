@@ -412,6 +412,7 @@ struct AdmmScalars {
   // the PREVIOUS iteration's values: its dual updates are still pending and its U, W are recomputed.
   // Equal to the current ones for plain ADMM; differ for unrolled ADMM (unrolled_admm.py:171-211)
   real mu1p, mu2p, mu3p, thrp;
+  real m_in_p, m_out_p;  // X_divmat of the previous iteration (its X is recomputed, never stored)
 };
 
 static __device__ __forceinline__ real soft_thresh_dev(real a, real thr) {
@@ -424,7 +425,7 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
                                                       const real* LPC_RESTRICT V,
                                                       const real* LPC_RESTRICT Vold,
                                                       const real* LPC_RESTRICT HV,
-                                                      real* LPC_RESTRICT X, real* LPC_RESTRICT xi,
+                                                      const real* LPC_RESTRICT HVold, real* LPC_RESTRICT xi,
                                                       const real* LPC_RESTRICT eta0,
                                                       const real* LPC_RESTRICT eta1,
                                                       real* LPC_RESTRICT eta0_out,
@@ -515,21 +516,21 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
     const real vc = sV[li];
     const real hv = HV[o];
     real xiv = xi[o], rhov = rho[o];
+    const bool inside = (gr >= g.sh) && (gr < g.sh + g.H) && (gc >= g.sw) && (gc < g.sw + g.W);
+    const real yv = inside ? y[(long)(gr - g.sh) * g.W + (gc - g.sw)] : (real)0;
     if (!p.first) {
-      const real xo = X[o];
+      // X of the previous iteration, recomputed bit-for-bit from what it was computed from (admm.py:252-254)
+      const real xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * HVold[o] + yv);
       xiv = xiv + p.mu1p * (hv - xo);
-      const real wo = rmax(rhov / p.mu3p + (VWo ? VWo[o] : sO[li]), (real)0.);
+      const real wo = rmax(rhov / p.mu3p + (VWo ? VWo[o] : sO[li]), (real)0);
       rhov = rhov + p.mu3p * (vc - wo);
     }
-    const bool inside = (gr >= g.sh) && (gr < g.sh + g.H) && (gc >= g.sw) && (gc < g.sw + g.W);
-    const real yv = inside ? y[(long)(gr - g.sh) * g.W + (gc - g.sw)] : (real)0.;
     const real xn = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
-    const real wn = rmax(rhov / p.mu3 + (VWc ? VWc[o] : vc), (real)0.);
+    const real wn = rmax(rhov / p.mu3 + (VWc ? VWc[o] : vc), (real)0);
     const real d1 = sQ0[(ly + 1) * TW + lx] - sQ0[ly * TW + lx];
     const real d2 = sQ1[ly * (TW + 1) + lx + 1] - sQ1[ly * (TW + 1) + lx];
     xi[o] = xiv;
     rho[o] = rhov;
-    X[o] = xn;
     Rsp[o] = (p.mu3 * wn - rhov) + (d1 + d2);
     Aout[o] = p.mu1 * xn - xiv;
   }
@@ -563,7 +564,7 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
                                                          const float* LPC_RESTRICT V,
                                                          const float* LPC_RESTRICT Vold,
                                                          const float* LPC_RESTRICT HV,
-                                                         float* LPC_RESTRICT X, float* LPC_RESTRICT xi,
+                                                         const float* LPC_RESTRICT HVold, float* LPC_RESTRICT xi,
                                                          const float* LPC_RESTRICT eta0,
                                                          const float* LPC_RESTRICT eta1,
                                                          float* LPC_RESTRICT eta0_out,
@@ -622,8 +623,8 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
     const float4 hv4 = ld4(HV + o), xi4 = ld4(xi + o), rho4 = ld4(rho + o);
     const float4 e04 = ld4(eta0 + o), e14 = ld4(eta1 + o), e0d4 = ld4(eta0 + o_dn);
     const float e1r = eta1[o_rt];
-    float4 xo4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!p.first) xo4 = ld4(X + o);
+    float4 ho4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (!p.first) ho4 = ld4(HVold + o);      // previous H V: lets the previous X be recomputed instead of stored
     // the image estimate as the W-update sees it: differs from V only for the two iterations that follow
     // an in-place clamp by _form_image (admm.py:331-338), see lpc_form_image
     float4 vwc4 = make_float4(0.f, 0.f, 0.f, 0.f), vwo4 = vwc4;
@@ -645,14 +646,14 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
     const float vms[4] = {vm4.x, vm4.y, vm4.z, vm4.w}, vps[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
     const float oms[4] = {om4.x, om4.y, om4.z, om4.w}, ops[4] = {op4.x, op4.y, op4.z, op4.w};
     const float hvs[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, xis[4] = {xi4.x, xi4.y, xi4.z, xi4.w};
-    const float rhs[4] = {rho4.x, rho4.y, rho4.z, rho4.w}, xos[4] = {xo4.x, xo4.y, xo4.z, xo4.w};
+    const float rhs[4] = {rho4.x, rho4.y, rho4.z, rho4.w}, hos[4] = {ho4.x, ho4.y, ho4.z, ho4.w};
     const float e0s[4] = {e04.x, e04.y, e04.z, e04.w}, e0ds[4] = {e0d4.x, e0d4.y, e0d4.z, e0d4.w};
     const float e1s[5] = {e14.x, e14.y, e14.z, e14.w, e1r};
     float q1[5], e1n[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i)   // column-difference component at cols gc .. gc+4 (the 5th only for q)
       tv_component(p, vcs[i + 1], vcs[i], ocs[i + 1], ocs[i], e1s[i], e1n[i], q1[i]);
-    float xin[4], e0n[4], rhn[4], xn[4], rs[4], as[4];
+    float xin[4], e0n[4], rhn[4], rs[4], as[4];
     const bool row_in = (gr >= g.sh) && (gr < g.sh + g.H);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -661,25 +662,25 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
       tv_component(p, vps[i], vcs[i + 1], ops[i], ocs[i + 1], e0ds[i], dummy, q0d);   // the pixel below
       const float vc = vcs[i + 1], hv = hvs[i];
       float xiv = xis[i], rhov = rhs[i];
-      if (!p.first) {
-        xiv = xiv + p.mu1p * (hv - xos[i]);
-        const float wo = fmaxf(rhov / p.mu3p + (VWo ? vwos[i] : ocs[i + 1]), 0.f);
-        rhov = rhov + p.mu3p * (vc - wo);
-      }
       const int cc = gc + i;
       const bool inside = row_in && (cc >= g.sw) && (cc < g.sw + g.W);
       const float yv = inside ? y[(long)(gr - g.sh) * g.W + (cc - g.sw)] : 0.f;
+      if (!p.first) {
+        const float xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
+        xiv = xiv + p.mu1p * (hv - xo);
+        const float wo = fmaxf(rhov / p.mu3p + (VWo ? vwos[i] : ocs[i + 1]), 0.f);
+        rhov = rhov + p.mu3p * (vc - wo);
+      }
       const float xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
       const float wn = fmaxf(rhov / p.mu3 + (VWc ? vwcs[i] : vc), 0.f);
       const float d1 = q0d - q0c;
       const float d2 = q1[i + 1] - q1[i];
-      xin[i] = xiv; rhn[i] = rhov; xn[i] = xnew;
+      xin[i] = xiv; rhn[i] = rhov;
       rs[i] = (p.mu3 * wn - rhov) + (d1 + d2);
       as[i] = p.mu1 * xnew - xiv;
     }
     st4(xi + o, make_float4(xin[0], xin[1], xin[2], xin[3]));
     st4(rho + o, make_float4(rhn[0], rhn[1], rhn[2], rhn[3]));
-    st4(X + o, make_float4(xn[0], xn[1], xn[2], xn[3]));
     st4(eta0_out + o, make_float4(e0n[0], e0n[1], e0n[2], e0n[3]));
     st4(eta1_out + o, make_float4(e1n[0], e1n[1], e1n[2], e1n[3]));
     st4(Rsp + o, make_float4(rs[0], rs[1], rs[2], rs[3]));
@@ -695,13 +696,14 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
                                                     const real* LPC_RESTRICT V,
                                                     const real* LPC_RESTRICT Vold,
                                                     const real* LPC_RESTRICT HV,
-                                                    const real* LPC_RESTRICT X,
+                                                    const real* LPC_RESTRICT HVold,
+                                                    const real* LPC_RESTRICT Y,
                                                     const real* LPC_RESTRICT xi,
                                                     const real* LPC_RESTRICT eta0,
                                                     const real* LPC_RESTRICT eta1,
                                                     const real* LPC_RESTRICT rho, real* LPC_RESTRICT out,
                                                     long ostride, const real* LPC_RESTRICT VWo) {
-  // out planes of size ostride*: 0 xi', 1 eta0', 2 eta1', 3 rho', 4 U0, 5 U1, 6 W
+  // out planes of size ostride*: 0 xi', 1 eta0', 2 eta1', 3 rho', 4 U0, 5 U1, 6 W, 7 X
   const long n = (long)g.Hp * g.Wp;
   const long pl = blockIdx.y;
   for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
@@ -710,13 +712,17 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
     const long ou = pl * g.rplane + (long)wrap_add(r, -1, g.Hp) * g.rpitch + c;
     const long ol = pl * g.rplane + (long)r * g.rpitch + wrap_add(c, -1, g.Wp);
     real xiv = xi[o], e0 = eta0[o], e1 = eta1[o], rh = rho[o];
-    real u0 = (real)0., u1 = (real)0., w = (real)0.;
+    real u0 = (real)0., u1 = (real)0., w = (real)0., x = (real)0.;
     if (!p.first) {
+      const bool inside = (r >= g.sh) && (r < g.sh + g.H) && (c >= g.sw) && (c < g.sw + g.W);
+      const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
+      const real yv = inside ? Y[(long)dpl * g.uplane + (long)(r - g.sh) * g.W + (c - g.sw)] : (real)0.;
+      x = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * HVold[o] + yv);   // X of the last iteration
       const real oc = Vold[o], vc = V[o];
       u0 = soft_thresh_dev((Vold[ou] - oc) + e0 / p.mu2p, p.thrp);
       u1 = soft_thresh_dev((Vold[ol] - oc) + e1 / p.mu2p, p.thrp);
       w = rmax(rh / p.mu3p + (VWo ? VWo[o] : oc), (real)0.);
-      xiv = xiv + p.mu1p * (HV[o] - X[o]);
+      xiv = xiv + p.mu1p * (HV[o] - x);
       e0 = e0 + p.mu2p * ((V[ou] - vc) - u0);
       e1 = e1 + p.mu2p * ((V[ol] - vc) - u1);
       rh = rh + p.mu3p * (vc - w);
@@ -728,6 +734,7 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
     out[4 * ostride + o] = u0;
     out[5 * ostride + o] = u1;
     out[6 * ostride + o] = w;
+    out[7 * ostride + o] = x;
   }
 }
 
