@@ -59,12 +59,15 @@ static int dispatch_cfg(int nelem, F&& f) {
               std::to_string(kMaxTilePoints) + ")");
 }
 
-// row kernels: (NT, EMAX) by row length, plus the LDS-skew flag of the plan
+// row kernels: (NT, EMAX) by row length, the LDS-skew flag and the radix-2-folding flag of the plan
 template <class F>
-static int dispatch_row(int Wp, int skew, F&& f) {
+static int dispatch_row(int Wp, int skew, bool r2, F&& f) {
+  using std::integral_constant;
   return dispatch_cfg(Wp, [&](auto NT, auto EM) {
-    if (skew) return f(NT, EM, std::integral_constant<bool, true>{});
-    return f(NT, EM, std::integral_constant<bool, false>{});
+    if (skew && r2) return f(NT, EM, integral_constant<bool, true>{}, integral_constant<bool, true>{});
+    if (skew) return f(NT, EM, integral_constant<bool, true>{}, integral_constant<bool, false>{});
+    if (r2) return f(NT, EM, integral_constant<bool, false>{}, integral_constant<bool, true>{});
+    return f(NT, EM, integral_constant<bool, false>{}, integral_constant<bool, false>{});
   });
 }
 
@@ -82,6 +85,8 @@ struct lpc_engine {
   int N1 = 1, N2 = 1;  // column split Hp = N1*N2 (N1 == 1: single pass)
   int T = 16;          // image columns per column-pass tile
   Fft1dPlan planW{}, planA{}, planB{};
+  Fft1dPlan planWi{};   // inverse-row plan with the radix-2 stage FIRST (rows_r2 only)
+  bool rows_r2 = false; // row plans end in a radix-2 stage: fold it into the Hermitian (un)tangling
   ColPass passA{}, passB{};
   int P = 0, Ppsf = 0, Pdata = 0;
   std::vector<void*> allocs;
@@ -198,6 +203,33 @@ static int make_twiddles(Engine* e, int n, real2** out) {
   return upload(e, *out, h.data(), h.size() * sizeof(real2));
 }
 
+static int plan_from_radices(Engine* e, Fft1dPlan& p, int n, const std::vector<int>& rad) {
+  p.n = n;
+  p.nst = 0;
+  if ((int)rad.size() > LPC_MAX_STAGES) return fail("too many FFT stages");
+  int ns = 1;
+  for (size_t s = 0; s < rad.size(); ++s) {
+    p.radix[s] = rad[s];
+    p.ns[s] = ns;
+    p.nsdiv[s] = make_fastdiv((unsigned)ns);
+    p.twstep[s] = n / (ns * rad[s]);
+    ns *= rad[s];
+  }
+  if (ns != n) return fail("internal: radices do not multiply to the length");
+  p.nst = (int)rad.size();
+  p.skew_ok = 1;  // see lpc_fft.h: every butterfly stride must be a multiple of 8
+  for (int st = 0; st < p.nst; ++st) {
+    const int nb = n / p.radix[st];
+    if (nb % 8 != 0) p.skew_ok = 0;
+    if (!(p.ns[st] % 8 == 0 || (p.ns[st] == 1 && p.radix[st] % 8 == 0))) p.skew_ok = 0;
+  }
+  if (std::getenv("LPC_NO_SKEW")) p.skew_ok = 0;
+  real2* tw = nullptr;
+  LPC_OK(make_twiddles(e, n, &tw));
+  p.tw = tw;
+  return 0;
+}
+
 static int build_plan(Engine* e, Fft1dPlan& p, int n) {
   p.n = n;
   p.nst = 0;
@@ -239,27 +271,7 @@ static int build_plan(Engine* e, Fft1dPlan& p, int n) {
   while (r % 5 == 0) { r /= 5; rad.push_back(5); }
   for (int i = 0; i < b3; ++i) rad.push_back(3);
   if (r != 1) return fail("length " + std::to_string(n) + " is not 5-smooth");
-  if ((int)rad.size() > LPC_MAX_STAGES) return fail("too many FFT stages");
-  int ns = 1;
-  for (size_t s = 0; s < rad.size(); ++s) {
-    p.radix[s] = rad[s];
-    p.ns[s] = ns;
-    p.nsdiv[s] = make_fastdiv((unsigned)ns);
-    p.twstep[s] = n / (ns * rad[s]);
-    ns *= rad[s];
-  }
-  p.nst = (int)rad.size();
-  p.skew_ok = 1;  // see lpc_fft.h: every butterfly stride must be a multiple of 8
-  for (int st = 0; st < p.nst; ++st) {
-    const int nb = n / p.radix[st];
-    if (nb % 8 != 0) p.skew_ok = 0;
-    if (!(p.ns[st] % 8 == 0 || (p.ns[st] == 1 && p.radix[st] % 8 == 0))) p.skew_ok = 0;
-  }
-  if (std::getenv("LPC_NO_SKEW")) p.skew_ok = 0;
-  real2* tw = nullptr;
-  LPC_OK(make_twiddles(e, n, &tw));
-  p.tw = tw;
-  return 0;
+  return plan_from_radices(e, p, n, rad);
 }
 
 // choose the column split Hp = N1*N2 and the tile width
@@ -310,6 +322,13 @@ static int setup_geometry(Engine* e) {
     return fail("padded width " + std::to_string(g.Wp) + " > " + std::to_string(kMaxTilePoints) + " is not supported");
   choose_split(g.Hp, g.Wc, &e->N1, &e->N2, &e->T);
   LPC_OK(build_plan(e, e->planW, g.Wp));
+  e->rows_r2 = e->planW.nst >= 2 && e->planW.radix[e->planW.nst - 1] == 2 && !std::getenv("LPC_NO_R2");
+  if (e->rows_r2) {
+    std::vector<int> rad{2};
+    for (int st = 0; st + 1 < e->planW.nst; ++st) rad.push_back(e->planW.radix[st]);
+    LPC_OK(plan_from_radices(e, e->planWi, g.Wp, rad));
+    e->planWi.skew_ok = 0;
+  }
   LPC_OK(build_plan(e, e->planB, e->N2));
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
@@ -344,10 +363,10 @@ static int setup_geometry(Engine* e) {
 static int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
   const int nblk = (src.nrows + 1) / 2;
-  return dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NT, auto EM, auto SK) {
+  return dispatch_row(g.Wp, e->planW.skew_ok, e->rows_r2, [&](auto NT, auto EM, auto SK, auto R2) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    constexpr bool sk = decltype(SK)::value;
-    return launch_k(e, kid, k_rfwd_rows<nt, em, sk>, dim3(nblk, nplanes), nt, LPC_ROW_SMEM_BYTES(g.Wp, sk), g,
+    constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
+    return launch_k(e, kid, k_rfwd_rows<nt, em, sk, r2>, dim3(nblk, nplanes), nt, LPC_ROW_SMEM_BYTES(g.Wp, sk), g,
                     e->planW, src, S);
   });
 }
@@ -424,11 +443,12 @@ static int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, 
 static int rows_inv_single(Engine* e, const real2* S, const RealDst& dst, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
   const int nblk = (dst.nrows + 1) / 2;
-  return dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NT, auto EM, auto SK) {
+  const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
+  return dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NT, auto EM, auto SK, auto R2) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    constexpr bool sk = decltype(SK)::value;
-    return launch_k(e, kid, k_rinv_rows<nt, em, sk>, dim3(nblk, nplanes), nt, LPC_ROW_SMEM_BYTES(g.Wp, sk), g,
-                    e->planW, S, dst);
+    constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
+    return launch_k(e, kid, k_rinv_rows<nt, em, sk, r2>, dim3(nblk, nplanes), nt, LPC_ROW_SMEM_BYTES(g.Wp, sk), g,
+                    pinv, S, dst);
   });
 }
 
@@ -615,10 +635,10 @@ static int admm_iterate(Engine* e, int n_iter) {
     e->vw_cur = false;
     e->ecur ^= 1;
     e->first = false;
-    LPC_OK(dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NTc, auto EM, auto SK) {
+    LPC_OK(dispatch_row(g.Wp, e->planW.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
-      constexpr bool sk = decltype(SK)::value;
-      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<nt, em, sk>, dim3(g.Hp, e->P), nt,
+      constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
+      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<nt, em, sk, r2>, dim3(g.Hp, e->P), nt,
                       LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
     }));
     if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, false, 0, g.Hp, LPC_K_COL_A_FWD));
@@ -635,11 +655,12 @@ static int admm_iterate(Engine* e, int n_iter) {
       }));
     }
     if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, true, 0, g.Hp, LPC_K_COL_A_INV));
-    LPC_OK(dispatch_row(g.Wp, e->planW.skew_ok, [&](auto NTc, auto EM, auto SK) {
+    const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
+    LPC_OK(dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
-      constexpr bool sk = decltype(SK)::value;
-      return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em, sk>, dim3(g.Hp, e->P), nt,
-                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const real2*)SA, (const real2*)SB, Vo, e->HVb[e->hcur ^ 1]);
+      constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
+      return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em, sk, r2>, dim3(g.Hp, e->P), nt,
+                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, pinv, (const real2*)SA, (const real2*)SB, Vo, e->HVb[e->hcur ^ 1]);
     }));
     e->vcur ^= 1;  // Vo now holds the new image estimate
     e->hcur ^= 1;  // ... and the other H V buffer its forward model

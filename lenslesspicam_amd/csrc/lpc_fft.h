@@ -395,10 +395,13 @@ struct NoFix {
 // FUSEL: fuse the last stage into the drain (fft_last_stage_fused); same per-call-site rule.
 template <int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, bool FUSE1 = false, bool FUSEL = false, class Src,
           class Dst, class Fix = NoFix>
+// skip_first / skip_last: the caller has fused that many stages at the front / back itself (row kernels
+// fold a radix-2 stage into the Hermitian tangling): only stages [skip_first, nst - skip_last) run here.
 static __device__ __forceinline__ void fft_tile(real2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
-                                                 int tid, Src src, Dst dst, Fix fix = Fix()) {
+                                                 int tid, Src src, Dst dst, Fix fix = Fix(), int skip_first = 0,
+                                                 int skip_last = 0) {
   const int nelem = p.n * BT;
-  int first_stage = 0;
+  int first_stage = skip_first;
   if constexpr (FUSE1 && !std::is_same<Src, LdsNatural>::value) {
     if (p.nst >= 1) {
 #define LPC_FUSED(R) fft_first_stage_fused<R, NT, EMAX, INV, SKEW, SRC_LDS>(s, p.n, BT, btdiv, tid, src, fix)
@@ -441,7 +444,7 @@ static __device__ __forceinline__ void fft_tile(real2* s, const Fft1dPlan& p, in
     __syncthreads();
   }
   if constexpr (FUSEL && !std::is_same<Dst, LdsNatural>::value) {
-    if (p.nst - first_stage >= 1) {
+    if (p.nst - first_stage >= 1 && skip_last == 0) {
       lds_fft<NT, EMAX, INV, SKEW>(s, p, BT, btdiv, tid, first_stage, 1);
       const int st = p.nst - 1;
 #define LPC_FUSEDL(R) \
@@ -458,7 +461,7 @@ static __device__ __forceinline__ void fft_tile(real2* s, const Fft1dPlan& p, in
       return;
     }
   }
-  lds_fft<NT, EMAX, INV, SKEW>(s, p, BT, btdiv, tid, first_stage);
+  lds_fft<NT, EMAX, INV, SKEW>(s, p, BT, btdiv, tid, first_stage, skip_last);
   if constexpr (!std::is_same<Dst, LdsNatural>::value) {
 #pragma unroll
     for (int k = 0; k < EMAX; ++k) {

@@ -14,8 +14,10 @@
 #include "lpc_kernels.h"
 
 // ---- inverse rows -> residual -> forward rows, all inside the workgroup -------------------------
-template <int NT, int EMAX, bool SK>
-__global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan,
+// R2: plan_inv is the inverse-row plan with the radix-2 stage first (fused into the tangling, un-skewed
+// tile); the forward transform keeps the skewed tile (SK) and folds its last radix-2 stage into the untangling.
+template <int NT, int EMAX, bool SK, bool R2>
+__global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan, Fft1dPlan plan_inv,
                                                      const real2* LPC_RESTRICT Sin,
                                                      real2* LPC_RESTRICT Sout,
                                                      const real* LPC_RESTRICT Y) {
@@ -29,9 +31,12 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan,
   const int sr0 = wrap_add(g.sh + u0, hh, g.Hp);
   const int sr1 = wrap_add(g.sh + (v1 ? u1 : u0), hh, g.Hp);
   const real2* sp = Sin + pl * g.cplane;
-  tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
+  constexpr bool SKI = R2 ? false : SK;    // tile layout of the inverse transform's result
+  if (R2) tangle_r2_load<NT>(s, g.Wp, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
+  else tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
   __syncthreads();
-  fft_tile<NT, EMAX, true, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
+  fft_tile<NT, EMAX, true, SKI, true>(s, R2 ? plan_inv : plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{},
+                                      NoFix{}, R2 ? 1 : 0, 0);
   // residual, re-padded: sample i of the new row = (i in window) ? conv[(i + Wp/2) mod Wp] - y[i - sw] : 0,
   // evaluated on the fly as the source of the forward transform's first stage
   const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
@@ -40,12 +45,14 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan,
   auto resid = [&](int i, int) {
     const int c = i - g.sw;
     if (c < 0 || c >= g.W) return make_real2((real)0., (real)0.);
-    const real2 z = s[lds_slot<SK>(wrap_add(i, hw, g.Wp))];
+    const real2 z = s[lds_slot<SKI>(wrap_add(i, hw, g.Wp))];
     return make_real2(z.x - y0[c], v1 ? z.y - y1[c] : (real)0.);
   };
-  fft_tile<NT, EMAX, false, SK, true, true>(s, plan, 1, make_fastdiv_dev1(), tid, resid, LdsNatural{});
+  fft_tile<NT, EMAX, false, SK, true, true>(s, plan, 1, make_fastdiv_dev1(), tid, resid, LdsNatural{}, NoFix{}, 0,
+                                            R2 ? 1 : 0);
   real2* o = Sout + pl * g.cplane + (long)(g.sh + u0) * g.cpitch;
-  untangle_store<NT, SK>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
+  if (R2) untangle_r2_store<NT, SK>(s, g.Wp, plan.tw, o, o + g.cpitch, v1, tid);
+  else untangle_store<NT, SK>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
 }
 
 // ---- inverse rows -> gradient -> fused update --------------------------------------------
@@ -78,7 +85,7 @@ static __device__ __forceinline__ void gd_update_one(real* LPC_RESTRICT X, real*
   }
 }
 
-template <int NT, int EMAX, bool SK>
+template <int NT, int EMAX, bool SK, bool R2>
 __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan plan,
                                                         const real2* LPC_RESTRICT Sin,
                                                         real* LPC_RESTRICT X, real* LPC_RESTRICT AUX,
@@ -93,7 +100,8 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan pl
   const int sr0 = wrap_add(g.sh + u0, hh, g.Hp);
   const int sr1 = wrap_add(g.sh + (v1 ? u1 : u0), hh, g.Hp);
   const real2* sp = Sin + pl * g.cplane;
-  tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
+  if (R2) tangle_r2_load<NT>(s, g.Wp, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
+  else tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
   __syncthreads();
   const real al = alpha[pl % g.C];
   const long base = pl * g.uplane + (long)u0 * g.W;
@@ -105,7 +113,8 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan pl
       if (v1) gd_update_one(X, AUX, base + g.W + c, z.y, al, p);
     }
   };
-  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, upd);
+  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, upd, NoFix{},
+                                                  R2 ? 1 : 0, 0);
 }
 
 // ---- reductions (set-up only): per-plane max/min with wavefront shuffles ---------------------

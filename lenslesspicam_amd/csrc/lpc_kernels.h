@@ -87,8 +87,74 @@ static __device__ __forceinline__ void tangle_load(real2* s, int Wp, int Wc, con
   }
 }
 
+// Radix-2 stage folded into the Hermitian (un)tangling (row lengths whose plan ends in a radix-2 stage,
+// e.g. 8192 = 8*8*8*8*2).  With nb = Wp/2, the lane that owns butterflies j and nb-j of that stage holds
+// Z[j], Z[nb+j], Z[nb-j], Z[Wp-j] -- exactly what the (un)tangling of bins j and nb-j needs -- so the stage
+// never makes its own trip through LDS.
+//
+// forward: s[] holds the tile BEFORE the last (radix-2, ns = nb) stage; writes A[k], B[k], k in [0, nb]
+template <int NT, bool SK>
+static __device__ __forceinline__ void untangle_r2_store(const real2* s, int Wp, const real2* LPC_RESTRICT tw,
+                                                          real2* outA, real2* outB, bool validB, int tid) {
+  const int nb = Wp >> 1;
+  auto emit = [&](int k, real2 zk, real2 zn) {     // zk = Z[k], zn = Z[Wp - k]
+    outA[k] = make_real2((real)0.5 * (zk.x + zn.x), (real)0.5 * (zk.y - zn.y));
+    if (validB) outB[k] = make_real2((real)0.5 * (zk.y + zn.y), (real)-0.5 * (zk.x - zn.x));
+  };
+  for (int j = tid; j <= nb / 2; j += NT) {
+    const int jm = nb - j;                          // mirror butterfly (== nb for j == 0: no such butterfly)
+    const real2 u0 = s[lds_slot<SK>(j)];
+    const real2 v0 = j ? cmul(s[lds_slot<SK>(j + nb)], tw[j]) : s[lds_slot<SK>(nb)];
+    const real2 zj = cadd(u0, v0), zjn = csub(u0, v0);            // Z[j], Z[j + nb]
+    if (j == 0) {
+      emit(0, zj, zj);                                           // DC pairs with itself
+      emit(nb, zjn, zjn);                                        // so does the Nyquist bin
+    } else if (j == jm) {
+      emit(j, zj, zjn);                                          // Wp - j == j + nb
+    } else {
+      const real2 u1 = s[lds_slot<SK>(jm)];
+      const real2 v1 = cmul(s[lds_slot<SK>(jm + nb)], tw[jm]);
+      const real2 zm = cadd(u1, v1), zmn = csub(u1, v1);         // Z[nb - j], Z[Wp - j]
+      emit(j, zj, zmn);
+      emit(jm, zm, zjn);                                         // Wp - (nb - j) == nb + j
+    }
+  }
+}
+
+// inverse: builds Z from the half spectra and applies the FIRST (radix-2, ns = 1, twiddle-free) stage of the
+// inverse plan: writes y[2j] = Z[j] + Z[j+nb], y[2j+1] = Z[j] - Z[j+nb] into the (un-skewed) LDS tile.
+// Every spectrum element is loaded exactly once.
+template <int NT>
+static __device__ __forceinline__ void tangle_r2_load(real2* s, int Wp, const real2* inA, const real2* inB,
+                                                       bool validB, int tid) {
+  const int nb = Wp >> 1;
+  const real2 zero = make_real2((real)0, (real)0);
+  for (int j = tid; j <= nb / 2; j += NT) {
+    const int jm = nb - j;
+    real2 a0 = inA[j], b0 = validB ? inB[j] : zero;
+    real2 a1 = inA[jm], b1 = validB ? inB[jm] : zero;               // j == 0: the Nyquist bin
+    if (j == 0) { a0.y = (real)0; b0.y = (real)0; a1.y = (real)0; b1.y = (real)0; }
+    // Z[k] = A[k] + i B[k];  Z[Wp - k] = conj(A[k]) + i conj(B[k])
+    const real2 zj = make_real2(a0.x - b0.y, a0.y + b0.x);          // Z[j]
+    const real2 zm = make_real2(a1.x - b1.y, a1.y + b1.x);          // Z[nb - j]   (j == 0: Z[nb])
+    const real2 zjn = make_real2(a1.x + b1.y, b1.x - a1.y);         // Z[j + nb]  = mirror of bin nb - j
+    const real2 zmn = make_real2(a0.x + b0.y, b0.x - a0.y);         // Z[Wp - j]  = mirror of bin j
+    if (j == 0) {
+      s[0] = cadd(zj, zm);
+      s[1] = csub(zj, zm);
+    } else {
+      s[2 * j] = cadd(zj, zjn);
+      s[2 * j + 1] = csub(zj, zjn);
+      if (j != jm) {
+        s[2 * jm] = cadd(zm, zmn);
+        s[2 * jm + 1] = csub(zm, zmn);
+      }
+    }
+  }
+}
+
 // ---- forward, ADMM: row r of array A and row r of array B -> spectra SA, SB ------------
-template <int NT, int EMAX, bool SK>
+template <int NT, int EMAX, bool SK, bool R2>
 __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
                                                      const real* LPC_RESTRICT A,
                                                      const real* LPC_RESTRICT B,
@@ -101,9 +167,12 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
   const real* a = A + pl * g.rplane + (long)row * g.rpitch;
   const real* b = B + pl * g.rplane + (long)row * g.rpitch;
   auto src = [&](int i, int) { return make_real2(a[i], b[i]); };
-  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
-  untangle_store<NT, SK>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
-                         SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
+  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{}, NoFix{}, 0,
+                                             R2 ? 1 : 0);
+  real2* oa = SA + pl * g.cplane + (long)row * g.cpitch;
+  real2* ob = SB + pl * g.cplane + (long)row * g.cpitch;
+  if (R2) untangle_r2_store<NT, SK>(s, g.Wp, plan.tw, oa, ob, true, tid);
+  else untangle_store<NT, SK>(s, g.Wp, g.Wc, oa, ob, true, tid);
 }
 
 // ---- forward, generic: rows (2b, 2b+1) of ONE real source -> spectrum rows ------------
@@ -116,7 +185,7 @@ struct RealSrc {
   int out_row0;       // source row r lands in spectrum row out_row0 + r
 };
 
-template <int NT, int EMAX, bool SK>
+template <int NT, int EMAX, bool SK, bool R2>
 __global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, RealSrc src,
                                                    real2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
@@ -132,13 +201,17 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, R
     const bool ok = (c >= 0) && (c < src.ncols);
     return make_real2(ok ? a[c] : (real)0., (ok && v1) ? b[c] : (real)0.);
   };
-  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, in, LdsNatural{});
+  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, in, LdsNatural{}, NoFix{}, 0,
+                                             R2 ? 1 : 0);
   real2* o = S + pl * g.cplane + (long)(src.out_row0 + r0) * g.cpitch;
-  untangle_store<NT, SK>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
+  if (R2) untangle_r2_store<NT, SK>(s, g.Wp, plan.tw, o, o + g.cpitch, v1, tid);
+  else untangle_store<NT, SK>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
 }
 
 // ---- inverse, ADMM: spectra SA, SB -> real arrays A, B (no shift, padded) ---------------
-template <int NT, int EMAX, bool SK>
+// R2: `plan` is the inverse-row plan whose FIRST stage is the radix-2 one (fused into the tangling); SK is
+// false in that case (the skew is not affine for ns = 2).
+template <int NT, int EMAX, bool SK, bool R2>
 __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, Fft1dPlan plan,
                                                      const real2* LPC_RESTRICT SA,
                                                      const real2* LPC_RESTRICT SB,
@@ -147,13 +220,16 @@ __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, Fft1dPlan plan,
   real2* s = (real2*)smem;
   const int tid = threadIdx.x, row = blockIdx.x;
   const long pl = blockIdx.y;
-  tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
-                            SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
+  const real2* ia = SA + pl * g.cplane + (long)row * g.cpitch;
+  const real2* ib = SB + pl * g.cplane + (long)row * g.cpitch;
+  if (R2) tangle_r2_load<NT>(s, g.Wp, ia, ib, true, tid);
+  else tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, ia, ib, true, tid);
   __syncthreads();
   real* a = A + pl * g.rplane + (long)row * g.rpitch;
   real* b = B + pl * g.rplane + (long)row * g.rpitch;
   auto out = [&](int i, int, real2 v) { a[i] = v.x; b[i] = v.y; };
-  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
+  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out, NoFix{},
+                                                  R2 ? 1 : 0, 0);
 }
 
 // ---- inverse, generic: spectrum rows -> ONE real sink with ifftshift (+ crop) -----------
@@ -177,7 +253,7 @@ static __device__ __forceinline__ int shifted_col(int i, int hw, int col0, int W
   return c;
 }
 
-template <int NT, int EMAX, bool SK>
+template <int NT, int EMAX, bool SK, bool R2>
 __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
                                                    const real2* LPC_RESTRICT S, RealDst dst) {
   LPC_DYN_SMEM(smem);
@@ -189,8 +265,10 @@ __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
   const int hh = g.Hp / 2, hw = g.Wp / 2;
   const int sr0 = wrap_add(dst.row0 + r0, hh, g.Hp);
   const int sr1 = wrap_add(dst.row0 + (v1 ? r1 : r0), hh, g.Hp);
-  tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, S + pl * g.cplane + (long)sr0 * g.cpitch,
-                            S + pl * g.cplane + (long)sr1 * g.cpitch, v1, tid);
+  if (R2) tangle_r2_load<NT>(s, g.Wp, S + pl * g.cplane + (long)sr0 * g.cpitch,
+                             S + pl * g.cplane + (long)sr1 * g.cpitch, v1, tid);
+  else tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, S + pl * g.cplane + (long)sr0 * g.cpitch,
+                                 S + pl * g.cplane + (long)sr1 * g.cpitch, v1, tid);
   __syncthreads();
   real* a = dst.base + pl * dst.plane_stride + (long)r0 * dst.pitch;
   real* b = dst.base + pl * dst.plane_stride + (long)r1 * dst.pitch;
@@ -201,7 +279,8 @@ __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
       if (v1) b[c] = v.y;
     }
   };
-  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
+  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out, NoFix{},
+                                                  R2 ? 1 : 0, 0);
 }
 
 #ifndef LPC_MID_FUSE1

@@ -244,3 +244,39 @@ def test_gd_family_matches_reference_golden(backend, name):
     out = rec.get_image_estimate()[0]
     assert out.dtype == (np.float64 if f64 else np.float32)       # test/test_algos.py:107: res.dtype == psf.dtype
     assert rel(out, g["final"]) <= (F64_TOL if f64 else 5e-5)
+
+
+@pytest.mark.parametrize("shape", [(10, 64, 3), (5, 512, 1)])
+@pytest.mark.parametrize("dtype", ["float32", "float64"])
+def test_rows_with_radix2_tail_fold_it_into_the_tangling(backend, shape, dtype):
+    """Padded widths 128 = 8*8*2 and 1024 = 8*8*8*2: the row plans end in a radix-2 stage, which
+    the row kernels fold into the Hermitian (un)tangling (untangle_r2_store / tangle_r2_load).  Checked
+    against the oracle for the operator pair, ADMM (incl. dual state) and all three GD variants."""
+    H, W, C = shape
+    tdt = torch.float32 if dtype == "float32" else torch.float64
+    tol = 5e-6 if dtype == "float32" else 1e-11
+    rng = np.random.default_rng(H * W)
+    psf = orc.synthetic_psf(1, H, W, C, seed=H + W).astype(dtype)
+    y = rng.random((H, W, C)).astype(dtype)
+    x = rng.standard_normal((2, 1, H, W, C)).astype(dtype)
+    cv = lpa.RealFFTConvolve2D(psf, dtype=dtype, pad=True)
+    oc = orc.ConvolverOracle(psf, dtype=tdt, pad=True)
+    assert cv._padded_shape[2] in (128, 1024)
+    assert rel(cv.convolve(x), oc.convolve(torch.from_numpy(x))) <= tol
+    assert rel(cv.deconvolve(x), oc.deconvolve(torch.from_numpy(x))) <= tol
+    rec = lpa.ADMM(psf, dtype=dtype, tau=2e-6, mu2=1e-4)
+    rec.set_data(y)
+    o = orc.ADMMOracle(psf, dtype=tdt, tau=2e-6, mu2=1e-4)
+    o.set_data(y)
+    got = rec.apply(n_iter=6, disp_iter=None)
+    assert got.dtype == np.dtype(dtype)
+    ref = o.apply(6)
+    assert rel(got, ref) <= 2 * tol
+    assert rel(rec._xi, o.xi) <= 40 * tol and rel(rec._X, o.X) <= 4 * tol
+    for kind, cls in (("vanilla", lpa.GradientDescent), ("nesterov", lpa.NesterovGradientDescent),
+                      ("fista", lpa.FISTA)):
+        g = cls(psf, dtype=dtype)
+        g.set_data(y)
+        og = orc.GDOracle(psf, kind=kind, dtype=tdt)
+        og.set_data(y)
+        assert rel(g.apply(n_iter=8, disp_iter=None), og.apply(8)) <= 2 * tol, kind
