@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--height", type=int, default=3040)
     ap.add_argument("--width", type=int, default=4056)
     ap.add_argument("--algo", default="admm", choices=["admm", "fista"])
+    ap.add_argument("--dtype", default="float32", choices=["float32", "float64"],
+                    help="float64 runs the second build of the engine (liblpc_f64.so); the headline metric is float32")
     ap.add_argument("--config", default="c2", choices=["c2", "c4"],
                     help="c2 (default, the headline metric): one 12-MP frame per GPU.  c4: BASELINE config 4, a "
                          "batch of 64 DiffuserCam frames (270x480x3) block-sharded over the ranks, ADMM 20 it, one "
@@ -158,16 +160,18 @@ def main():
     H, W, C, n_iter = args.height, args.width, 3, args.n_iter
     log("generating synthetic inputs")
     psf, scene, y = synth_inputs(H, W, C, rank, dev)
+    if args.dtype == "float64":
+        psf, y = psf.double(), y.double()
     torch.cuda.synchronize()
     log("inputs ready; building solver")
     if args.algo == "admm":
-        rec = lpa.ADMM(psf, n_iter=n_iter)
+        rec = lpa.ADMM(psf, dtype=args.dtype, n_iter=n_iter)
     else:
-        rec = lpa.FISTA(psf, n_iter=n_iter)
+        rec = lpa.FISTA(psf, dtype=args.dtype, n_iter=n_iter)
     rec.set_data(y)
     hp, wp = rec._padded_shape[1], rec._padded_shape[2]
 
-    gathered = [torch.empty((1, H, W, C), dtype=torch.float32, device=dev) for _ in range(world)] if dist else None
+    gathered = [torch.empty((1, H, W, C), dtype=psf.dtype, device=dev) for _ in range(world)] if dist else None
 
     def step():
         out = rec.apply(n_iter=n_iter, disp_iter=None, plot=False)
@@ -250,7 +254,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if args.dtype == "float32" else "f64",
             "data": "synthetic",
             "config": {
                 "workload": f"C2: one {H}x{W}x{C} frame per GPU, {args.algo.upper()}"
@@ -273,7 +277,7 @@ def main():
         }
 
     # ---- CPU baseline + parity: rank 0, N == 1 only --------------------------------------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.algo == "admm":
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.algo == "admm" and args.dtype == "float32":
         import psutil
 
         cores = os.cpu_count() or 1

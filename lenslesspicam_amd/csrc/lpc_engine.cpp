@@ -969,10 +969,11 @@ int lpc_profile_read(lpc_handle e, double* avg_ms, long* launches) {
 int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
   if (!e || !bytes) return fail("null argument");
   const PlaneGeom& g = e->g;
-  const double R = 4.0 * g.Hp * g.Wp * e->P;          // padded real arrays, all planes
-  const double S = 8.0 * g.Hp * g.Wc * e->P;          // half spectra
-  const double R0 = 4.0 * g.H * g.W * e->Pdata;
-  const double Sc = 8.0 * g.Hp * g.Wc * e->Ppsf;      // spectral constants
+  const double eb = (double)sizeof(real);             // 4 (liblpc) or 8 (liblpc_f64)
+  const double R = eb * g.Hp * g.Wp * e->P;           // padded real arrays, all planes
+  const double S = 2 * eb * g.Hp * g.Wc * e->P;       // half spectra
+  const double R0 = eb * g.H * g.W * e->Pdata;
+  const double Sc = 2 * eb * g.Hp * g.Wc * e->Ppsf;   // spectral constants
   const bool split = e->N1 > 1;
   double b = 0.0;
   if (e->cfg.algo == LPC_ALGO_ADMM) {
@@ -981,7 +982,7 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
                                                      // moves 14R + R0: X is recomputed instead of stored
       case LPC_K_ROW_FWD: b = 2.0 * R + 2.0 * S; break;
       case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
-      case LPC_K_COL_MID: b = 4.0 * S + Sc + 4.0 * g.Hp * g.Wc; break;  // + H (complex) + |G| (real, one plane)
+      case LPC_K_COL_MID: b = 4.0 * S + Sc + eb * g.Hp * g.Wc; break;  // + H (complex) + |G| (real, one plane)
       case LPC_K_COL_A_INV: b = split ? 4.0 * S : 0.0; break;
       case LPC_K_ROW_INV: b = 2.0 * S + 2.0 * R; break;
       default: return fail("bad kernel id");
