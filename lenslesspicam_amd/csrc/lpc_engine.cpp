@@ -293,6 +293,10 @@ static void choose_split(int Hp, int Wc, int* N1, int* N2, int* T) {
     const int cost = std::max(n1, 2 * n2);
     if (cost < bestcost) { bestcost = cost; best1 = n1; best2 = n2; }
   }
+  if (const char* env = std::getenv("LPC_SPLIT_N2")) {  // tuning knob: force the length of the fused middle transform
+    const int n2 = atoi(env);
+    if (n2 > 0 && Hp % n2 == 0 && (long)n2 * 2 * t <= budget && (long)(Hp / n2) * t <= budget) { best2 = n2; best1 = Hp / n2; }
+  }
   *N1 = best1; *N2 = best2; *T = t;
 }
 
