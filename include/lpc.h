@@ -117,6 +117,15 @@ int lpc_set_fista_schedule(lpc_handle h, int n, const lpc_real* alpha, const lpc
 /* exactly n_iter iterations, asynchronous on `stream`; no early exit exists on this path */
 int lpc_iterate(lpc_handle h, int n_iter, void* stream);
 
+/* Plug-and-play hook (gradient-descent family): ONE iteration split where the reference calls
+ * `self._form_image()` = `self._proj(self._image_est[, noise_level])` inside `_update` (gd.py:132-140,183-188,
+ * 235-241; `proj=` argument gd.py:67, external denoiser gd.py:89-92).  lpc_iterate_begin runs the fused gradient /
+ * momentum half and leaves the UNPROJECTED estimate readable as lpc_get_state("image_est"); the caller applies its
+ * projection or denoiser to that (B,D,H,W,C) array and passes the result to lpc_iterate_end, which completes the
+ * iteration (FISTA: the extrapolation and the t_k recursion).  Mixing with lpc_iterate between the two is an error. */
+int lpc_iterate_begin(lpc_handle h, void* stream);
+int lpc_iterate_end(lpc_handle h, const lpc_real* dev_projected, void* stream);
+
 /* _form_image(): ADMM crop + clamp (admm.py:331-338), GD family projection (gd.py:136-140).
  * dev_out: (B,D,H,W,C).  Like the reference, the ADMM clamp is an in-place side effect on the image
  * estimate: it is visible to the W-update of the following iterations (and to "image_est"). */
@@ -127,6 +136,48 @@ int lpc_form_image(lpc_handle h, lpc_real* dev_out, void* stream);
  * [values as the reference holds them after the same number of iterations].
  * GD family: "alpha" writes C floats. */
 int lpc_get_state(lpc_handle h, const char* name, lpc_real* dev_out, void* stream);
+
+/* ---- evaluation reductions on the device (no host synchronisation of the results) -------------- */
+/* ReconstructionAlgorithm.reconstruction_error (recon.py:607-653):
+ *   out[b] = sum_{d,h,w,c} (N(H x)[b,d] - y[b])^2 / (D*H*W*C),  N(z) = (z - min z) / max(z - min z) over (H,W,C)
+ * (N = identity when normalize == 0).  dev_pred: (B,D,H,W,C), e.g. what lpc_form_image wrote; dev_data:
+ * (B,H,W,C) or NULL = the frame given to lpc_set_data; dev_out: B values.  Works on every handle kind. */
+int lpc_reconstruction_error(lpc_handle h, const lpc_real* dev_pred, const lpc_real* dev_data, int normalize,
+                             lpc_real* dev_out, void* stream);
+/* mse() and psnr() of lensless/eval/metric.py:119-172 for n_items image pairs of n values each:
+ * dev_out[2*i] = mean((t/max t - e/max e)^2), dev_out[2*i+1] = 10 log10(R^2 / mse) with R = 1 if min t >= 0 else 2
+ * (skimage's data-range rule for float images); normalize == 0 skips the division by the maxima.
+ * Handle-free and asynchronous on `stream` (scratch comes from the device's stream-ordered memory pool). */
+int lpc_image_metrics(const lpc_real* dev_true, const lpc_real* dev_est, long n, int n_items, int normalize,
+                      lpc_real* dev_out, void* stream);
+
+/* ---- raw-frame preparation on the device: the step in front of lpc_set_psf / lpc_set_data -------------
+ * Restates lensless/utils/io.py load_image (:157-196), load_psf (:283-375) and their chaining in load_data
+ * (:462-552), minus file decoding, Bayer demosaicing and resizing.  Handle-free, asynchronous on `stream` (scratch
+ * comes from the device's stream-ordered memory pool); results stay on the device. */
+enum lpc_raw_type { LPC_RAW_U8 = 0, LPC_RAW_U16 = 1, LPC_RAW_F32 = 2, LPC_RAW_F64 = 3 };
+typedef struct lpc_prep_config {
+  int raw_type;          /* enum lpc_raw_type of the raw buffer                                        */
+  int height, width;     /* of the raw buffer == of the result (no resizing)                            */
+  int channels;          /* of the raw buffer, channels-last: 1 or 3                                    */
+  int flip_ud, flip_lr;  /* io.py:160-166 (load_image's flip = both)                                    */
+  int bgr_input;         /* 3 channels arrive as BGR (io.py:153-154)                                    */
+  int gray;              /* rgb2gray AFTER normalisation, weights 0.299/0.587/0.114 (io.py:550-552)      */
+  int normalize;         /* frames: divide by the frame's maximum (io.py:196-197)                        */
+  int single_psf;        /* PSF: sum the colour channels into one (io.py:355-364)                        */
+  int out_channels;      /* PSF with single_psf: replicate it over 1 or 3 channels (io.py:553-559)       */
+  int bg_pix0, bg_pix1;  /* PSF: background level = mean of [p0:p1, p0:p1] per channel (io.py:331-350);  */
+                         /* p1 <= p0: no background estimation (bg_pix=None)                             */
+} lpc_prep_config;
+/* n raw frames (n,H,W,C) -> dev_out (n,H,W,C') lpc_real, C' = 1 if gray else C.  dev_bg: C background levels on the
+ * device (what lpc_preprocess_psf wrote: fractions of full scale, re-scaled by get_max_val of each integer frame,
+ * image.py:251-278; values > 1 are taken as pixel units) or NULL.  Background removal clips at 0 (io.py:175). */
+int lpc_preprocess_frames(const lpc_prep_config* cfg, const void* dev_raw, int n, const lpc_real* dev_bg,
+                          lpc_real* dev_out, void* stream);
+/* raw PSF stack (D,H,W,C) -> dev_psf_out (D,H,W,C') with unit l2 norm; dev_bg_out (may be NULL): the C background
+ * levels divided by the stack's full-scale value (io.py:368). */
+int lpc_preprocess_psf(const lpc_prep_config* cfg, const void* dev_raw, int depth, lpc_real* dev_psf_out,
+                       lpc_real* dev_bg_out, void* stream);
 
 /* ---- measurement support (bench.py roofline leg) ----------------------------------- */
 enum lpc_kernel_id {

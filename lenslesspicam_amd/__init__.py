@@ -13,6 +13,7 @@ from .recon import ReconstructionAlgorithm
 from .rfft_convolve import RealFFTConvolve2D
 from .unrolled_admm import UnrolledADMM
 from .unrolled_fista import UnrolledFISTA
+from . import metric, prep  # noqa: F401  (on-device evaluation metrics; raw-frame preparation)
 
 __all__ = ["ADMM", "FISTA", "GradientDescent", "GradientDescentUpdate", "NesterovGradientDescent",
            "RealFFTConvolve2D", "ReconstructionAlgorithm", "UnrolledADMM", "UnrolledFISTA", "apply_admm", "apply_gradient_descent", "non_neg"]

@@ -44,6 +44,14 @@ class Config(C.Structure):
     ]
 
 
+class PrepConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("raw_type", "height", "width", "channels", "flip_ud", "flip_lr", "bgr_input",
+                                       "gray", "normalize", "single_psf", "out_channels", "bg_pix0", "bg_pix1")]
+
+
+RAW_TYPES = {"uint8": 0, "uint16": 1, "float32": 2, "float64": 3}
+
+
 class NativeError(RuntimeError):
     pass
 
@@ -72,6 +80,8 @@ class Lib:
             "lpc_reset": [vp, vp],
             "lpc_set_momentum": [vp, C.c_double, C.c_double, C.c_double],
             "lpc_iterate": [vp, C.c_int, vp],
+            "lpc_iterate_begin": [vp, vp],
+            "lpc_iterate_end": [vp, fp, vp],
             "lpc_set_admm_schedule": [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
                                       C.POINTER(C.c_double), C.POINTER(C.c_double)],
             "lpc_set_fista_schedule": [vp, C.c_int, vp, vp, vp],
@@ -81,6 +91,10 @@ class Lib:
             "lpc_profile_read": [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)],
             "lpc_kernel_bytes": [vp, C.c_int, C.POINTER(C.c_double)],
             "lpc_workspace_bytes": [vp, C.POINTER(C.c_size_t)],
+            "lpc_reconstruction_error": [vp, fp, fp, C.c_int, fp, vp],
+            "lpc_image_metrics": [fp, fp, C.c_long, C.c_int, C.c_int, fp, vp],
+            "lpc_preprocess_frames": [C.POINTER(PrepConfig), vp, C.c_int, fp, fp, vp],
+            "lpc_preprocess_psf": [C.POINTER(PrepConfig), vp, C.c_int, fp, fp, vp],
         }
         for name, args in sig.items():
             fn = getattr(d, name)
@@ -99,6 +113,16 @@ class Lib:
     def check(self, rc: int):
         if rc != 0:
             raise NativeError(self.dll.lpc_last_error().decode())
+
+    def image_metrics(self, true_ptr, est_ptr, n, n_items, normalize, out_ptr, stream=0):
+        self.check(self.dll.lpc_image_metrics(true_ptr, est_ptr, int(n), int(n_items), int(normalize), out_ptr,
+                                              stream))
+
+    def preprocess_frames(self, cfg: PrepConfig, raw_ptr, n, bg_ptr, out_ptr, stream=0):
+        self.check(self.dll.lpc_preprocess_frames(C.byref(cfg), raw_ptr, int(n), bg_ptr, out_ptr, stream))
+
+    def preprocess_psf(self, cfg: PrepConfig, raw_ptr, depth, psf_ptr, bg_ptr, stream=0):
+        self.check(self.dll.lpc_preprocess_psf(C.byref(cfg), raw_ptr, int(depth), psf_ptr, bg_ptr, stream))
 
     def create(self, **kw) -> "Handle":
         cfg = Config()
@@ -173,11 +197,20 @@ class Handle:
     def iterate(self, n, stream=0):
         self._c(self.lib.dll.lpc_iterate(self.h, int(n), stream))
 
+    def iterate_begin(self, stream=0):
+        self._c(self.lib.dll.lpc_iterate_begin(self.h, stream))
+
+    def iterate_end(self, proj_ptr, stream=0):
+        self._c(self.lib.dll.lpc_iterate_end(self.h, proj_ptr, stream))
+
     def form_image(self, out_ptr, stream=0):
         self._c(self.lib.dll.lpc_form_image(self.h, out_ptr, stream))
 
     def get_state(self, name, out_ptr, stream=0):
         self._c(self.lib.dll.lpc_get_state(self.h, name.encode(), out_ptr, stream))
+
+    def reconstruction_error(self, pred_ptr, data_ptr, normalize, out_ptr, stream=0):
+        self._c(self.lib.dll.lpc_reconstruction_error(self.h, pred_ptr, data_ptr, int(normalize), out_ptr, stream))
 
     def profile_enable(self, on=True):
         self._c(self.lib.dll.lpc_profile_enable(self.h, int(on)))

@@ -3,6 +3,8 @@
 // test-suite only, as plain C++ with -DLPC_SIMT_EMU (see lpc_rt.h).
 #include "lpc_kernels.h"
 #include "lpc_gd_kernels.h"
+#include "lpc_metric_kernels.h"
+#include "lpc_prep_kernels.h"
 #include "lpc.h"
 
 #include <algorithm>
@@ -127,6 +129,7 @@ struct lpc_engine {
   real* init_est = nullptr;  // planar copy of the initial estimate (or null)
   real* psf_planar = nullptr;
   bool has_init = false, psf_set = false, data_set = false, first = true;
+  bool split_pending = false;  // lpc_iterate_begin ran, lpc_iterate_end has not yet
   long iters_done = 0;
   KernelTimer timer;
   lpcStream_t stream = nullptr;
@@ -871,9 +874,30 @@ int lpc_iterate(lpc_handle e, int n_iter, void* stream) {
   if (!e->psf_set) return fail("lpc_iterate: PSF not set");
   if (!e->data_set) return fail("Must set data with `set_data()`");
   e->stream = (lpcStream_t)stream;
+  if (e->split_pending) return fail("lpc_iterate: a split iteration is in flight (lpc_iterate_end missing)");
   if (e->cfg.algo == LPC_ALGO_ADMM) return admm_iterate(e, n_iter);
   if (e->cfg.algo >= LPC_ALGO_GD) return gd_iterate(e, n_iter);
   return fail("lpc_iterate: operator-only handle");
+}
+
+// ---- plug-and-play hook (section 8f row N4): one iteration split at the projection ----
+int lpc_iterate_begin(lpc_handle e, void* stream) {
+  if (!e) return fail("null handle");
+  if (e->cfg.algo < LPC_ALGO_GD) return fail("lpc_iterate_begin: gradient-descent family only");
+  if (!e->psf_set) return fail("lpc_iterate_begin: PSF not set");
+  if (!e->data_set) return fail("Must set data with `set_data()`");
+  if (e->split_pending) return fail("lpc_iterate_begin: the previous split iteration was not finished");
+  if (e->fista_sched_n > 0) return fail("lpc_iterate_begin: not available with an unrolled schedule");
+  e->stream = (lpcStream_t)stream;
+  return gd_iterate(e, 1, 1);
+}
+
+int lpc_iterate_end(lpc_handle e, const real* dev_projected, void* stream) {
+  if (!e || !dev_projected) return fail("lpc_iterate_end: null argument");
+  if (e->cfg.algo < LPC_ALGO_GD) return fail("lpc_iterate_end: gradient-descent family only");
+  if (!e->split_pending) return fail("lpc_iterate_end: no split iteration in flight");
+  e->stream = (lpcStream_t)stream;
+  return gd_finish_split(e, dev_projected);
 }
 
 int lpc_form_image(lpc_handle e, real* dev_out, void* stream) {
@@ -939,6 +963,151 @@ int lpc_get_state(lpc_handle e, const char* name, real* dev_out, void* stream) {
   }
   (void)rt::stream_sync(e->stream);
   (void)rt::dev_free(scratch);
+  return rc;
+}
+
+// ---- evaluation reductions (section 8f row N2): nothing here synchronises with the host ----
+int lpc_reconstruction_error(lpc_handle e, const real* dev_pred, const real* dev_data, int normalize,
+                             real* dev_out, void* stream) {
+  if (!e || !dev_pred || !dev_out) return fail("lpc_reconstruction_error: null argument");
+  if (!e->psf_set) return fail("lpc_reconstruction_error: PSF not set");
+  if (!dev_data && !e->data_set) return fail("lpc_reconstruction_error: no data (lpc_set_data or dev_data)");
+  e->stream = (lpcStream_t)stream;
+  const PlaneGeom& g = e->g;
+  const size_t up = (size_t)g.uplane * e->P;
+  // two un-padded planar staging arrays out of buffers that are dead between iterations
+  real *xin = nullptr, *xout = nullptr;
+  if (e->cfg.algo == LPC_ALGO_ADMM) { xin = e->Rsp; xout = e->Aarr; }
+  else if (e->cfg.algo == LPC_ALGO_CONV) { xin = e->gaux; xout = e->gx; }
+  else { xin = (real*)e->S2; xout = xin + up; }
+  const int nimg = e->cfg.batch * e->cfg.depth;
+  LPC_OK(hwc_to_planar(e, dev_pred, xin, nimg, g.H, g.W, g.W, g.uplane));
+  LPC_OK(convolve_planar(e, xin, xout, e->P, false, false));   // H x, cropped (recon.py:632-638)
+  // partials live in the work spectrum, free again once the convolution has been enqueued
+  const int nblk = (int)std::max<long>(1, std::min<long>(64, g.uplane / 1024));
+  if ((4 * (size_t)e->P * nblk + 2 * (size_t)nimg + 8) * sizeof(real) + (size_t)e->P * nblk * sizeof(double) >
+      (size_t)g.cplane * e->P * sizeof(real2))
+    return fail("lpc_reconstruction_error: frame too small for the reduction scratch");
+  real* mm = (real*)e->S;                                     // [P][nblk](max, min)
+  real* rng = mm + 2 * (size_t)e->P * nblk;                   // [B*D](min, max - min)
+  double* part = (double*)(rng + 2 * (size_t)nimg + 2);       // [P][nblk]
+  part = (double*)(((uintptr_t)part + 7) & ~(uintptr_t)7);
+  if (normalize) {
+    LPC_OK(launch_k(e, -1, k_plane_minmax<256>, dim3(nblk, e->P), 256, 2 * 256 * sizeof(real), g,
+                    (const real2*)nullptr, (const real*)xout, 1, mm));
+    LPC_OK(launch_k(e, -1, k_item_range, dim3((nimg + 63) / 64), 64, 0, (const real*)mm, nblk,
+                    e->cfg.channels, nimg, rng));
+  }
+  LPC_OK(launch_k(e, -1, k_sqerr<256>, dim3(nblk, e->P), 256, 256 * sizeof(double), g, (const real*)xout,
+                  dev_data ? dev_data : (const real*)e->Y, dev_data ? 1 : 0,
+                  (const real*)(normalize ? rng : nullptr), part));
+  const double npix = (double)e->cfg.depth * g.H * g.W * e->cfg.channels;   // recon.py:258
+  LPC_OK(launch_k(e, -1, k_sqerr_finish, dim3((e->cfg.batch + 63) / 64), 64, 0, (const double*)part, nblk,
+                  g.DC, e->cfg.batch, npix, dev_out));
+  return 0;
+}
+
+int lpc_image_metrics(const real* dev_true, const real* dev_est, long n, int n_items, int normalize,
+                      real* dev_out, void* stream) {
+  if (!dev_true || !dev_est || !dev_out) return fail("lpc_image_metrics: null argument");
+  if (n < 1 || n_items < 1) return fail("lpc_image_metrics: empty input");
+  Engine tmp;                       // launch context only (stream); owns nothing
+  tmp.stream = (lpcStream_t)stream;
+  Engine* e = &tmp;
+  const int nblk = (int)std::max<long>(1, std::min<long>(1024, n / 4096));
+  const size_t nr = (size_t)n_items * nblk;
+  void* scratch = nullptr;          // [2 nr] + [2 nr] min/max partials, 2 x [2 items] ranges, [nr] doubles
+  const size_t bytes = (4 * nr + 4 * (size_t)n_items) * sizeof(real) + 16 + nr * sizeof(double);
+  LPC_RT(rt::dev_malloc_async(&scratch, bytes, e->stream));
+  real* pt = (real*)scratch;
+  real* px = pt + 2 * nr;
+  real* rt_ = px + 2 * nr;
+  real* rx = rt_ + 2 * n_items;
+  double* part = (double*)(((uintptr_t)(rx + 2 * n_items) + 7) & ~(uintptr_t)7);
+  int rc = launch_k(e, -1, k_flat_minmax<256>, dim3(nblk, n_items), 256, 2 * 256 * sizeof(real), dev_true, n, pt);
+  if (!rc) rc = launch_k(e, -1, k_flat_minmax<256>, dim3(nblk, n_items), 256, 2 * 256 * sizeof(real), dev_est, n, px);
+  if (!rc) rc = launch_k(e, -1, k_flat_range, dim3((n_items + 63) / 64), 64, 0, (const real*)pt, nblk, n_items, rt_);
+  if (!rc) rc = launch_k(e, -1, k_flat_range, dim3((n_items + 63) / 64), 64, 0, (const real*)px, nblk, n_items, rx);
+  if (!rc) rc = launch_k(e, -1, k_pair_sqdiff<256>, dim3(nblk, n_items), 256, 256 * sizeof(double), dev_true,
+                         dev_est, n, (const real*)rt_, (const real*)rx, normalize, part);
+  if (!rc) rc = launch_k(e, -1, k_pair_finish, dim3((n_items + 63) / 64), 64, 0, (const double*)part, nblk,
+                         n_items, n, (const real*)rt_, normalize, dev_out);
+  (void)rt::dev_free_async(scratch, e->stream);   // stream-ordered: freed after the kernels, no host sync
+  return rc;
+}
+
+// ---- raw-frame preparation (section 8f row N3): handle-free, results stay on the device ----
+static int prep_geom(const lpc_prep_config* c, PrepGeom* g, const char* who) {
+  if (!c) return fail(std::string(who) + ": null config");
+  if (c->height < 1 || c->width < 1) return fail(std::string(who) + ": bad spatial size");
+  if (c->channels != 1 && c->channels != 3) return fail(std::string(who) + ": channels must be 1 or 3");
+  if (c->raw_type < LPC_RAW_U8 || c->raw_type > LPC_RAW_F64) return fail(std::string(who) + ": unknown raw type");
+  g->H = c->height; g->W = c->width; g->Cin = c->channels;
+  g->flip_ud = c->flip_ud != 0; g->flip_lr = c->flip_lr != 0; g->rev = c->bgr_input != 0 && c->channels == 3;
+  g->gray = c->gray != 0; g->raw_type = c->raw_type; g->p0 = c->bg_pix0; g->p1 = c->bg_pix1;
+  g->single = c->single_psf != 0 && c->channels == 3; g->normalize = c->normalize != 0;
+  g->Cout = (g->gray && g->Cin == 3) ? 1 : g->Cin;
+  return 0;
+}
+
+int lpc_preprocess_frames(const lpc_prep_config* cfg, const void* dev_raw, int n, const real* dev_bg,
+                          real* dev_out, void* stream) {
+  PrepGeom g;
+  LPC_OK(prep_geom(cfg, &g, "lpc_preprocess_frames"));
+  if (!dev_raw || !dev_out || n < 1) return fail("lpc_preprocess_frames: null / empty argument");
+  Engine tmp;
+  tmp.stream = (lpcStream_t)stream;
+  Engine* e = &tmp;
+  const long npx = (long)g.H * g.W;
+  const int nblk = (int)std::max<long>(1, std::min<long>(512, npx / 4096));
+  void* scratch = nullptr;
+  LPC_RT(rt::dev_malloc_async(&scratch, ((size_t)n * g.Cin * nblk + 5 * (size_t)n) * sizeof(real), e->stream));
+  real* partial = (real*)scratch;
+  real* par = partial + (size_t)n * g.Cin * nblk;
+  int rc = launch_k(e, -1, k_prep_chanmax<256>, dim3(nblk, n * g.Cin), 256, 2 * 256 * sizeof(real), g, dev_raw,
+                    partial);
+  if (!rc) rc = launch_k(e, -1, k_prep_frame_params, dim3((n + 63) / 64), 64, 0, g, (const real*)partial, nblk,
+                         dev_bg, n, par);
+  if (!rc) rc = launch_k(e, -1, k_prep_frame<256>, grid1d(npx, 256, n), 256, 0, g, dev_raw, (const real*)par,
+                         dev_out);
+  (void)rt::dev_free_async(scratch, e->stream);
+  return rc;
+}
+
+int lpc_preprocess_psf(const lpc_prep_config* cfg, const void* dev_raw, int depth, real* dev_psf_out,
+                       real* dev_bg_out, void* stream) {
+  PrepGeom g;
+  LPC_OK(prep_geom(cfg, &g, "lpc_preprocess_psf"));
+  if (!dev_raw || !dev_psf_out || depth < 1) return fail("lpc_preprocess_psf: null / empty argument");
+  const bool has_bg = g.p1 > g.p0;
+  if (has_bg && (g.p0 < 0 || g.p1 > g.H || g.p1 > g.W)) return fail("lpc_preprocess_psf: bg_pix outside the frame");
+  int rep = g.Cin;
+  if (g.single) {
+    rep = cfg->out_channels;
+    if (rep != 1 && rep != 3) return fail("lpc_preprocess_psf: out_channels must be 1 or 3 with single_psf");
+  }
+  Engine tmp;
+  tmp.stream = (lpcStream_t)stream;
+  Engine* e = &tmp;
+  const long npx = (long)depth * g.H * g.W;
+  const int nblk = (int)std::max<long>(1, std::min<long>(1024, npx / 4096));
+  void* scratch = nullptr;
+  LPC_RT(rt::dev_malloc_async(&scratch, (size_t)nblk * sizeof(double) + ((size_t)nblk + 8) * sizeof(real),
+                              e->stream));
+  double* psum = (double*)scratch;
+  real* pmax = (real*)(psum + nblk);
+  real* bgv = pmax + nblk;   // [3]
+  real* nrm = bgv + 3;       // [1]
+  int rc = 0;
+  if (has_bg)
+    rc = launch_k(e, -1, k_prep_psf_bg<256>, dim3(g.Cin), 256, 256 * sizeof(double), g, dev_raw, depth, bgv);
+  if (!rc) rc = launch_k(e, -1, k_prep_psf_energy<256>, dim3(nblk), 256, 256 * sizeof(double) + 2 * 256 * sizeof(real),
+                         g, dev_raw, depth, (const real*)bgv, (int)has_bg, psum, pmax);
+  if (!rc) rc = launch_k(e, -1, k_prep_psf_finish, dim3(1), 64, 0, g, (const double*)psum, (const real*)pmax, nblk,
+                         (const real*)bgv, (int)has_bg, nrm, dev_bg_out);
+  if (!rc) rc = launch_k(e, -1, k_prep_psf<256>, grid1d(npx, 256), 256, 0, g, dev_raw, depth, (const real*)bgv,
+                         (int)has_bg, (const real*)nrm, rep, dev_psf_out);
+  (void)rt::dev_free_async(scratch, e->stream);
   return rc;
 }
 

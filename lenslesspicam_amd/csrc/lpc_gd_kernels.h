@@ -63,11 +63,25 @@ struct GdScalars {
   real onepmu;    // nesterov: float32(1 + mu)
   real coef;      // fista: float32((t_k - 1) / t_{k+1})
   int first;       // fista: x_k aliases the iterate during the first update (gd.py:233,236)
+  int split;       // 1: stop in front of the projection (plug-and-play hook, lpc_iterate_begin / _end)
 };
 
 static __device__ __forceinline__ void gd_update_one(real* LPC_RESTRICT X, real* LPC_RESTRICT AUX, long o,
                                                       real gr, real al, const GdScalars& p) {
   const real x = X[o];
+  if (p.split) {   // everything up to `self._form_image()` of the three _update()s; k_gd_post finishes
+    if (p.kind == 1) {
+      const real pp = AUX[o];
+      const real pn = p.mu * pp - al * gr;
+      AUX[o] = pn;
+      X[o] = x + (p.negmu * pp + p.onepmu * pn);
+    } else {
+      const real x1 = x - al * gr;
+      X[o] = x1;
+      if (p.kind == 2 && p.first) AUX[o] = x1;   // x_k aliases the iterate before the first projection
+    }
+    return;
+  }
   if (p.kind == 0) {                       // gd.py:132-134
     X[o] = rmax(x - al * gr, (real)0.);
   } else if (p.kind == 1) {                // gd.py:183-188
@@ -115,6 +129,27 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan pl
   };
   fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, upd, NoFix{},
                                                   R2 ? 1 : 0, 0);
+}
+
+// second half of a split iteration: PROJ = proj(image_est) as the caller computed it, channels-last (n,H,W,C)
+//   vanilla / nesterov: x = PROJ                          gd.py:134,188
+//   fista: x_k = PROJ; x = x_k + coef (x_k - x_{k-1})     gd.py:236-241
+template <int NT>
+__global__ __launch_bounds__(NT) void k_gd_post(PlaneGeom g, const real* LPC_RESTRICT PROJ, real* LPC_RESTRICT X,
+                                                 real* LPC_RESTRICT AUX, int kind, real coef) {
+  const long pl = blockIdx.y;
+  const long img = pl / g.C;
+  const int ch = (int)(pl % g.C);
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < g.uplane; e += (long)gridDim.x * NT) {
+    const real xk = PROJ[(img * g.uplane + e) * g.C + ch];
+    const long o = pl * g.uplane + e;
+    if (kind == 2) {
+      X[o] = xk + coef * (xk - AUX[o]);
+      AUX[o] = xk;
+    } else {
+      X[o] = xk;
+    }
+  }
 }
 
 // ---- reductions (set-up only): per-plane max/min with wavefront shuffles ---------------------

@@ -64,6 +64,8 @@ namespace rt {
 static inline const char* err_string(lpcError_t) { return "emu"; }
 static inline lpcError_t dev_malloc(void** p, size_t n) { *p = std::malloc(n ? n : 1); return *p ? 0 : 1; }
 static inline lpcError_t dev_free(void* p) { std::free(p); return 0; }
+static inline lpcError_t dev_malloc_async(void** p, size_t n, lpcStream_t) { return dev_malloc(p, n); }
+static inline lpcError_t dev_free_async(void* p, lpcStream_t) { std::free(p); return 0; }
 static inline lpcError_t memset_async(void* p, int v, size_t n, lpcStream_t) { std::memset(p, v, n); return 0; }
 static inline lpcError_t copy_d2d_async(void* d, const void* s, size_t n, lpcStream_t) { std::memmove(d, s, n); return 0; }
 static inline lpcError_t copy_h2d_async(void* d, const void* s, size_t n, lpcStream_t) { std::memcpy(d, s, n); return 0; }
@@ -97,6 +99,9 @@ namespace rt {
 static inline const char* err_string(lpcError_t e) { return hipGetErrorString(e); }
 static inline lpcError_t dev_malloc(void** p, size_t n) { return hipMalloc(p, n ? n : 1); }
 static inline lpcError_t dev_free(void* p) { return hipFree(p); }
+// stream-ordered scratch (the device's default memory pool): no host synchronisation on either side
+static inline lpcError_t dev_malloc_async(void** p, size_t n, lpcStream_t s) { return hipMallocAsync(p, n ? n : 1, s); }
+static inline lpcError_t dev_free_async(void* p, lpcStream_t s) { return hipFreeAsync(p, s); }
 static inline lpcError_t memset_async(void* p, int v, size_t n, lpcStream_t s) { return hipMemsetAsync(p, v, n, s); }
 static inline lpcError_t copy_d2d_async(void* d, const void* s, size_t n, lpcStream_t st) { return hipMemcpyAsync(d, s, n, hipMemcpyDeviceToDevice, st); }
 static inline lpcError_t copy_h2d_async(void* d, const void* s, size_t n, lpcStream_t st) { return hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, st); }

@@ -43,13 +43,45 @@ class GradientDescent(ReconstructionAlgorithm):
 
     def __init__(self, psf, dtype=None, proj=non_neg, lip_fact=1.8, **kwargs):
         assert callable(proj)
-        if proj is not non_neg:
-            raise NotImplementedError(
-                "custom projection callables cannot be fused into the HIP kernels; only non_neg is supported"
-            )
         self._proj = proj
         self._lip_fact = lip_fact
+        # Plug-and-play hook.  ``non_neg`` is fused into the update kernel; any
+        # other ``proj`` callable, or an external denoiser (gd.py:89-92: it REPLACES the projection and is called
+        # as denoiser(image_est, noise_level)), splits every iteration at ``self._form_image()``:
+        # lpc_iterate_begin -> callable on the (B,D,H,W,C) estimate -> lpc_iterate_end.
+        denoiser = kwargs.pop("denoiser", None)
+        self._pnp = None
+        if denoiser is not None:
+            assert "network" in denoiser.keys() and "noise_level" in denoiser.keys()     # recon.py:310-312
+            if not callable(denoiser["network"]):
+                raise NotImplementedError(
+                    f"Unsupported denoiser: {denoiser['network']!r} (pretrained networks are outside the hot "
+                    "path; pass the denoising function itself as denoiser['network'])")
+            self._pnp = (denoiser["network"], denoiser["noise_level"])
+        self._hook = self._pnp is not None or proj is not non_neg
         super().__init__(psf, dtype, **kwargs)
+        if self._pnp is not None:
+            self._denoiser, self._denoiser_noise_level = self._pnp
+            self._proj = self._denoiser
+
+    def _apply_proj(self, x):
+        if self._pnp is not None:                      # gd.py:136-140
+            return self._proj(x, self._denoiser_noise_level)
+        return self._proj(x)
+
+    def _iterate(self, n):
+        if not self._hook:
+            return super()._iterate(n)
+        for _ in range(int(n)):
+            self._handle.iterate_begin(self._stream())
+            projected = self._to_dev(self._apply_proj(self._image_est))
+            assert tuple(projected.shape) == self._state_shape(), "the projection must keep the estimate's shape"
+            self._handle.iterate_end(projected.data_ptr(), self._stream())
+
+    def _form_image(self):
+        if not self._hook:
+            return super()._form_image()
+        return self._apply_proj(self._image_est)       # the reference projects again on read-out (gd.py:136-140)
 
     def _config(self):
         return dict(lip_fact=float(self._lip_fact))

@@ -1,0 +1,121 @@
+"""
+Raw-frame preparation on the MI355X -- the step in front of ``set_data``.
+
+Array-level counterparts of the reference's loaders (``lensless/utils/io.py``): the same keyword names and
+arithmetic as ``load_image`` (:46-196), ``load_psf`` (:199-375) and ``load_data`` (:378-552), minus what lives in
+front of the arrays (file decoding with cv2 / rawpy, Bayer demosaicing) and minus resizing (cv2.resize; neither
+is available here, so neither has an oracle).  Raw camera buffers -- uint8, uint16 or float, NumPy or torch --
+go in; float tensors on the device come out, ready for ``ADMM(psf)`` / ``set_data(data)``, with every
+normaliser (frame maximum, bit depth, background level, PSF energy) computed on the device by
+``lpc_preprocess_frames`` / ``lpc_preprocess_psf`` (include/lpc.h).
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _native
+from . import recon as _recon
+
+
+def _raw_to_dev(a, dev):
+    if isinstance(a, np.ndarray):
+        if a.dtype == np.uint16:       # torch has no arithmetic on uint16; the kernels only need the bytes
+            a = torch.from_numpy(np.ascontiguousarray(a).view(np.int16))
+            return a.to(dev).contiguous(), "uint16"
+        a = torch.from_numpy(np.ascontiguousarray(a))
+    name = {torch.uint8: "uint8", torch.int16: "uint16", torch.float32: "float32", torch.float64: "float64"}
+    if hasattr(torch, "uint16"):
+        name[torch.uint16] = "uint16"
+    if a.dtype not in name:
+        raise ValueError(f"unsupported raw dtype {a.dtype}: expected uint8, uint16, float32 or float64")
+    return a.detach().to(dev).contiguous(), name[a.dtype]
+
+
+def _cfg(raw_name, H, W, C, flip, flip_ud, flip_lr, bgr_input, **kw):
+    cfg = _native.PrepConfig()
+    cfg.raw_type = _native.RAW_TYPES[raw_name]
+    cfg.height, cfg.width, cfg.channels = int(H), int(W), int(C)
+    cfg.flip_ud = int(bool(flip) ^ bool(flip_ud))          # io.py:160-166: flip = both axes, then the single flips
+    cfg.flip_lr = int(bool(flip) ^ bool(flip_lr))
+    cfg.bgr_input = int(bool(bgr_input))
+    for k, v in kw.items():
+        setattr(cfg, k, int(v))
+    return cfg
+
+
+def preprocess_frames(raw, bg=None, flip=False, flip_ud=False, flip_lr=False, bgr_input=False, normalize=True,
+                      gray=False, dtype="float32"):
+    """``load_image(..., as_4d=True, return_float=True)`` (io.py:157-196) for raw frames already in memory.
+
+    raw: (H,W), (H,W,C) or a batch (B,H,W,C); bg: C background levels (fractions of full scale if <= 1, like the
+    value ``load_psf`` returns, else pixel units), array or device tensor.  Returns a (B,H,W,C') device tensor
+    (B = 1 for a single frame, C' = 1 if ``gray``) -- the layout ``set_data`` takes.
+    """
+    lib, dev = _recon.runtime(dtype)
+    tdt = torch.float64 if dtype == "float64" else torch.float32
+    if raw.ndim == 2:
+        raw = raw[None, :, :, None]
+    elif raw.ndim == 3:
+        raw = raw[None]
+    assert raw.ndim == 4, "raw frames must be (H,W), (H,W,C) or (B,H,W,C)"
+    r, name = _raw_to_dev(raw, dev)
+    B, H, W, C = (int(v) for v in r.shape)
+    cfg = _cfg(name, H, W, C, flip, flip_ud, flip_lr, bgr_input, normalize=normalize, gray=gray)
+    bg_dev = None
+    if bg is not None:
+        bg_dev = torch.as_tensor(np.asarray(bg) if not isinstance(bg, torch.Tensor) else bg).to(dev, tdt).reshape(-1)
+        assert bg_dev.numel() == C, "one background level per channel"
+        bg_dev = bg_dev.contiguous()
+    out = torch.empty((B, H, W, 1 if (gray and C == 3) else C), dtype=tdt, device=dev)
+    lib.preprocess_frames(cfg, r.data_ptr(), B, bg_dev.data_ptr() if bg_dev is not None else None, out.data_ptr(),
+                          _recon._stream_handle(dev))
+    return out
+
+
+def preprocess_psf(raw, bg_pix=(5, 25), flip=False, flip_ud=False, flip_lr=False, bgr_input=False,
+                   single_psf=False, gray=False, out_channels=None, return_bg=False, dtype="float32"):
+    """``load_psf(..., return_float=True)`` (io.py:283-375) for a raw PSF already in memory: background level from
+    the corner window ``bg_pix``, clip, optional ``single_psf``, division by the l2 norm.  raw: (H,W), (H,W,C) or
+    a depth stack (D,H,W,C).  Returns the (D,H,W,C') device tensor and, with ``return_bg``, the C background levels
+    as fractions of full scale (device tensor) -- what ``preprocess_frames(bg=...)`` expects."""
+    lib, dev = _recon.runtime(dtype)
+    tdt = torch.float64 if dtype == "float64" else torch.float32
+    if raw.ndim == 2:
+        raw = raw[None, :, :, None]
+    elif raw.ndim == 3:
+        raw = raw[None]
+    assert raw.ndim == 4, "raw PSF must be (H,W), (H,W,C) or (D,H,W,C)"
+    r, name = _raw_to_dev(raw, dev)
+    D, H, W, C = (int(v) for v in r.shape)
+    single = bool(single_psf) and C == 3
+    rep = (out_channels or 1) if single else C
+    p0, p1 = (0, 0) if bg_pix is None else (int(bg_pix[0]), int(bg_pix[1]))
+    cfg = _cfg(name, H, W, C, flip, flip_ud, flip_lr, bgr_input, single_psf=single, out_channels=rep, gray=gray,
+               bg_pix0=p0, bg_pix1=p1)
+    c_out = 1 if (gray and rep == 3) else rep
+    psf = torch.empty((D, H, W, c_out), dtype=tdt, device=dev)
+    bg = torch.zeros((C,), dtype=tdt, device=dev)
+    lib.preprocess_psf(cfg, r.data_ptr(), D, psf.data_ptr(), bg.data_ptr(), _recon._stream_handle(dev))
+    return (psf, bg) if return_bg else psf
+
+
+def preprocess_data(raw_psf, raw_data, bg_pix=(5, 25), flip=False, flip_ud=False, flip_lr=False, gray=False,
+                    single_psf=False, normalize=False, bgr_input=False, dtype=None, return_bg=False):
+    """``load_data`` (io.py:462-552) on arrays: the PSF's background level (as a fraction of full scale) is
+    re-scaled to the frame's bit depth and removed from the frame; both come back as float device tensors,
+    psf (D,H,W,C') and data (1,H,W,C') [or (B,H,W,C') for a batch of frames]."""
+    dtype = dtype or "float32"
+    if dtype not in ("float32", "float64"):
+        raise ValueError("dtype must be float32 or float64")
+    c_data = 1 if raw_data.ndim == 2 else int(raw_data.shape[-1])
+    psf, bg = preprocess_psf(raw_psf, bg_pix=bg_pix, single_psf=single_psf, gray=gray, out_channels=c_data,
+                             return_bg=True, dtype=dtype)
+    data = preprocess_frames(raw_data, bg=bg if bg_pix is not None else None, flip=flip, flip_ud=flip_ud,
+                             flip_lr=flip_lr, bgr_input=bgr_input, normalize=normalize, gray=gray, dtype=dtype)
+    if data.shape[-1] != psf.shape[-1]:
+        if psf.shape[-1] == 1:       # io.py:553-559: a grayscale PSF is repeated over the frame's channels
+            psf = psf.repeat(1, 1, 1, data.shape[-1])
+        elif data.shape[-1] == 1:    # io.py:561-567
+            data = data.repeat(1, 1, 1, psf.shape[-1])
+    return (psf, data, bg) if return_bg else (psf, data)

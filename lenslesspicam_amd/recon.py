@@ -281,22 +281,34 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
         return final_im, full
 
     def reconstruction_error(self, prediction=None, lensless=None, psfs=None, normalize=True):
-        """``|| norm(H x) - y ||^2 / npix`` per batch item (recon.py:607-653)."""
-        from .rfft_convolve import RealFFTConvolve2D
-
+        """``|| norm(H x) - y ||^2 / npix`` per batch item (recon.py:607-653).  One convolution and
+        three device reductions through ``lpc_reconstruction_error``; nothing is copied to the host
+        except the final value(s) when the solver was built from NumPy arrays."""
         if prediction is None:
             prediction = self.get_image_estimate()
         if lensless is None:
             lensless = self._data
-        if psfs is None:
-            psfs = self._psf
-        conv = RealFFTConvolve2D(psfs, dtype=self._real, pad=True, norm=self._norm)
-        Hx = conv.convolve(prediction)
-        Hx_t = torch.as_tensor(Hx) if not isinstance(Hx, torch.Tensor) else Hx
-        y_t = torch.as_tensor(lensless) if not isinstance(lensless, torch.Tensor) else lensless
-        y_t = y_t.to(Hx_t.device)
-        if normalize:
-            Hx_t = Hx_t - torch.amin(Hx_t, dim=(-1, -2, -3), keepdim=True)
-            Hx_t = Hx_t / torch.amax(Hx_t, dim=(-1, -2, -3), keepdim=True)
-        err = torch.sum((Hx_t - y_t) ** 2, dim=(-1, -2, -3, -4)) / self._npix
-        return err if self.is_torch else err.cpu().numpy()
+        pred = self._to_dev(prediction)
+        if pred.dim() == 4:
+            pred = pred[None]
+        y = self._to_dev(lensless)
+        y = y.reshape((-1,) + tuple(y.shape[-3:])).contiguous()          # (B,1,H,W,C) | (H,W,C) -> (B,H,W,C)
+        B = int(pred.shape[0])
+        assert y.shape[0] == B, "prediction and lensless must have the same batch size"
+        own = psfs is None and B == self._handle_batch
+        if own:
+            h = self._handle
+        else:     # another PSF of the same shape (recon.py:631-633) or another batch size: a throw-away
+            psf_dev = self._psf_dev if psfs is None else self._to_dev(psfs)      # operator handle
+            assert tuple(psf_dev.shape) == tuple(self._psf_dev.shape)
+            D, H, W, C = (int(v) for v in psf_dev.shape)
+            h = self._lib.create(algo=_native.ALGO_CONV, height=H, width=W, channels=C, depth=D, batch=B,
+                                 norm=_native.NORM[self._norm], pad=1)
+            h.set_psf(psf_dev.data_ptr(), self._stream())
+        out = self._empty((B,))
+        h.reconstruction_error(pred.data_ptr(), y.data_ptr(), bool(normalize), out.data_ptr(), self._stream())
+        if not own:
+            if self._device.type == "cuda":
+                torch.cuda.current_stream(self._device).synchronize()
+            h.close()
+        return self._to_user(out)

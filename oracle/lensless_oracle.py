@@ -289,8 +289,11 @@ class GDOracle:
     """kind in {"vanilla", "nesterov", "fista"}; PSF may have depth D >= 1."""
 
     def __init__(self, psf, kind="fista", dtype=torch.float32, lip_fact=1.8, mu=0.9, p=0.0,
-                 tk=1.0, initial_est=None, norm="ortho"):
+                 tk=1.0, initial_est=None, norm="ortho", proj=None):
+        """proj: the projection applied by ``_form_image`` (gd.py:136-140); None = non_neg (gd.py:41-59).  An
+        external denoiser is the same thing with its noise level bound (gd.py:89-92)."""
         assert kind in ("vanilla", "nesterov", "fista")
+        self.proj = proj if proj is not None else (lambda x: torch.maximum(x, torch.zeros_like(x)))
         psf = _as_tensor(psf, dtype)
         assert psf.dim() == 4
         self.kind, self.dtype = kind, dtype
@@ -346,15 +349,15 @@ class GDOracle:
     def step(self):
         if self.kind == "vanilla":                                           # gd.py:132-134
             self.x = self.x - self.alpha * self.grad()
-            self.x = torch.maximum(self.x, torch.zeros_like(self.x))
+            self.x = self.proj(self.x)
         elif self.kind == "nesterov":                                        # gd.py:183-188
             p_prev = self.p
             self.p = self.mu * self.p - self.alpha * self.grad()
             self.x = self.x + (-self.mu * p_prev + (1 + self.mu) * self.p)
-            self.x = torch.maximum(self.x, torch.zeros_like(self.x))
+            self.x = self.proj(self.x)
         else:                                                                # gd.py:235-241
             self.x = self.x - self.alpha * self.grad()
-            xk = torch.maximum(self.x, torch.zeros_like(self.x))
+            xk = self.proj(self.x)
             tk = (1 + math.sqrt(1 + 4 * self.tk ** 2)) / 2
             xk_prev = self.x if self.xk is None else self.xk   # aliasing quirk, see reset()
             self.x = xk + (self.tk - 1) / tk * (xk - xk_prev)
@@ -362,7 +365,7 @@ class GDOracle:
             self.xk = xk
 
     def form_image(self):
-        return torch.maximum(self.x, torch.zeros_like(self.x))               # gd.py:136-140,41-59
+        return self.proj(self.x)                                             # gd.py:136-140,41-59
 
     def apply(self, n_iter, reset=True, background=None):
         assert self.data is not None and self.data.shape[0] == 1
@@ -404,13 +407,35 @@ def unrolled_fista_oracle(psf, data, alpha, tk, dtype=torch.float32):
 
 
 def reconstruction_error(conv: ConvolverOracle, prediction, lensless, normalize=True):
-    """recon.py:607-653 restated for a pad=True convolver (GD family)."""
+    """recon.py:607-653 restated.  conv: a pad=True ConvolverOracle; the reference's pad=False branch (ADMM)
+    pads, convolves and crops, which is the same arithmetic.  prediction (B,D,H,W,C), lensless (B,1,H,W,C)."""
     Hx = conv.convolve(prediction)
     if normalize:
         Hx = Hx - torch.amin(Hx, dim=(-1, -2, -3), keepdim=True)
         Hx = Hx / torch.amax(Hx, dim=(-1, -2, -3), keepdim=True)
     npix = float(np.prod(conv.psf.shape))
     return torch.sum((Hx - lensless) ** 2, dim=(-1, -2, -3, -4)) / npix
+
+
+def mse(true, est, normalize=True):
+    """lensless/eval/metric.py:119-144: both images / their own max (float32), then skimage's
+    mean_squared_error = float64 mean of the squared float32 difference."""
+    a = np.array(true, dtype=np.float32)
+    b = np.array(est, dtype=np.float32)
+    if normalize:
+        a = a / a.max()
+        b = b / b.max()
+    return float(np.mean((a - b) ** 2, dtype=np.float64))
+
+
+def psnr_skimage(true, est, normalize=True):
+    """lensless/eval/metric.py:147-172 with skimage.metrics.peak_signal_noise_ratio(data_range=None) restated:
+    for float images the range is 1 when min(true) >= 0, else 2 (dtype range (-1, 1))."""
+    a = np.array(true, dtype=np.float32)
+    if normalize:
+        a = a / a.max()
+    r = 1.0 if a.min() >= 0 else 2.0
+    return 10.0 * math.log10(r * r / mse(true, est, normalize))
 
 
 def psnr(img, ref):

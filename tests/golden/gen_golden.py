@@ -165,6 +165,116 @@ def unrolled_fista_case(name, h, w, c, seed, n_iter, batch):
     print("wrote", name, out.shape)
 
 
+def recon_error_case(name):
+    """ReconstructionAlgorithm.reconstruction_error (recon.py:607-653) through the public API: ADMM and FISTA,
+    normalised and raw, default arguments and an explicit (prediction, lensless, psfs) triple, depth 2."""
+    out = {}
+    psf, data = make_inputs(24, 32, 3, 31)
+    rec = ADMM(t(psf), tau=2e-6, mu2=1e-4)
+    rec.set_data(t(data))
+    rec.apply(n_iter=6, disp_iter=None, plot=False)
+    out.update(admm_psf=psf, admm_data=data, admm_iters=np.array(6), admm_params=np.array([2e-6, 1e-4]),
+               admm_err=rec.reconstruction_error().numpy().copy(),
+               admm_err_raw=rec.reconstruction_error(normalize=False).numpy().copy())
+    psf2, data2 = make_inputs(19, 27, 3, 32, d=2)
+    fis = FISTA(t(psf2))
+    fis.set_data(t(data2))
+    fis.apply(n_iter=9, disp_iter=None, plot=False)
+    out.update(fista_psf=psf2, fista_data=data2, fista_iters=np.array(9),
+               fista_err=fis.reconstruction_error().numpy().copy(),
+               fista_err_raw=fis.reconstruction_error(normalize=False).numpy().copy())
+    # explicit arguments: a batch of 2 arbitrary predictions against 2 frames with another PSF
+    rng = np.random.default_rng(33)
+    pred = rng.random((2, 2, 19, 27, 3)).astype(np.float32)
+    frames = rng.random((2, 1, 19, 27, 3)).astype(np.float32)
+    psf3, _ = make_inputs(19, 27, 3, 34, d=2)
+    out.update(x_pred=pred, x_frames=frames, x_psf=psf3,
+               x_err=fis.reconstruction_error(prediction=t(pred), lensless=t(frames), psfs=t(psf3)).numpy().copy())
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, {k: v for k, v in out.items() if k.endswith("err") or k.endswith("raw")})
+
+
+def preprocess_case(name):
+    """load_data / load_psf / load_image (lensless/utils/io.py) on .npy inputs: the raw-frame preparation in
+    front of set_data.  No cv2 call is reached (no resize, bgr_input=False, no Bayer)."""
+    import tempfile
+
+    from lensless.utils.io import load_data, load_image, load_psf
+
+    out = {}
+    rng = np.random.default_rng(41)
+    tmp = tempfile.mkdtemp()
+
+    def raw_pair(tag, d, h, w, c, maxv, dt):
+        psf = (rng.random((d, h, w, c)) ** 8 * maxv * 0.9 + rng.random((d, h, w, c)) * maxv * 0.02 + maxv * 0.03)
+        dat = rng.random((h, w, c)) * maxv * 0.8 + maxv * 0.05
+        psf, dat = psf.astype(dt), dat.astype(dt)
+        np.save(os.path.join(tmp, tag + "_psf.npy"), psf)
+        np.save(os.path.join(tmp, tag + "_dat.npy"), dat)
+        out[tag + "_raw_psf"], out[tag + "_raw_data"] = psf, dat
+        return os.path.join(tmp, tag + "_psf.npy"), os.path.join(tmp, tag + "_dat.npy")
+
+    cases = {
+        "a": dict(shape=(1, 40, 52, 3), maxv=3000, dt=np.uint16, kw=dict(flip=True, normalize=True)),
+        "b": dict(shape=(1, 33, 47, 3), maxv=250, dt=np.uint8, kw=dict(flip_ud=True, gray=True, normalize=True)),
+        "c": dict(shape=(2, 40, 52, 3), maxv=60000, dt=np.uint16, kw=dict(single_psf=True, flip_lr=True)),
+        "d": dict(shape=(1, 30, 36, 3), maxv=1000, dt=np.uint16, kw=dict(normalize=True, dtype="float64")),
+        "e": dict(shape=(1, 30, 36, 1), maxv=4000, dt=np.uint16, kw=dict(normalize=True, bg_pix=None)),
+    }
+    for tag, cs in cases.items():
+        pf, df = raw_pair(tag, *cs["shape"], cs["maxv"], cs["dt"])
+        kw = dict(downsample=1, plot=False, bgr_input=False, return_bg=True)
+        kw.update(cs["kw"])
+        if kw.get("bg_pix", 0) is None:
+            kw["return_bg"] = False
+            psf, data = load_data(pf, df, **kw)
+            bg = np.zeros(0)
+        else:
+            psf, data, bg = load_data(pf, df, **kw)
+        out[tag + "_psf"], out[tag + "_data"], out[tag + "_bg"] = psf, data, bg
+        print(tag, psf.shape, psf.dtype, data.shape, float(data.max()), bg)
+    # load_image alone: explicit background in pixel units on a float frame (no bit-depth scaling), no normalise
+    fr = (rng.random((28, 34, 3)) * 5.0).astype(np.float32)
+    np.save(os.path.join(tmp, "f.npy"), fr)
+    bgv = np.array([0.4, 1.7, 0.9], dtype=np.float32)
+    out["f_raw"], out["f_bg"] = fr, bgv
+    out["f_out"] = load_image(os.path.join(tmp, "f.npy"), bg=bgv, as_4d=True, return_float=True, normalize=False,
+                              flip=True, flip_ud=True, bgr_input=False)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name)
+
+
+def _shrink(x):
+    """a NON-idempotent projection: shrink towards 0, then clamp (so that projecting twice is visible)"""
+    return torch.clamp(x - 0.05, min=0)
+
+
+def _fake_denoiser(x, noise_level):
+    return torch.clamp(x, min=0) * (1.0 - noise_level / 100.0)
+
+
+def hook_case(name):
+    """Custom `proj=` callables (gd.py:67,136-140) on the three solvers through the public API, and the
+    denoiser-as-projection wiring of gd.py:89-92 (the DruNet weights cannot be loaded here, so the three
+    attributes the constructor would set are set by hand to a stand-in function)."""
+    out = {}
+    psf, data = make_inputs(22, 30, 3, 51)
+    out.update(psf=psf, data=data, iters=np.array(7), noise_level=np.array(7.0))
+    for nm, cls in (("gd", GradientDescent), ("nesterov", NesterovGradientDescent), ("fista", FISTA)):
+        rec = cls(t(psf), proj=_shrink)
+        rec.set_data(t(data))
+        out[nm + "_final"] = rec.apply(n_iter=7, disp_iter=None, plot=False).numpy().copy()
+        out[nm + "_state"] = rec._image_est.numpy().copy()
+    rec = FISTA(t(psf))
+    rec._denoiser = _fake_denoiser
+    rec._denoiser_noise_level = 7.0
+    rec._proj = rec._denoiser
+    rec.set_data(t(data))
+    out["pnp_final"] = rec.apply(n_iter=7, disp_iter=None, plot=False).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, {k: float(np.abs(v).max()) for k, v in out.items() if k.endswith("final")})
+
+
 def operator_case():
     rng = np.random.default_rng(5)
     out = {}
@@ -212,6 +322,15 @@ if __name__ == "__main__":
         unrolled_admm_case("unrolled_admm_24x32x3_b3", 24, 32, 3, seed=21, n_iter=6, batch=3)
         unrolled_fista_case("unrolled_fista_24x32x3_b3", 24, 32, 3, seed=22, n_iter=7, batch=3)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "hook":
+        hook_case("pnp_hook")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "preprocess":
+        preprocess_case("preprocess")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "recon_error":
+        recon_error_case("recon_error")
+        sys.exit(0)
     operator_case()
     # default hyper-parameters (U stays 0: tau/mu2 = 10, SURVEY section 7 caveat)
     admm_case("admm_24x32x3_default", 24, 32, 3, seed=1, iters=[1, 2, 5, 20])
@@ -239,3 +358,6 @@ if __name__ == "__main__":
     gd_case("fista_24x32x1_f64", FISTA, 24, 32, 1, seed=17, iters=[5, 20], dtype="float64")
     unrolled_admm_case("unrolled_admm_24x32x3_b3", 24, 32, 3, seed=21, n_iter=6, batch=3)
     unrolled_fista_case("unrolled_fista_24x32x3_b3", 24, 32, 3, seed=22, n_iter=7, batch=3)
+    recon_error_case("recon_error")
+    preprocess_case("preprocess")
+    hook_case("pnp_hook")

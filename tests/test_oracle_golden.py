@@ -160,3 +160,42 @@ def test_unrolled_fista_matches_reference():
     for b in range(g["data"].shape[0]):
         out = orc.unrolled_fista_oracle(g["psf"], g["data"][b, 0], g["alpha"], g["tk"])
         assert rel(out[0], g["out"][b]) <= 2e-6
+
+
+def test_reconstruction_error_matches_reference():
+    """recon.py:607-653 values produced by the imported reference (gen_golden.py recon_error)."""
+    g = np.load(os.path.join(GOLDEN, "recon_error.npz"))
+    tau, mu2 = (float(v) for v in g["admm_params"])
+    o = orc.ADMMOracle(g["admm_psf"], tau=tau, mu2=mu2)
+    o.set_data(g["admm_data"])
+    pred = o.apply(int(g["admm_iters"]))[None]
+    conv = orc.ConvolverOracle(g["admm_psf"], pad=True, norm="backward")
+    assert rel(orc.reconstruction_error(conv, pred, o.data), g["admm_err"]) <= 2e-5
+    assert rel(orc.reconstruction_error(conv, pred, o.data, normalize=False), g["admm_err_raw"]) <= 2e-5
+    f = orc.GDOracle(g["fista_psf"], kind="fista")
+    f.set_data(g["fista_data"])
+    pred = f.apply(int(g["fista_iters"]))[None]
+    assert rel(orc.reconstruction_error(f.conv, pred, f.data), g["fista_err"]) <= 2e-5
+    assert rel(orc.reconstruction_error(f.conv, pred, f.data, normalize=False), g["fista_err_raw"]) <= 2e-5
+    conv3 = orc.ConvolverOracle(g["x_psf"], pad=True, norm="ortho")
+    err = orc.reconstruction_error(conv3, torch.from_numpy(g["x_pred"]), torch.from_numpy(g["x_frames"]))
+    assert rel(err, g["x_err"]) <= 2e-5
+
+
+def _shrink(x):
+    return torch.clamp(x - 0.05, min=0)
+
+
+def test_custom_projection_and_denoiser_hook_match_reference():
+    """gd.py:67,89-92,136-140: `proj=` callables / a denoiser standing in for the projection."""
+    g = np.load(os.path.join(GOLDEN, "pnp_hook.npz"))
+    n = int(g["iters"])
+    for nm, kind in (("gd", "vanilla"), ("nesterov", "nesterov"), ("fista", "fista")):
+        o = orc.GDOracle(g["psf"], kind=kind, proj=_shrink)
+        o.set_data(g["data"])
+        assert rel(o.apply(n), g[nm + "_final"]) <= 1e-6
+        assert rel(o.x, g[nm + "_state"]) <= 1e-6
+    nl = float(g["noise_level"])
+    o = orc.GDOracle(g["psf"], kind="fista", proj=lambda x: torch.clamp(x, min=0) * (1.0 - nl / 100.0))
+    o.set_data(g["data"])
+    assert rel(o.apply(n), g["pnp_final"]) <= 1e-6

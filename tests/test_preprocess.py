@@ -1,0 +1,104 @@
+"""Raw-frame preparation on the device against the reference's own outputs
+(tests/golden/preprocess.npz: lensless.utils.io.load_data / load_image run on .npy inputs) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from lenslesspicam_amd import prep
+from oracle import preprocess_oracle as po
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+CASES = {
+    "a": dict(flip=True, normalize=True),
+    "b": dict(flip_ud=True, gray=True, normalize=True),
+    "c": dict(single_psf=True, flip_lr=True),
+    "d": dict(normalize=True, dtype="float64"),
+    "e": dict(normalize=True, bg_pix=None),
+}
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = np.asarray(b)
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))) / max(np.max(np.abs(b)), 1e-300))
+
+
+def test_oracle_matches_reference_vectors():
+    g = np.load(os.path.join(GOLDEN, "preprocess.npz"))
+    for tag, kw in CASES.items():
+        kw = dict(kw)
+        if "dtype" in kw:
+            kw["dtype"] = np.float64
+        psf, data, bg = po.preprocess_pair(g[tag + "_raw_psf"], g[tag + "_raw_data"], **kw)
+        assert psf.shape == g[tag + "_psf"].shape and data.shape == g[tag + "_data"].shape
+        assert rel(psf, g[tag + "_psf"]) == 0.0 and rel(data, g[tag + "_data"]) == 0.0
+        if g[tag + "_bg"].size:
+            assert rel(bg, g[tag + "_bg"]) == 0.0
+    out = po.preprocess_frame(g["f_raw"], bg=g["f_bg"], flip=True, flip_ud=True, normalize=False)
+    assert rel(out, g["f_out"]) == 0.0
+
+
+@pytest.mark.parametrize("tag", sorted(CASES))
+def test_load_data_golden(backend, tag):
+    """float32: window mean / energy are accumulated in double on the device, in float32 pairwise sums by NumPy:
+    agreement to a few float32 ulps of the normalisers, not bit-exact."""
+    g = np.load(os.path.join(GOLDEN, "preprocess.npz"))
+    kw = dict(CASES[tag])
+    psf, data, bg = prep.preprocess_data(g[tag + "_raw_psf"], g[tag + "_raw_data"], return_bg=True, **kw)
+    tol = 1e-6 if kw.get("dtype") != "float64" else 2e-7    # "d": the reference prepares the frame in float32
+    assert tuple(psf.shape) == g[tag + "_psf"].shape and tuple(data.shape) == g[tag + "_data"].shape
+    assert rel(psf, g[tag + "_psf"]) <= tol
+    assert rel(data, g[tag + "_data"]) <= tol
+    if g[tag + "_bg"].size:
+        assert rel(bg, g[tag + "_bg"]) <= tol
+
+
+def test_load_image_golden_float_frame_pixel_background(backend):
+    g = np.load(os.path.join(GOLDEN, "preprocess.npz"))
+    out = prep.preprocess_frames(g["f_raw"], bg=g["f_bg"], flip=True, flip_ud=True, normalize=False)
+    assert tuple(out.shape) == g["f_out"].shape
+    assert rel(out, g["f_out"]) == 0.0          # pure float32 element-wise work: bit-exact
+
+
+@pytest.mark.parametrize("dt,maxv", [(np.uint8, 200), (np.uint16, 1000), (np.uint16, 5000), (np.float32, 1.0)])
+def test_batched_frames_match_oracle(backend, dt, maxv):
+    rng = np.random.default_rng(3)
+    raw = (rng.random((3, 21, 30, 3)) * maxv).astype(dt)
+    bg = np.array([0.02, 0.05, 0.03], dtype=np.float32)
+    if dt == np.float32:
+        bg = bg * 0.5
+    out = prep.preprocess_frames(raw, bg=bg, flip_lr=True, bgr_input=True, normalize=True, gray=True)
+    for b in range(3):
+        ref = po.preprocess_frame(raw[b], bg=bg, flip_lr=True, bgr_input=True, normalize=True)
+        ref = po.rgb2gray(ref).astype(np.float32)
+        assert rel(out[b:b + 1], ref) <= 2e-7
+    # every frame is normalised by its OWN maximum
+    plain = prep.preprocess_frames(raw, normalize=True)
+    assert float(plain.reshape(3, -1).max(dim=1).values.min()) == 1.0
+
+
+def test_prepared_arrays_feed_the_solver(backend):
+    import lenslesspicam_amd as lpa
+    from oracle import lensless_oracle as orc
+
+    g = np.load(os.path.join(GOLDEN, "preprocess.npz"))
+    psf, data = prep.preprocess_data(g["a_raw_psf"], g["a_raw_data"], flip=True, normalize=True)
+    rec = lpa.ADMM(psf, tau=2e-6, mu2=1e-4)
+    rec.set_data(data)
+    got = rec.apply(n_iter=4, disp_iter=None)
+    o = orc.ADMMOracle(g["a_psf"], tau=2e-6, mu2=1e-4)
+    o.set_data(g["a_data"][0])
+    assert rel(got, o.apply(4)) <= 1e-5
+
+
+def test_rejects_bad_arguments(backend):
+    with pytest.raises(ValueError):
+        prep.preprocess_frames(np.zeros((4, 4, 3), dtype=np.int32))
+    from lenslesspicam_amd._native import NativeError
+    with pytest.raises(NativeError):
+        prep.preprocess_psf(np.ones((1, 8, 8, 3), dtype=np.uint8), bg_pix=(5, 25))   # window outside the frame
+    with pytest.raises(AssertionError):
+        prep.preprocess_frames(np.ones((4, 4, 3), dtype=np.uint8), bg=np.array([0.1, 0.2]))
