@@ -227,6 +227,9 @@ static int plan_from_radices(Engine* e, Fft1dPlan& p, int n, const std::vector<i
     if (!(p.ns[st] % 8 == 0 || (p.ns[st] == 1 && p.radix[st] % 8 == 0))) p.skew_ok = 0;
   }
   if (std::getenv("LPC_NO_SKEW")) p.skew_ok = 0;
+  // diagnostic only (results are garbage): no butterflies at all, every pass degenerates to "tile in, tile out"
+  // through LDS -- times the memory access pattern of the passes alone (profiles/r01b_notes.md)
+  if (std::getenv("LPC_DEBUG_NOFFT")) p.nst = 0;
   real2* tw = nullptr;
   LPC_OK(make_twiddles(e, n, &tw));
   p.tw = tw;
