@@ -88,6 +88,8 @@ struct lpc_engine {
   int T = 16;          // image columns per column-pass tile
   Fft1dPlan planW{}, planA{}, planB{};
   Fft1dPlan planWi{};   // inverse-row plan with the radix-2 stage FIRST (rows_r2 only)
+  Fft1dPlan planWh{};   // length Wp/2: ADMM rows, one real row per half-length transform (rows_half)
+  bool rows_half = false;
   bool rows_r2 = false; // row plans end in a radix-2 stage: fold it into the Hermitian (un)tangling
   ColPass passA{}, passB{};
   int P = 0, Ppsf = 0, Pdata = 0;
@@ -339,6 +341,9 @@ static int setup_geometry(Engine* e) {
     LPC_OK(plan_from_radices(e, e->planWi, g.Wp, rad));
     e->planWi.skew_ok = 0;
   }
+  // ADMM row passes: one real row per half-length complex transform (k_rfwd_half / k_rinv_half)
+  e->rows_half = c.algo == LPC_ALGO_ADMM && g.Wp % 2 == 0 && g.Wp >= 4 && !std::getenv("LPC_ROWS_PAIRED");
+  if (e->rows_half) LPC_OK(build_plan(e, e->planWh, g.Wp / 2));
   LPC_OK(build_plan(e, e->planB, e->N2));
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
@@ -645,6 +650,15 @@ static int admm_iterate(Engine* e, int n_iter) {
     e->vw_cur = false;
     e->ecur ^= 1;
     e->first = false;
+    if (e->rows_half) {
+      LPC_OK(dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
+        constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
+        constexpr bool sk = decltype(SK)::value;
+        return launch_k(e, LPC_K_ROW_FWD, k_rfwd_half<nt, em, sk>, dim3(2 * g.Hp, e->P), nt,
+                        LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real*)e->Rsp,
+                        (const real*)e->Aarr, SA, SB);
+      }));
+    } else
     LPC_OK(dispatch_row(g.Wp, e->planW.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
       constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
@@ -666,6 +680,15 @@ static int admm_iterate(Engine* e, int n_iter) {
     }
     if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, true, 0, g.Hp, LPC_K_COL_A_INV));
     const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
+    if (e->rows_half) {
+      LPC_OK(dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
+        constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
+        constexpr bool sk = decltype(SK)::value;
+        return launch_k(e, LPC_K_ROW_INV, k_rinv_half<nt, em, sk>, dim3(2 * g.Hp, e->P), nt,
+                        LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real2*)SA,
+                        (const real2*)SB, Vo, e->HVb[e->hcur ^ 1]);
+      }));
+    } else
     LPC_OK(dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
       constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;

@@ -175,6 +175,79 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
   else untangle_store<NT, SK>(s, g.Wp, g.Wc, oa, ob, true, tid);
 }
 
+// ---- ADMM rows, one real row per HALF-length complex transform ---------------------------------------
+// Even / odd packing: z[j] = x[2j] + i x[2j+1], Z = FFT_M(z), M = Wp/2, then
+//   X[k] = E + w^k O,  X[M-k] = conj(E - w^k O),   E = (Z[k] + conj Z[M-k])/2,  O = -i (Z[k] - conj Z[M-k])/2,
+// w = exp(-2 pi i / Wp).  Same arithmetic per row as pairing two arrays in one length-Wp transform, but the tile
+// is half as large (4 workgroups of 256 threads per CU instead of 2 of 512 at Wp = 8192): measured on MI355X the
+// row passes are bound by compute that two workgroups per CU cannot hide (profiles/r01b_notes.md).
+// blockIdx.x = 2*row + array.  `plan` has length M, `twW` is the length-Wp table.  Needs Wp even.
+template <int NT, int EMAX, bool SK>
+__global__ __launch_bounds__(NT) void k_rfwd_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+                                                   const real* LPC_RESTRICT A, const real* LPC_RESTRICT B,
+                                                   real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB) {
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int tid = threadIdx.x, row = blockIdx.x >> 1, arr = blockIdx.x & 1;
+  const long pl = blockIdx.y;
+  const real2* a2 = (const real2*)((arr ? B : A) + pl * g.rplane + (long)row * g.rpitch);
+  auto src = [&](int i, int) { return a2[i]; };
+  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
+  real2* o = (arr ? SB : SA) + pl * g.cplane + (long)row * g.cpitch;
+  const int M = g.Wp >> 1;
+  for (int k = tid; k <= M / 2; k += NT) {
+    const int km = M - k;
+    const real2 zk = s[lds_slot<SK>(k)];
+    const real2 zm = s[lds_slot<SK>(k == 0 ? 0 : km)];
+    const real ex = (real)0.5 * (zk.x + zm.x), ey = (real)0.5 * (zk.y - zm.y);
+    const real2 od = make_real2((real)0.5 * (zk.y + zm.y), (real)-0.5 * (zk.x - zm.x));   // O
+    const real2 wo = cmul(twW[k], od);
+    o[k] = make_real2(ex + wo.x, ey + wo.y);
+    if (k != km) o[km] = make_real2(ex - wo.x, wo.y - ey);
+  }
+}
+
+// inverse: Z[k] = E' + i O',  Z[M-k] = conj(E') + i conj(O'),  E' = X[k] + conj X[M-k],
+// O' = (X[k] - conj X[M-k]) conj(w^k); the unnormalised inverse FFT_M of Z is (x[2j], x[2j+1]).
+// irfft semantics: the imaginary parts of the DC and Nyquist bins are ignored.
+template <int NT, int EMAX, bool SK>
+__global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+                                                   const real2* LPC_RESTRICT SA, const real2* LPC_RESTRICT SB,
+                                                   real* LPC_RESTRICT A, real* LPC_RESTRICT B) {
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int tid = threadIdx.x, row = blockIdx.x >> 1, arr = blockIdx.x & 1;
+  const long pl = blockIdx.y;
+  const real2* in = (arr ? SB : SA) + pl * g.cplane + (long)row * g.cpitch;
+  const int M = g.Wp >> 1;
+  constexpr int EH = EMAX / 2 + 1;
+  real2 xk[EH], xm[EH];
+#pragma unroll
+  for (int q = 0; q < EH; ++q) {          // every spectrum element is loaded once; all loads before the LDS writes
+    const int k = tid + q * NT;
+    xk[q] = make_real2((real)0., (real)0.);
+    xm[q] = xk[q];
+    if (k <= M / 2) { xk[q] = in[k]; xm[q] = in[M - k]; }
+  }
+#pragma unroll
+  for (int q = 0; q < EH; ++q) {
+    const int k = tid + q * NT;
+    if (k <= M / 2) {
+      real2 a = xk[q], b = xm[q];
+      if (k == 0) { a.y = (real)0.; b.y = (real)0.; }
+      const real2 e = make_real2(a.x + b.x, a.y - b.y);            // E'
+      const real2 d = make_real2(a.x - b.x, a.y + b.y);            // X[k] - conj X[M-k]
+      const real2 od = cmul_conj(d, twW[k]);                       // O'
+      s[lds_slot<SK>(k)] = make_real2(e.x - od.y, e.y + od.x);
+      if (k != 0 && k != M - k) s[lds_slot<SK>(M - k)] = make_real2(e.x + od.y, od.x - e.y);
+    }
+  }
+  __syncthreads();
+  real2* o2 = (real2*)((arr ? B : A) + pl * g.rplane + (long)row * g.rpitch);
+  auto out = [&](int i, int, real2 v) { o2[i] = v; };
+  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
+}
+
 // ---- forward, generic: rows (2b, 2b+1) of ONE real source -> spectrum rows ------------
 struct RealSrc {
   const real* base;
