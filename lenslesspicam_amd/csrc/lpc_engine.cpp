@@ -90,6 +90,7 @@ struct lpc_engine {
   Fft1dPlan planWi{};   // inverse-row plan with the radix-2 stage FIRST (rows_r2 only)
   Fft1dPlan planWh{};   // length Wp/2: ADMM rows, one real row per half-length transform (rows_half)
   bool rows_half = false;
+  bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (LPC_MID_LDS=1: off)
   bool rows_r2 = false; // row plans end in a radix-2 stage: fold it into the Hermitian (un)tangling
   ColPass passA{}, passB{};
   int P = 0, Ppsf = 0, Pdata = 0;
@@ -342,6 +343,7 @@ static int setup_geometry(Engine* e) {
     e->planWi.skew_ok = 0;
   }
   // ADMM row passes: one real row per half-length complex transform (k_rfwd_half / k_rinv_half)
+  e->mid_reg = !std::getenv("LPC_MID_LDS");
   e->rows_half = c.algo == LPC_ALGO_ADMM && g.Wp % 2 == 0 && g.Wp >= 4 && !std::getenv("LPC_ROWS_PAIRED");
   if (e->rows_half) LPC_OK(build_plan(e, e->planWh, g.Wp / 2));
   LPC_OK(build_plan(e, e->planB, e->N2));
@@ -446,6 +448,11 @@ static int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, 
   cp.zr1 = split ? g.Hp : zr1;
   const dim3 grid(cp.G * cp.ntile_c, nplanes);
   const real hscale = (real)1.0 / ((real)g.Hp * (real)g.Wp);
+  if (split && cp.N == 48 && e->mid_reg) {   // one lane = one 48-point column transform, all in registers
+    const dim3 rgrid((g.Wc + 63) / 64, cp.G, nplanes);
+    LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_mul_reg<8, 6>, rgrid, 64, 0, g, e->planB, cp, S,
+                    (const real2*)e->Hs, adjoint ? 1 : 0, hscale, e->Ppsf));
+  } else
   LPC_OK(dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
     return launch_k(e, LPC_K_COL_MID, k_cols_mid_mul<nt, em>, grid, nt, (size_t)cp.N * cp.T * sizeof(real2), g,

@@ -467,6 +467,82 @@ __global__ __launch_bounds__(NT) void k_cols_mid_mul(PlaneGeom g, Fft1dPlan plan
   fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL>(s, plan, T, cp.tdiv, tid, LdsNatural{}, out);
 }
 
+// ---- register-resident middle (split column passes, short pass-B transforms) ---------------------------
+// When the fused middle transform is short (N = R1*R2 <= 64, e.g. 48 = 8*6 at 6144 rows) ONE LANE can hold a whole
+// column transform: N complex values in VGPRs, two-factor Cooley-Tukey with compile-time indices -- no LDS, no
+// barriers, no index arithmetic, twiddles at constant table offsets (scalar loads).  A wave covers 64 adjacent
+// columns, so every row access is one 512-byte segment.  Measured on MI355X (profiles/r01b_notes.md) the LDS
+// version of this kernel spent a third of its time on un-hidden butterflies.
+//
+// forward: x[j1*R2 + j2] = element n = j1*R2 + j2 (natural)  ->  x[k1*R2 + k2] = X[k1 + R1*k2]
+template <int R1, int R2>
+static __device__ __forceinline__ void reg_fft_fwd(real2* x, const real2* LPC_RESTRICT tw) {
+  constexpr int N = R1 * R2;
+#pragma unroll
+  for (int j2 = 0; j2 < R2; ++j2) {
+    real2 v[R1];
+#pragma unroll
+    for (int j1 = 0; j1 < R1; ++j1) v[j1] = x[j1 * R2 + j2];
+    Dft<R1, false>::run(v);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) x[k1 * R2 + j2] = (k1 * j2) ? cmul(v[k1], tw[(k1 * j2) % N]) : v[k1];
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < R1; ++k1) Dft<R2, false>::run(x + k1 * R2);
+}
+// inverse (unnormalised): x[k1*R2 + k2] = X[k1 + R1*k2] (what reg_fft_fwd leaves)  ->  x[s] = element s (natural)
+template <int R1, int R2>
+static __device__ __forceinline__ void reg_fft_inv(real2* x, const real2* LPC_RESTRICT tw) {
+  constexpr int N = R1 * R2;
+#pragma unroll
+  for (int k1 = 0; k1 < R1; ++k1) {           // length-R2 transforms over k2, then the twiddle w^(m1*k1)
+    Dft<R2, true>::run(x + k1 * R2);
+#pragma unroll
+    for (int m1 = 0; m1 < R2; ++m1)
+      if (m1 * k1) x[k1 * R2 + m1] = cmul_conj(x[k1 * R2 + m1], tw[(m1 * k1) % N]);
+  }
+#pragma unroll
+  for (int m1 = 0; m1 < R2; ++m1) {           // length-R1 transforms over k1: output m1 + R2*m2 at slot m2*R2 + m1
+    real2 v[R1];
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) v[k1] = x[k1 * R2 + m1];
+    Dft<R1, true>::run(v);
+#pragma unroll
+    for (int m2 = 0; m2 < R1; ++m2) x[m2 * R2 + m1] = v[m2];
+  }
+}
+
+// fused middle of a convolution, register-resident (same contract as k_cols_mid_mul; split passes only:
+// cp.istride == 1, every row valid).  grid = (ceil(Wc/64), groups, planes), 64 threads.
+template <int R1, int R2>
+__global__ __launch_bounds__(64) void k_cols_mid_mul_reg(PlaneGeom g, Fft1dPlan plan, ColPass cp,
+                                                          real2* LPC_RESTRICT S, const real2* LPC_RESTRICT Hs,
+                                                          int conjH, real hscale, int psf_planes) {
+  constexpr int N = R1 * R2;
+  const int col = (int)blockIdx.x * 64 + (int)threadIdx.x;
+  if (col >= g.Wc) return;
+  const long rowoff = (long)blockIdx.y * cp.gstride * g.cpitch + col;
+  real2* base = S + (long)blockIdx.z * g.cplane + rowoff;
+  const real2* hb = Hs + (long)((int)blockIdx.z % psf_planes) * g.cplane + rowoff;
+  real2 x[N], h[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) x[n] = base[(long)n * g.cpitch];
+#pragma unroll
+  for (int n = 0; n < N; ++n) h[n] = hb[(long)n * g.cpitch];
+  reg_fft_fwd<R1, R2>(x, plan.tw);
+  const real hs = conjH ? -hscale : hscale;
+#pragma unroll
+  for (int k1 = 0; k1 < R1; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) {
+      const real2 hh = make_real2(h[k1 + R1 * k2].x * hscale, h[k1 + R1 * k2].y * hs);   // H or conj(H), scaled
+      x[k1 * R2 + k2] = cmul(x[k1 * R2 + k2], hh);
+    }
+  reg_fft_inv<R1, R2>(x, plan.tw);
+#pragma unroll
+  for (int n = 0; n < N; ++n) base[(long)n * g.cpitch] = x[n];
+}
+
 // fused middle of one ADMM iteration (4-FFT form).  In: SA = rows+colsA transform of
 // r_sp, SB = same of a = mu1 X - xi.  After forward pass B:
 //   Vh  = Rdiv * (Rh + s * conj(H) * Ah)        (Rdiv formed in-kernel, includes 1/(Hp*Wp))

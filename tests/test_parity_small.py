@@ -280,3 +280,29 @@ def test_rows_with_radix2_tail_fold_it_into_the_tangling(backend, shape, dtype):
         og = orc.GDOracle(psf, kind=kind, dtype=tdt)
         og.set_data(y)
         assert rel(g.apply(n_iter=8, disp_iter=None), og.apply(8)) <= 2 * tol, kind
+
+
+@pytest.mark.parametrize("n2", [48, 12])
+def test_forced_four_step_column_split(backend, monkeypatch, n2):
+    """The split column passes (pass A + fused middle + inverse pass A) normally start at ~1000 padded rows;
+    tuning knobs force them on a 96-row padded frame so that the CPU suite executes those kernels too:
+    96 = 2 x 48 (the register-resident 48-point middle) and 96 = 8 x 12 (the LDS middle)."""
+    monkeypatch.setenv("LPC_TILE_BUDGET", "512")
+    monkeypatch.setenv("LPC_COL_T", "4")
+    monkeypatch.setenv("LPC_SPLIT_N2", str(n2))
+    psf = orc.synthetic_psf(1, 48, 20, 3, seed=8)
+    y = np.random.default_rng(8).random((48, 20, 3), dtype=np.float32)
+    rec = lpa.ADMM(torch.from_numpy(psf), tau=2e-6, mu2=1e-4)
+    assert rec._padded_shape[1] == 96
+    rec.set_data(torch.from_numpy(y))
+    o = orc.ADMMOracle(psf, tau=2e-6, mu2=1e-4)
+    o.set_data(y)
+    assert rel(rec.apply(n_iter=6, disp_iter=None), o.apply(6)) <= 5e-6
+    fis = lpa.FISTA(torch.from_numpy(psf))
+    fis.set_data(torch.from_numpy(y))
+    of = orc.GDOracle(psf, kind="fista")
+    of.set_data(y)
+    assert rel(fis.apply(n_iter=6, disp_iter=None), of.apply(6)) <= 5e-6
+    conv = lpa.RealFFTConvolve2D(torch.from_numpy(psf))
+    x = torch.from_numpy(np.random.default_rng(9).random((1, 48, 20, 3), dtype=np.float32))
+    assert rel(conv.deconvolve(x), of.conv.deconvolve(x)) <= 2e-6
