@@ -342,9 +342,13 @@ static int setup_geometry(Engine* e) {
     LPC_OK(plan_from_radices(e, e->planWi, g.Wp, rad));
     e->planWi.skew_ok = 0;
   }
-  // ADMM row passes: one real row per half-length complex transform (k_rfwd_half / k_rinv_half)
   e->mid_reg = !std::getenv("LPC_MID_LDS");
-  e->rows_half = c.algo == LPC_ALGO_ADMM && g.Wp % 2 == 0 && g.Wp >= 4 && !std::getenv("LPC_ROWS_PAIRED");
+  // ADMM row passes: one real row per half-length complex transform (k_rfwd_half / k_rinv_half) once the
+  // paired tile is so large that fewer than 4 workgroups fit a CU's 160 KiB of LDS.  Measured (r01b_notes.md):
+  // 8192 columns +3 % it/s; 960 columns (C4) -5 %, the short transforms leave most of a 256-thread group idle.
+  const bool half_ok = c.algo == LPC_ALGO_ADMM && g.Wp % 2 == 0 && g.Wp >= 4;
+  e->rows_half = half_ok && 4 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024 && !std::getenv("LPC_ROWS_PAIRED");
+  if (half_ok && std::getenv("LPC_ROWS_HALF")) e->rows_half = true;   // test knob: small frames too
   if (e->rows_half) LPC_OK(build_plan(e, e->planWh, g.Wp / 2));
   LPC_OK(build_plan(e, e->planB, e->N2));
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
@@ -448,11 +452,20 @@ static int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, 
   cp.zr1 = split ? g.Hp : zr1;
   const dim3 grid(cp.G * cp.ntile_c, nplanes);
   const real hscale = (real)1.0 / ((real)g.Hp * (real)g.Wp);
-  if (split && cp.N == 48 && e->mid_reg) {   // one lane = one 48-point column transform, all in registers
+  // one lane = one whole pass-B column transform in registers, for the lengths choose_split produces most
+  auto reg_mid = [&](auto kernel) {
     const dim3 rgrid((g.Wc + 63) / 64, cp.G, nplanes);
-    LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_mul_reg<8, 6>, rgrid, 64, 0, g, e->planB, cp, S,
-                    (const real2*)e->Hs, adjoint ? 1 : 0, hscale, e->Ppsf));
-  } else
+    return launch_k(e, LPC_K_COL_MID, kernel, rgrid, 64, 0, g, e->planB, cp, S, (const real2*)e->Hs,
+                    adjoint ? 1 : 0, hscale, e->Ppsf);
+  };
+  const int regN = (split && e->mid_reg) ? cp.N : 0;
+  if (regN == 48) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 6>)); }
+  else if (regN == 40) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 5>)); }
+  else if (regN == 36) { LPC_OK(reg_mid(k_cols_mid_mul_reg<6, 6>)); }
+  else if (regN == 32) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 4>)); }
+  else if (regN == 30) { LPC_OK(reg_mid(k_cols_mid_mul_reg<6, 5>)); }
+  else if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 3>)); }
+  else
   LPC_OK(dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
     return launch_k(e, LPC_K_COL_MID, k_cols_mid_mul<nt, em>, grid, nt, (size_t)cp.N * cp.T * sizeof(real2), g,

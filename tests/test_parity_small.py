@@ -282,18 +282,20 @@ def test_rows_with_radix2_tail_fold_it_into_the_tangling(backend, shape, dtype):
         assert rel(g.apply(n_iter=8, disp_iter=None), og.apply(8)) <= 2 * tol, kind
 
 
-@pytest.mark.parametrize("n2", [48, 12])
-def test_forced_four_step_column_split(backend, monkeypatch, n2):
+@pytest.mark.parametrize("h,hp,n2", [(48, 96, 48), (48, 96, 12), (48, 96, 24), (48, 96, 32), (60, 120, 30),
+                                     (60, 120, 40), (54, 108, 36)])
+def test_forced_four_step_column_split(backend, monkeypatch, h, hp, n2):
     """The split column passes (pass A + fused middle + inverse pass A) normally start at ~1000 padded rows;
-    tuning knobs force them on a 96-row padded frame so that the CPU suite executes those kernels too:
-    96 = 2 x 48 (the register-resident 48-point middle) and 96 = 8 x 12 (the LDS middle)."""
+    tuning knobs force them on ~100-row padded frames so that the CPU suite executes those kernels too:
+    every pass-B length that has a register-resident middle (48, 40, 36, 32, 30, 24) and one that takes the
+    LDS middle (12)."""
     monkeypatch.setenv("LPC_TILE_BUDGET", "512")
     monkeypatch.setenv("LPC_COL_T", "4")
     monkeypatch.setenv("LPC_SPLIT_N2", str(n2))
-    psf = orc.synthetic_psf(1, 48, 20, 3, seed=8)
-    y = np.random.default_rng(8).random((48, 20, 3), dtype=np.float32)
+    psf = orc.synthetic_psf(1, h, 20, 3, seed=8)
+    y = np.random.default_rng(8).random((h, 20, 3), dtype=np.float32)
     rec = lpa.ADMM(torch.from_numpy(psf), tau=2e-6, mu2=1e-4)
-    assert rec._padded_shape[1] == 96
+    assert rec._padded_shape[1] == hp
     rec.set_data(torch.from_numpy(y))
     o = orc.ADMMOracle(psf, tau=2e-6, mu2=1e-4)
     o.set_data(y)
@@ -304,5 +306,14 @@ def test_forced_four_step_column_split(backend, monkeypatch, n2):
     of.set_data(y)
     assert rel(fis.apply(n_iter=6, disp_iter=None), of.apply(6)) <= 5e-6
     conv = lpa.RealFFTConvolve2D(torch.from_numpy(psf))
-    x = torch.from_numpy(np.random.default_rng(9).random((1, 48, 20, 3), dtype=np.float32))
+    x = torch.from_numpy(np.random.default_rng(9).random((1, h, 20, 3), dtype=np.float32))
     assert rel(conv.deconvolve(x), of.conv.deconvolve(x)) <= 2e-6
+
+
+@pytest.mark.parametrize("name", ["admm_24x32x3_tv", "admm_47x29x3_tv"])
+def test_admm_half_length_row_kernels(backend, monkeypatch, name):
+    """ADMM's row passes switch to one real row per half-length complex transform (k_rfwd_half / k_rinv_half) for
+    wide frames only; LPC_ROWS_HALF forces them on the golden-vector sizes (row transforms of 32 and 30 points,
+    the second one without the LDS skew): same trajectory checks as the regular golden test."""
+    monkeypatch.setenv("LPC_ROWS_HALF", "1")
+    test_admm_matches_reference_golden(backend, name)
