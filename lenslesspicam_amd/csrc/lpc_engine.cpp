@@ -343,10 +343,10 @@ static int setup_geometry(Engine* e) {
     e->planWi.skew_ok = 0;
   }
   e->mid_reg = !std::getenv("LPC_MID_LDS");
-  // ADMM row passes: one real row per half-length complex transform (k_rfwd_half / k_rinv_half) once the
+  // Row passes: one real row per half-length complex transform (k_r*_half kernels) once the
   // paired tile is so large that fewer than 4 workgroups fit a CU's 160 KiB of LDS.  Measured (r01b_notes.md):
   // 8192 columns +3 % it/s; 960 columns (C4) -5 %, the short transforms leave most of a 256-thread group idle.
-  const bool half_ok = c.algo == LPC_ALGO_ADMM && g.Wp % 2 == 0 && g.Wp >= 4;
+  const bool half_ok = g.Wp % 2 == 0 && g.Wp >= 4;
   e->rows_half = half_ok && 4 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024 && !std::getenv("LPC_ROWS_PAIRED");
   if (half_ok && std::getenv("LPC_ROWS_HALF")) e->rows_half = true;   // test knob: small frames too
   if (e->rows_half) LPC_OK(build_plan(e, e->planWh, g.Wp / 2));
@@ -383,6 +383,13 @@ static int setup_geometry(Engine* e) {
 // forward rows of ONE real source (pairs of rows) into spectrum S (planes = nplanes)
 static int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
+  if (e->rows_half)
+    return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NT, auto EM, auto SK, auto) {
+      constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+      constexpr bool sk = decltype(SK)::value;
+      return launch_k(e, kid, k_rfwd_rows_half<nt, em, sk>, dim3(src.nrows, nplanes), nt,
+                      LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, src, S);
+    });
   const int nblk = (src.nrows + 1) / 2;
   return dispatch_row(g.Wp, e->planW.skew_ok, e->rows_r2, [&](auto NT, auto EM, auto SK, auto R2) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
@@ -477,6 +484,13 @@ static int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, 
 
 static int rows_inv_single(Engine* e, const real2* S, const RealDst& dst, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
+  if (e->rows_half)
+    return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NT, auto EM, auto SK, auto) {
+      constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+      constexpr bool sk = decltype(SK)::value;
+      return launch_k(e, kid, k_rinv_rows_half<nt, em, sk>, dim3(dst.nrows, nplanes), nt,
+                      LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, S, dst);
+    });
   const int nblk = (dst.nrows + 1) / 2;
   const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
   return dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NT, auto EM, auto SK, auto R2) {

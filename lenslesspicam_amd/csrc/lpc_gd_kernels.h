@@ -131,6 +131,61 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan pl
                                                   R2 ? 1 : 0, 0);
 }
 
+// ---- the same two kernels with one real row per half-length transform (wide frames, see k_rfwd_half) ----
+template <int NT, int EMAX, bool SK>
+__global__ __launch_bounds__(NT) void k_rinv_gd_mid_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+                                                          const real2* LPC_RESTRICT Sin,
+                                                          real2* LPC_RESTRICT Sout,
+                                                          const real* LPC_RESTRICT Y) {
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int tid = threadIdx.x, u = blockIdx.x;
+  const long pl = blockIdx.y;
+  const int hh = g.Hp / 2, hw = g.Wp / 2, M = g.Wp >> 1;
+  const int sr = wrap_add(g.sh + u, hh, g.Hp);
+  tangle_half_load<NT, EMAX, SK>(s, M, twW, Sin + pl * g.cplane + (long)sr * g.cpitch, tid);
+  __syncthreads();
+  fft_tile<NT, EMAX, true, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
+  // slot j now holds (conv[2j], conv[2j+1]); residual sample m = (m in window) ? conv[(m + Wp/2) mod Wp] - y[m - sw] : 0
+  const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
+  const real* y = Y + (long)dpl * g.uplane + (long)u * g.W;
+  auto sample = [&](int m) {
+    const int c = m - g.sw;
+    if (c < 0 || c >= g.W) return (real)0.;
+    const int q = wrap_add(m, hw, g.Wp);
+    const real2 z = s[lds_slot<SK>(q >> 1)];
+    return ((q & 1) ? z.y : z.x) - y[c];
+  };
+  auto resid = [&](int i, int) { return make_real2(sample(2 * i), sample(2 * i + 1)); };
+  fft_tile<NT, EMAX, false, SK, true, true>(s, plan, 1, make_fastdiv_dev1(), tid, resid, LdsNatural{});
+  untangle_half_store<NT, SK>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
+}
+
+template <int NT, int EMAX, bool SK>
+__global__ __launch_bounds__(NT) void k_rinv_gd_update_half(PlaneGeom g, Fft1dPlan plan,
+                                                             const real2* LPC_RESTRICT twW,
+                                                             const real2* LPC_RESTRICT Sin, real* LPC_RESTRICT X,
+                                                             real* LPC_RESTRICT AUX, const real* LPC_RESTRICT alpha,
+                                                             GdScalars p) {
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int tid = threadIdx.x, u = blockIdx.x;
+  const long pl = blockIdx.y;
+  const int hh = g.Hp / 2, hw = g.Wp / 2;
+  const int sr = wrap_add(g.sh + u, hh, g.Hp);
+  tangle_half_load<NT, EMAX, SK>(s, g.Wp >> 1, twW, Sin + pl * g.cplane + (long)sr * g.cpitch, tid);
+  __syncthreads();
+  const real al = alpha[pl % g.C];
+  const long base = pl * g.uplane + (long)u * g.W;
+  auto upd = [&](int i, int, real2 z) {     // gradient samples 2i, 2i+1 -> shift + crop -> fused update
+    const int c0 = shifted_col(2 * i, hw, g.sw, g.Wp);
+    if (c0 < g.W) gd_update_one(X, AUX, base + c0, z.x, al, p);
+    const int c1 = shifted_col(2 * i + 1, hw, g.sw, g.Wp);
+    if (c1 < g.W) gd_update_one(X, AUX, base + c1, z.y, al, p);
+  };
+  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, upd);
+}
+
 // second half of a split iteration: PROJ = proj(image_est) as the caller computed it, channels-last (n,H,W,C)
 //   vanilla / nesterov: x = PROJ                          gd.py:134,188
 //   fista: x_k = PROJ; x = x_k + coef (x_k - x_{k-1})     gd.py:236-241

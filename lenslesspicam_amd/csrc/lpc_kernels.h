@@ -182,19 +182,10 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
 // is half as large (4 workgroups of 256 threads per CU instead of 2 of 512 at Wp = 8192): measured on MI355X the
 // row passes are bound by compute that two workgroups per CU cannot hide (profiles/r01b_notes.md).
 // blockIdx.x = 2*row + array.  `plan` has length M, `twW` is the length-Wp table.  Needs Wp even.
-template <int NT, int EMAX, bool SK>
-__global__ __launch_bounds__(NT) void k_rfwd_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
-                                                   const real* LPC_RESTRICT A, const real* LPC_RESTRICT B,
-                                                   real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB) {
-  LPC_DYN_SMEM(smem);
-  real2* s = (real2*)smem;
-  const int tid = threadIdx.x, row = blockIdx.x >> 1, arr = blockIdx.x & 1;
-  const long pl = blockIdx.y;
-  const real2* a2 = (const real2*)((arr ? B : A) + pl * g.rplane + (long)row * g.rpitch);
-  auto src = [&](int i, int) { return a2[i]; };
-  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
-  real2* o = (arr ? SB : SA) + pl * g.cplane + (long)row * g.cpitch;
-  const int M = g.Wp >> 1;
+// s[] holds Z = FFT_M(z) in natural order; writes X[0 .. M] (M = Wp/2) to o
+template <int NT, bool SK>
+static __device__ __forceinline__ void untangle_half_store(const real2* s, int M, const real2* LPC_RESTRICT twW,
+                                                            real2* LPC_RESTRICT o, int tid) {
   for (int k = tid; k <= M / 2; k += NT) {
     const int km = M - k;
     const real2 zk = s[lds_slot<SK>(k)];
@@ -207,19 +198,27 @@ __global__ __launch_bounds__(NT) void k_rfwd_half(PlaneGeom g, Fft1dPlan plan, c
   }
 }
 
-// inverse: Z[k] = E' + i O',  Z[M-k] = conj(E') + i conj(O'),  E' = X[k] + conj X[M-k],
-// O' = (X[k] - conj X[M-k]) conj(w^k); the unnormalised inverse FFT_M of Z is (x[2j], x[2j+1]).
-// irfft semantics: the imaginary parts of the DC and Nyquist bins are ignored.
 template <int NT, int EMAX, bool SK>
-__global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
-                                                   const real2* LPC_RESTRICT SA, const real2* LPC_RESTRICT SB,
-                                                   real* LPC_RESTRICT A, real* LPC_RESTRICT B) {
+__global__ __launch_bounds__(NT) void k_rfwd_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+                                                   const real* LPC_RESTRICT A, const real* LPC_RESTRICT B,
+                                                   real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = threadIdx.x, row = blockIdx.x >> 1, arr = blockIdx.x & 1;
   const long pl = blockIdx.y;
-  const real2* in = (arr ? SB : SA) + pl * g.cplane + (long)row * g.cpitch;
-  const int M = g.Wp >> 1;
+  const real2* a2 = (const real2*)((arr ? B : A) + pl * g.rplane + (long)row * g.rpitch);
+  auto src = [&](int i, int) { return a2[i]; };
+  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
+  untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, (arr ? SB : SA) + pl * g.cplane + (long)row * g.cpitch, tid);
+}
+
+// inverse: Z[k] = E' + i O',  Z[M-k] = conj(E') + i conj(O'),  E' = X[k] + conj X[M-k],
+// O' = (X[k] - conj X[M-k]) conj(w^k); the unnormalised inverse FFT_M of Z is (x[2j], x[2j+1]).
+// irfft semantics: the imaginary parts of the DC and Nyquist bins are ignored.
+// builds Z (natural order, length M) in LDS from one half-spectrum row; ends WITHOUT a barrier
+template <int NT, int EMAX, bool SK>
+static __device__ __forceinline__ void tangle_half_load(real2* s, int M, const real2* LPC_RESTRICT twW,
+                                                         const real2* LPC_RESTRICT in, int tid) {
   constexpr int EH = EMAX / 2 + 1;
   real2 xk[EH], xm[EH];
 #pragma unroll
@@ -242,6 +241,17 @@ __global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, Fft1dPlan plan, c
       if (k != 0 && k != M - k) s[lds_slot<SK>(M - k)] = make_real2(e.x + od.y, od.x - e.y);
     }
   }
+}
+
+template <int NT, int EMAX, bool SK>
+__global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+                                                   const real2* LPC_RESTRICT SA, const real2* LPC_RESTRICT SB,
+                                                   real* LPC_RESTRICT A, real* LPC_RESTRICT B) {
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int tid = threadIdx.x, row = blockIdx.x >> 1, arr = blockIdx.x & 1;
+  const long pl = blockIdx.y;
+  tangle_half_load<NT, EMAX, SK>(s, g.Wp >> 1, twW, (arr ? SB : SA) + pl * g.cplane + (long)row * g.cpitch, tid);
   __syncthreads();
   real2* o2 = (real2*)((arr ? B : A) + pl * g.rplane + (long)row * g.rpitch);
   auto out = [&](int i, int, real2 v) { o2[i] = v; };
@@ -279,6 +289,24 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, R
   real2* o = S + pl * g.cplane + (long)(src.out_row0 + r0) * g.cpitch;
   if (R2) untangle_r2_store<NT, SK>(s, g.Wp, plan.tw, o, o + g.cpitch, v1, tid);
   else untangle_store<NT, SK>(s, g.Wp, g.Wc, o, o + g.cpitch, v1, tid);
+}
+
+// one real row per half-length transform (see k_rfwd_half), generic source with pad on load
+template <int NT, int EMAX, bool SK>
+__global__ __launch_bounds__(NT) void k_rfwd_rows_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+                                                        RealSrc src, real2* LPC_RESTRICT S) {
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int tid = threadIdx.x, r = blockIdx.x;
+  const long pl = blockIdx.y;
+  const real* a = src.base + pl * src.plane_stride + (long)r * src.pitch;
+  auto in = [&](int i, int) {   // z[i] = (x[2i], x[2i+1]), x zero outside [col0, col0 + ncols)
+    const int c = 2 * i - src.col0;
+    return make_real2((c >= 0 && c < src.ncols) ? a[c] : (real)0.,
+                      (c + 1 >= 0 && c + 1 < src.ncols) ? a[c + 1] : (real)0.);
+  };
+  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, in, LdsNatural{});
+  untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, S + pl * g.cplane + (long)(src.out_row0 + r) * g.cpitch, tid);
 }
 
 // ---- inverse, ADMM: spectra SA, SB -> real arrays A, B (no shift, padded) ---------------
@@ -354,6 +382,28 @@ __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
   };
   fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out, NoFix{},
                                                   R2 ? 1 : 0, 0);
+}
+
+// one real row per half-length transform, generic sink with ifftshift (+ crop)
+template <int NT, int EMAX, bool SK>
+__global__ __launch_bounds__(NT) void k_rinv_rows_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+                                                        const real2* LPC_RESTRICT S, RealDst dst) {
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int tid = threadIdx.x, r = blockIdx.x;
+  const long pl = blockIdx.y;
+  const int hh = g.Hp / 2, hw = g.Wp / 2;
+  const int sr = wrap_add(dst.row0 + r, hh, g.Hp);
+  tangle_half_load<NT, EMAX, SK>(s, g.Wp >> 1, twW, S + pl * g.cplane + (long)sr * g.cpitch, tid);
+  __syncthreads();
+  real* a = dst.base + pl * dst.plane_stride + (long)r * dst.pitch;
+  auto out = [&](int i, int, real2 v) {     // samples 2i and 2i+1 of the row
+    const int c0 = shifted_col(2 * i, hw, dst.col0, g.Wp);
+    if (c0 < dst.ncols) a[c0] = v.x;
+    const int c1 = shifted_col(2 * i + 1, hw, dst.col0, g.Wp);
+    if (c1 < dst.ncols) a[c1] = v.y;
+  };
+  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
 }
 
 #ifndef LPC_MID_FUSE1
