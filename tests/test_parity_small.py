@@ -317,3 +317,20 @@ def test_admm_half_length_row_kernels(backend, monkeypatch, name):
     the second one without the LDS skew): same trajectory checks as the regular golden test."""
     monkeypatch.setenv("LPC_ROWS_HALF", "1")
     test_admm_matches_reference_golden(backend, name)
+
+
+@pytest.mark.parametrize("name", ["gd_24x32x3", "nesterov_24x32x3", "fista_24x32x3", "fista_47x29x3_d3",
+                                  "fista_24x32x1_f64"])
+def test_gd_family_half_length_row_kernels(backend, monkeypatch, name):
+    """Same for the gradient-descent family: pad-on-load forward rows, the irfft -> residual -> rfft kernel and the
+    fused update, each with one real row per half-length transform (k_rfwd_rows_half, k_rinv_gd_mid_half,
+    k_rinv_gd_update_half), float32 and float64, depth 3, 32- and 30-point row transforms."""
+    monkeypatch.setenv("LPC_ROWS_HALF", "1")
+    test_gd_family_matches_reference_golden(backend, name)
+
+
+def test_convolver_half_length_row_kernels(backend, monkeypatch):
+    monkeypatch.setenv("LPC_ROWS_HALF", "1")
+    for tag in ("a", "b", "c"):
+        test_convolver_golden(backend, tag)
+    test_convolver_slice_commutes(backend)
