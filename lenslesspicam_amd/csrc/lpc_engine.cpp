@@ -704,6 +704,17 @@ static int admm_iterate(Engine* e, int n_iter) {
       ColPass cp = e->passB;
       const dim3 grid(cp.G * cp.ntile_c, e->P);
       const FastDiv t2 = make_fastdiv((unsigned)(2 * cp.T));
+      auto reg_mid = [&](auto kernel) {
+        const dim3 rgrid((g.Wc + 63) / 64, cp.G, e->P);
+        return launch_k(e, LPC_K_COL_MID, kernel, rgrid, 64, 0, g, e->planB, cp, SA, SB, (const real2*)e->Hs,
+                        (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, sc.mu1, sc.mu2, sc.mu3,
+                        (real)1.0 / ((real)g.Hp * (real)g.Wp));
+      };
+      const int regN = (split && e->mid_reg) ? cp.N : 0;
+      // two arrays per lane: only the 24-point pass B fits the register file (measured: 24 points 0.89 vs 0.99 ms
+      // at 12 MP, 32 points 1.32 vs 0.92 ms, 48 points 2.63 vs 0.98 ms -- profiles/r01b_notes.md)
+      if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_admm_reg<8, 3>)); }
+      else
       LPC_OK(dispatch_cfg(cp.N * cp.T * 2, [&](auto NTc, auto EM) {
         constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
         return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<nt, em>, grid, nt,

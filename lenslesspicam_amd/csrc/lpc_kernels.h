@@ -593,6 +593,66 @@ __global__ __launch_bounds__(64) void k_cols_mid_mul_reg(PlaneGeom g, Fft1dPlan 
   for (int n = 0; n < N; ++n) base[(long)n * g.cpitch] = x[n];
 }
 
+// fused middle of one ADMM iteration, register-resident (same contract as k_cols_mid_admm below; split passes
+// only, SHORT pass-B transforms: the lane holds 2 x N complex values).  One lane owns column c of BOTH spectra,
+// one after the other: a = FFT(SB column) is turned into t = s conj(H) a in place, then r = FFT(SA column),
+// Vh = Rdiv (r + t) and HVh = s H Vh overwrite the two register arrays, which are inverse-transformed and stored.
+// The row phases are wave-uniform (scalar loads), H is simply read twice.
+// grid = (ceil(Wc/64), groups, planes), 64 threads.
+template <int R1, int R2>
+__global__ __launch_bounds__(64) void k_cols_mid_admm_reg(PlaneGeom g, Fft1dPlan plan, ColPass cp,
+                                                           real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB,
+                                                           const real2* LPC_RESTRICT Hs,
+                                                           const real* LPC_RESTRICT Gabs,
+                                                           const real2* LPC_RESTRICT phr,
+                                                           const real2* LPC_RESTRICT phc, real mu1, real mu2,
+                                                           real mu3, real rscale) {
+  constexpr int N = R1 * R2;
+  const int col = (int)blockIdx.x * 64 + (int)threadIdx.x;
+  if (col >= g.Wc) return;
+  const int row0 = (int)blockIdx.y * cp.gstride;
+  const long rowoff = (long)row0 * g.cpitch + col;
+  real2* ba = SA + (long)blockIdx.z * g.cplane + rowoff;
+  real2* bb = SB + (long)blockIdx.z * g.cplane + rowoff;
+  const real2* hb = Hs + (long)((int)blockIdx.z % g.DC) * g.cplane + rowoff;
+  const real* gb = Gabs + rowoff;
+  const real2* pr = phr + row0;
+  const real2 pc = phc[col];
+  real2 a[N], r[N];
+#pragma unroll
+  for (int n = 0; n < N; ++n) a[n] = bb[(long)n * g.cpitch];
+#pragma unroll
+  for (int n = 0; n < N; ++n) r[n] = ba[(long)n * g.cpitch];
+  reg_fft_fwd<R1, R2>(a, plan.tw);
+#pragma unroll
+  for (int k1 = 0; k1 < R1; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) {          // slot k1*R2 + k2 holds frequency k = k1 + R1*k2
+      const int k = k1 + R1 * k2;
+      a[k1 * R2 + k2] = cmul(cmul_conj(a[k1 * R2 + k2], hb[(long)k * g.cpitch]), cmul(pr[k], pc));   // s conj(H) Ah
+    }
+  reg_fft_fwd<R1, R2>(r, plan.tw);
+#pragma unroll
+  for (int k1 = 0; k1 < R1; ++k1)
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) {
+      const int k = k1 + R1 * k2, sl = k1 * R2 + k2;
+      const real2 hh = hb[(long)k * g.cpitch];
+      // R_divmat = 1 / (mu1 |H* H| + mu2 |PsiT Psi| + mu3)  (admm.py:186-190); rscale folds 1/(Hp*Wp)
+      const real rdiv =
+          rscale * ((real)1.0 / (mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * gb[(long)k * g.cpitch] + mu3));
+      const real2 vh = cscale(cadd(r[sl], a[sl]), rdiv);
+      r[sl] = vh;
+      a[sl] = cmul(cmul(vh, hh), cmul(pr[k], pc));
+    }
+  reg_fft_inv<R1, R2>(r, plan.tw);
+#pragma unroll
+  for (int n = 0; n < N; ++n) ba[(long)n * g.cpitch] = r[n];
+  reg_fft_inv<R1, R2>(a, plan.tw);
+#pragma unroll
+  for (int n = 0; n < N; ++n) bb[(long)n * g.cpitch] = a[n];
+}
+
 // fused middle of one ADMM iteration (4-FFT form).  In: SA = rows+colsA transform of
 // r_sp, SB = same of a = mu1 X - xi.  After forward pass B:
 //   Vh  = Rdiv * (Rh + s * conj(H) * Ah)        (Rdiv formed in-kernel, includes 1/(Hp*Wp))
