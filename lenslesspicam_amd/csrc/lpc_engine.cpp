@@ -711,8 +711,9 @@ static int admm_iterate(Engine* e, int n_iter) {
                         (real)1.0 / ((real)g.Hp * (real)g.Wp));
       };
       const int regN = (split && e->mid_reg) ? cp.N : 0;
-      // two arrays per lane: only the 24-point pass B fits the register file (measured: 24 points 0.89 vs 0.99 ms
-      // at 12 MP, 32 points 1.32 vs 0.92 ms, 48 points 2.63 vs 0.98 ms -- profiles/r01b_notes.md)
+      // two arrays per lane: only short pass-B transforms fit the register file.  Measured at 12 MP
+      // (profiles/r01b_notes.md): 24 points 0.89 ms and 32 points 0.83 ms beat the LDS middle (0.99 / 0.92 ms) but
+      // need a 256- / 192-point pass A that costs more than it saves; 48 points is 1.62 ms (AGPR traffic).
       if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_admm_reg<8, 3>)); }
       else
       LPC_OK(dispatch_cfg(cp.N * cp.T * 2, [&](auto NTc, auto EM) {

@@ -562,6 +562,21 @@ static __device__ __forceinline__ void reg_fft_inv(real2* x, const real2* LPC_RE
   }
 }
 
+// keeps the instruction scheduler from hoisting every load of a later phase to the top (which costs more
+// registers than the lane has: measured 996 bytes of scratch per lane without the fences)
+#if defined(LPC_SIMT_EMU)
+#define LPC_SCHED_FENCE() ((void)0)
+#else
+#define LPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+template <class T>
+static __device__ __forceinline__ T ld_off(const T* LPC_RESTRICT ubase, unsigned byte_off) {
+  return *(const T*)((const char*)ubase + byte_off);
+}
+template <class T>
+static __device__ __forceinline__ void st_off(T* LPC_RESTRICT ubase, unsigned byte_off, T v) {
+  *(T*)((char*)ubase + byte_off) = v;
+}
 // fused middle of a convolution, register-resident (same contract as k_cols_mid_mul; split passes only:
 // cp.istride == 1, every row valid).  grid = (ceil(Wc/64), groups, planes), 64 threads.
 template <int R1, int R2>
@@ -571,6 +586,9 @@ __global__ __launch_bounds__(64) void k_cols_mid_mul_reg(PlaneGeom g, Fft1dPlan 
   constexpr int N = R1 * R2;
   const int col = (int)blockIdx.x * 64 + (int)threadIdx.x;
   if (col >= g.Wc) return;
+  // plain 64-bit addresses on purpose: with wave-uniform bases + 32-bit offsets this kernel needs 58 instead of
+  // 214 AGPRs but runs 65 % slower (0.62 vs 0.38 ms at 12 MP) -- the hoisted address arithmetic is what lets
+  // all 2N loads of a lane be in flight at once
   const long rowoff = (long)blockIdx.y * cp.gstride * g.cpitch + col;
   real2* base = S + (long)blockIdx.z * g.cplane + rowoff;
   const real2* hb = Hs + (long)((int)blockIdx.z % psf_planes) * g.cplane + rowoff;
@@ -611,46 +629,58 @@ __global__ __launch_bounds__(64) void k_cols_mid_admm_reg(PlaneGeom g, Fft1dPlan
   const int col = (int)blockIdx.x * 64 + (int)threadIdx.x;
   if (col >= g.Wc) return;
   const int row0 = (int)blockIdx.y * cp.gstride;
-  const long rowoff = (long)row0 * g.cpitch + col;
-  real2* ba = SA + (long)blockIdx.z * g.cplane + rowoff;
-  real2* bb = SB + (long)blockIdx.z * g.cplane + rowoff;
-  const real2* hb = Hs + (long)((int)blockIdx.z % g.DC) * g.cplane + rowoff;
-  const real* gb = Gabs + rowoff;
+  // wave-uniform bases (SGPR pairs) + 32-bit per-lane byte offsets: global_load ... v_off, s[base]
+  const long urow = (long)row0 * g.cpitch;
+  real2* ba = SA + (long)blockIdx.z * g.cplane + urow;
+  real2* bb = SB + (long)blockIdx.z * g.cplane + urow;
+  const real2* hb = Hs + (long)((int)blockIdx.z % g.DC) * g.cplane + urow;
+  const real* gb = Gabs + urow;
   const real2* pr = phr + row0;
   const real2 pc = phc[col];
+  const unsigned c8 = (unsigned)col * (unsigned)sizeof(real2), c4 = (unsigned)col * (unsigned)sizeof(real);
+  const unsigned p8 = (unsigned)g.cpitch * (unsigned)sizeof(real2), p4 = (unsigned)g.cpitch * (unsigned)sizeof(real);
   real2 a[N], r[N];
 #pragma unroll
-  for (int n = 0; n < N; ++n) a[n] = bb[(long)n * g.cpitch];
+  for (int n = 0; n < N; ++n) a[n] = ld_off(bb, c8 + (unsigned)n * p8);
 #pragma unroll
-  for (int n = 0; n < N; ++n) r[n] = ba[(long)n * g.cpitch];
+  for (int n = 0; n < N; ++n) r[n] = ld_off(ba, c8 + (unsigned)n * p8);
+  LPC_SCHED_FENCE();
   reg_fft_fwd<R1, R2>(a, plan.tw);
+  LPC_SCHED_FENCE();
 #pragma unroll
-  for (int k1 = 0; k1 < R1; ++k1)
+  for (int k1 = 0; k1 < R1; ++k1) {
+    LPC_SCHED_FENCE();
 #pragma unroll
     for (int k2 = 0; k2 < R2; ++k2) {          // slot k1*R2 + k2 holds frequency k = k1 + R1*k2
       const int k = k1 + R1 * k2;
-      a[k1 * R2 + k2] = cmul(cmul_conj(a[k1 * R2 + k2], hb[(long)k * g.cpitch]), cmul(pr[k], pc));   // s conj(H) Ah
+      a[k1 * R2 + k2] = cmul(cmul_conj(a[k1 * R2 + k2], ld_off(hb, c8 + (unsigned)k * p8)), cmul(pr[k], pc));
     }
+  }
+  LPC_SCHED_FENCE();
   reg_fft_fwd<R1, R2>(r, plan.tw);
+  LPC_SCHED_FENCE();
 #pragma unroll
-  for (int k1 = 0; k1 < R1; ++k1)
+  for (int k1 = 0; k1 < R1; ++k1) {
+    LPC_SCHED_FENCE();
 #pragma unroll
     for (int k2 = 0; k2 < R2; ++k2) {
       const int k = k1 + R1 * k2, sl = k1 * R2 + k2;
-      const real2 hh = hb[(long)k * g.cpitch];
-      // R_divmat = 1 / (mu1 |H* H| + mu2 |PsiT Psi| + mu3)  (admm.py:186-190); rscale folds 1/(Hp*Wp)
-      const real rdiv =
-          rscale * ((real)1.0 / (mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * gb[(long)k * g.cpitch] + mu3));
+      const real2 hh = ld_off(hb, c8 + (unsigned)k * p8);
+      const real rdiv = rscale * ((real)1.0 / (mu1 * rabs(hh.x * hh.x + hh.y * hh.y) +
+                                               mu2 * ld_off(gb, c4 + (unsigned)k * p4) + mu3));
       const real2 vh = cscale(cadd(r[sl], a[sl]), rdiv);
       r[sl] = vh;
       a[sl] = cmul(cmul(vh, hh), cmul(pr[k], pc));
     }
+  }
+  LPC_SCHED_FENCE();
   reg_fft_inv<R1, R2>(r, plan.tw);
 #pragma unroll
-  for (int n = 0; n < N; ++n) ba[(long)n * g.cpitch] = r[n];
+  for (int n = 0; n < N; ++n) st_off(ba, c8 + (unsigned)n * p8, r[n]);
+  LPC_SCHED_FENCE();
   reg_fft_inv<R1, R2>(a, plan.tw);
 #pragma unroll
-  for (int n = 0; n < N; ++n) bb[(long)n * g.cpitch] = a[n];
+  for (int n = 0; n < N; ++n) st_off(bb, c8 + (unsigned)n * p8, a[n]);
 }
 
 // fused middle of one ADMM iteration (4-FFT form).  In: SA = rows+colsA transform of
