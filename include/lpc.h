@@ -126,6 +126,16 @@ int lpc_iterate(lpc_handle h, int n_iter, void* stream);
 int lpc_iterate_begin(lpc_handle h, void* stream);
 int lpc_iterate_end(lpc_handle h, const lpc_real* dev_projected, void* stream);
 
+/* Plug-and-play ADMM (admm.py:126-133,235-243,266-275,300-311): ONE iteration split at the U-update, where the
+ * reference calls the external denoiser.  lpc_admm_pnp_begin writes the denoiser's input as (B,D,Hp,Wp,C):
+ * U + eta/mu2 if use_dual, else the image estimate; the caller runs its denoiser and hands U (same shape) to
+ * lpc_admm_pnp_end, which does the X / W updates, the spectral image update and the dual updates exactly as the
+ * reference's branch is written (U and eta image-shaped, Psi^T = identity; use_dual: r_k = (mu3 W - rho) + mu2 U - eta,
+ * else r_k = mu2 U + H^T(mu1 X - xi)).  A handle runs either these or lpc_iterate between two resets, not both.
+ * lpc_get_state then serves "U","eta","X","W","xi","rho","forward_out","image_est" as (B,D,Hp,Wp,C). */
+int lpc_admm_pnp_begin(lpc_handle h, int use_dual, lpc_real* dev_denoiser_in, void* stream);
+int lpc_admm_pnp_end(lpc_handle h, int use_dual, const lpc_real* dev_U, void* stream);
+
 /* _form_image(): ADMM crop + clamp (admm.py:331-338), GD family projection (gd.py:136-140).
  * dev_out: (B,D,H,W,C).  Like the reference, the ADMM clamp is an in-place side effect on the image
  * estimate: it is visible to the W-update of the following iterations (and to "image_est"). */

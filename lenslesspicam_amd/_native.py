@@ -80,6 +80,8 @@ class Lib:
             "lpc_reset": [vp, vp],
             "lpc_set_momentum": [vp, C.c_double, C.c_double, C.c_double],
             "lpc_iterate": [vp, C.c_int, vp],
+            "lpc_admm_pnp_begin": [vp, C.c_int, fp, vp],
+            "lpc_admm_pnp_end": [vp, C.c_int, fp, vp],
             "lpc_iterate_begin": [vp, vp],
             "lpc_iterate_end": [vp, fp, vp],
             "lpc_set_admm_schedule": [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -196,6 +198,12 @@ class Handle:
 
     def iterate(self, n, stream=0):
         self._c(self.lib.dll.lpc_iterate(self.h, int(n), stream))
+
+    def admm_pnp_begin(self, use_dual, out_ptr, stream=0):
+        self._c(self.lib.dll.lpc_admm_pnp_begin(self.h, int(bool(use_dual)), out_ptr, stream))
+
+    def admm_pnp_end(self, use_dual, u_ptr, stream=0):
+        self._c(self.lib.dll.lpc_admm_pnp_end(self.h, int(bool(use_dual)), u_ptr, stream))
 
     def iterate_begin(self, stream=0):
         self._c(self.lib.dll.lpc_iterate_begin(self.h, stream))

@@ -36,8 +36,34 @@ class ADMM(ReconstructionAlgorithm):
         # D independent 2-D problems sharing the measurement;
         # a depth-COUPLED model has no oracle and is out of scope.
         kwargs.pop("reset", None)
-        super().__init__(psf, dtype, pad=False, norm=norm, denoiser=denoiser, reset=False, **kwargs)
+        # Plug-and-play (admm.py:126-133): an external denoiser replaces the TV prox.  Passed as the function
+        # itself -- denoiser={"network": fn, "noise_level": s, "use_dual": bool}; fn(x, noise_level) -> x on the
+        # padded (B,D,Hp,Wp,C) estimate -- every iteration is then split at the U-update
+        # (lpc_admm_pnp_begin / lpc_admm_pnp_end).
+        self._pnp = None
+        if denoiser is not None:
+            assert "network" in denoiser.keys() and "noise_level" in denoiser.keys()      # recon.py:310-312
+            if not callable(denoiser["network"]):
+                raise NotImplementedError(
+                    f"Unsupported denoiser: {denoiser['network']!r} (pretrained networks are outside the hot "
+                    "path; pass the denoising function itself as denoiser['network'])")
+            self._pnp = (denoiser["network"], denoiser["noise_level"], bool(denoiser["use_dual"]))   # admm.py:128
+        super().__init__(psf, dtype, pad=False, norm=norm, denoiser=None, reset=False, **kwargs)
+        if self._pnp is not None:
+            self._denoiser, self._denoiser_noise_level, self._denoiser_use_dual = self._pnp
         self.reset()
+
+    def _iterate(self, n):
+        if self._pnp is None:
+            return super()._iterate(n)
+        B = self._handle_batch
+        D, Hp, Wp, C = self._padded_shape
+        for _ in range(int(n)):
+            x = self._empty((B, D, Hp, Wp, C))
+            self._handle.admm_pnp_begin(self._denoiser_use_dual, x.data_ptr(), self._stream())
+            u = self._to_dev(self._denoiser(self._to_user(x), self._denoiser_noise_level))       # admm.py:235-243
+            assert tuple(u.shape) == (B, D, Hp, Wp, C), "the denoiser must keep the estimate's shape"
+            self._handle.admm_pnp_end(self._denoiser_use_dual, u.data_ptr(), self._stream())
 
     def _config(self):
         return dict(mu1=float(self._mu1), mu2=float(self._mu2), mu3=float(self._mu3), tau=float(self._tau))
@@ -54,9 +80,9 @@ class ADMM(ReconstructionAlgorithm):
 
     _X = property(lambda self: self._padded_state("X"))
     _W = property(lambda self: self._padded_state("W"))
-    _U = property(lambda self: self._padded_state("U", True))
+    _U = property(lambda self: self._padded_state("U", self._pnp is None))      # image-shaped with a denoiser
     _xi = property(lambda self: self._padded_state("xi"))
-    _eta = property(lambda self: self._padded_state("eta", True))
+    _eta = property(lambda self: self._padded_state("eta", self._pnp is None))
     _rho = property(lambda self: self._padded_state("rho"))
     _forward_out = property(lambda self: self._padded_state("forward_out"))
 

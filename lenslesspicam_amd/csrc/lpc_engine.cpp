@@ -133,6 +133,9 @@ struct lpc_engine {
   real* psf_planar = nullptr;
   bool has_init = false, psf_set = false, data_set = false, first = true;
   bool split_pending = false;  // lpc_iterate_begin ran, lpc_iterate_end has not yet
+  // plug-and-play ADMM (lpc_admm_pnp_begin / _end): explicit state in the arrays the fused path uses for the TV duals
+  //   eta0[0] = eta, eta1[0] = U, eta0[1] = X, eta1[1] = W   (all image-shaped)
+  bool pnp_mode = false, pnp_pending = false;
   long iters_done = 0;
   KernelTimer timer;
   lpcStream_t stream = nullptr;
@@ -634,56 +637,18 @@ static int admm_reset(Engine* e) {
     LPC_RT(rt::memset_async(e->V[0], 0, rb, e->stream));
   }
   e->first = true;
+  e->pnp_mode = e->pnp_pending = false;
   e->iters_done = 0;
   return 0;
 }
 
-static int admm_iterate(Engine* e, int n_iter) {
+// (r_sp, a) in e->Rsp / e->Aarr  ->  Vout = irfft2(R_div (rfft2 r_sp + s H* rfft2 a)),  HVout = H Vout:
+// forward rows, [pass A], fused middle, [inverse pass A], inverse rows
+static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real* HVout) {
   const PlaneGeom& g = e->g;
-  constexpr int TH = 16, TW = 64, NT = 256;
-  const size_t k1_smem = (size_t)(2 * (TH + 2) * (TW + 2) + (TH + 1) * TW + TH * (TW + 1)) * sizeof(real);
-  const unsigned tiles_x = (g.Wp + TW - 1) / TW, tiles_y = (g.Hp + TH - 1) / TH;
-  const dim3 k1_grid(tiles_x * tiles_y, e->P, 1);
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const bool split = e->N1 > 1;
-  // 16-byte-lane kernel whenever the padded width allows aligned float4 rows (every BASELINE size does)
-  static int force_scalar = -1;
-  if (force_scalar < 0) force_scalar = std::getenv("LPC_K1_SCALAR") ? 1 : 0;
-#ifdef LPC_DOUBLE
-  const bool vec4 = false;  // the 16-byte-lane kernel is float-only
-#else
-  const bool vec4 = (g.Wp % 4 == 0) && !force_scalar;
-#endif
-  constexpr int TH4 = 8, TW4 = 256;
-  const unsigned tiles_x4 = (g.Wp + TW4 - 1) / TW4, tiles_y4 = (g.Hp + TH4 - 1) / TH4;
-  const dim3 k1_grid4(tiles_x4 * tiles_y4, e->P, 1);
-  const size_t k1_smem4 = (size_t)2 * (TH4 + 2) * (TW4 + 8) * sizeof(real);
-  for (int it = 0; it < n_iter; ++it) {
-    real* Vc = e->V[e->vcur];
-    real* Vo = e->V[e->vcur ^ 1];
-    double par[4];
-    admm_params(e, e->iters_done, par);
-    AdmmScalars sc = admm_scalars(e, par);
-#ifndef LPC_DOUBLE
-    if (vec4)
-      LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT>, k1_grid4, NT, k1_smem4, g, sc, (const real*)Vc,
-                      (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
-                      (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
-                      (const real*)e->Y, e->Rsp, e->Aarr, tiles_x4,
-                      (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
-    else
-#endif
-    LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial<TH, TW, NT>, k1_grid, NT, k1_smem, g, sc, (const real*)Vc,
-                    (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
-                    (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
-                    (const real*)e->Y, e->Rsp, e->Aarr, tiles_x,
-                    (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
-    std::swap(e->Vw[0], e->Vw[1]);  // this iteration's "V for W" becomes the next one's "V_old for W_old"
-    e->vw_old = e->vw_cur;
-    e->vw_cur = false;
-    e->ecur ^= 1;
-    e->first = false;
     if (e->rows_half) {
       LPC_OK(dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
         constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
@@ -732,15 +697,62 @@ static int admm_iterate(Engine* e, int n_iter) {
         constexpr bool sk = decltype(SK)::value;
         return launch_k(e, LPC_K_ROW_INV, k_rinv_half<nt, em, sk>, dim3(2 * g.Hp, e->P), nt,
                         LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real2*)SA,
-                        (const real2*)SB, Vo, e->HVb[e->hcur ^ 1]);
+                        (const real2*)SB, Vout, HVout);
       }));
     } else
     LPC_OK(dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
       constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
       return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em, sk, r2>, dim3(g.Hp, e->P), nt,
-                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, pinv, (const real2*)SA, (const real2*)SB, Vo, e->HVb[e->hcur ^ 1]);
+                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, pinv, (const real2*)SA, (const real2*)SB, Vout, HVout);
     }));
+  return 0;
+}
+
+static int admm_iterate(Engine* e, int n_iter) {
+  const PlaneGeom& g = e->g;
+  constexpr int TH = 16, TW = 64, NT = 256;
+  const size_t k1_smem = (size_t)(2 * (TH + 2) * (TW + 2) + (TH + 1) * TW + TH * (TW + 1)) * sizeof(real);
+  const unsigned tiles_x = (g.Wp + TW - 1) / TW, tiles_y = (g.Hp + TH - 1) / TH;
+  const dim3 k1_grid(tiles_x * tiles_y, e->P, 1);
+  // 16-byte-lane kernel whenever the padded width allows aligned float4 rows (every BASELINE size does)
+  static int force_scalar = -1;
+  if (force_scalar < 0) force_scalar = std::getenv("LPC_K1_SCALAR") ? 1 : 0;
+#ifdef LPC_DOUBLE
+  const bool vec4 = false;  // the 16-byte-lane kernel is float-only
+#else
+  const bool vec4 = (g.Wp % 4 == 0) && !force_scalar;
+#endif
+  constexpr int TH4 = 8, TW4 = 256;
+  const unsigned tiles_x4 = (g.Wp + TW4 - 1) / TW4, tiles_y4 = (g.Hp + TH4 - 1) / TH4;
+  const dim3 k1_grid4(tiles_x4 * tiles_y4, e->P, 1);
+  const size_t k1_smem4 = (size_t)2 * (TH4 + 2) * (TW4 + 8) * sizeof(real);
+  for (int it = 0; it < n_iter; ++it) {
+    real* Vc = e->V[e->vcur];
+    real* Vo = e->V[e->vcur ^ 1];
+    double par[4];
+    admm_params(e, e->iters_done, par);
+    AdmmScalars sc = admm_scalars(e, par);
+#ifndef LPC_DOUBLE
+    if (vec4)
+      LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT>, k1_grid4, NT, k1_smem4, g, sc, (const real*)Vc,
+                      (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
+                      (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
+                      (const real*)e->Y, e->Rsp, e->Aarr, tiles_x4,
+                      (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
+    else
+#endif
+    LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial<TH, TW, NT>, k1_grid, NT, k1_smem, g, sc, (const real*)Vc,
+                    (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
+                    (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
+                    (const real*)e->Y, e->Rsp, e->Aarr, tiles_x,
+                    (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
+    std::swap(e->Vw[0], e->Vw[1]);  // this iteration's "V for W" becomes the next one's "V_old for W_old"
+    e->vw_old = e->vw_cur;
+    e->vw_cur = false;
+    e->ecur ^= 1;
+    e->first = false;
+    LPC_OK(admm_spectral_step(e, sc, Vo, e->HVb[e->hcur ^ 1]));
     e->vcur ^= 1;  // Vo now holds the new image estimate
     e->hcur ^= 1;  // ... and the other H V buffer its forward model
     for (int k = 0; k < 4; ++k) e->last_par[k] = par[k];
@@ -947,6 +959,7 @@ int lpc_iterate(lpc_handle e, int n_iter, void* stream) {
   if (!e->data_set) return fail("Must set data with `set_data()`");
   e->stream = (lpcStream_t)stream;
   if (e->split_pending) return fail("lpc_iterate: a split iteration is in flight (lpc_iterate_end missing)");
+  if (e->pnp_mode) return fail("lpc_iterate: the handle runs plug-and-play iterations since the last reset");
   if (e->cfg.algo == LPC_ALGO_ADMM) return admm_iterate(e, n_iter);
   if (e->cfg.algo >= LPC_ALGO_GD) return gd_iterate(e, n_iter);
   return fail("lpc_iterate: operator-only handle");
@@ -972,11 +985,78 @@ int lpc_iterate_end(lpc_handle e, const real* dev_projected, void* stream) {
   return gd_finish_split(e, dev_projected);
 }
 
+// ---- plug-and-play ADMM (section 8f row N4): one iteration split at the U-update ----
+static int pnp_check(lpc_handle e, const char* who) {
+  if (!e) return fail("null handle");
+  if (e->cfg.algo != LPC_ALGO_ADMM) return fail(std::string(who) + ": ADMM handles only");
+  if (!e->psf_set) return fail(std::string(who) + ": PSF not set");
+  if (!e->data_set) return fail("Must set data with `set_data()`");
+  if (!e->sched[0].empty()) return fail(std::string(who) + ": not available with an unrolled schedule");
+  return 0;
+}
+
+int lpc_admm_pnp_begin(lpc_handle e, int use_dual, real* dev_denoiser_in, void* stream) {
+  LPC_OK(pnp_check(e, "lpc_admm_pnp_begin"));
+  if (!dev_denoiser_in) return fail("lpc_admm_pnp_begin: null argument");
+  if (e->pnp_pending) return fail("lpc_admm_pnp_begin: the previous split iteration was not finished");
+  if (!e->pnp_mode && e->iters_done != 0)
+    return fail("lpc_admm_pnp_begin: fused iterations already ran since the last reset");
+  e->stream = (lpcStream_t)stream;
+  e->pnp_mode = true;
+  const PlaneGeom& g = e->g;
+  const int nimg = e->cfg.batch * e->cfg.depth;
+  real* src = e->V[e->vcur];                    // admm.py:242: denoiser(image_est)
+  if (use_dual) {                               // admm.py:237-240: denoiser(U + eta / mu2)
+    const long n = (long)g.rplane * e->P;
+    LPC_OK(launch_k(e, -1, k_pnp_input<256>, grid1d(n, 256), 256, 0, e->Rsp, (const real*)e->eta1[0],
+                    (const real*)e->eta0[0], (real)e->cfg.mu2, n));
+    src = e->Rsp;
+  }
+  LPC_OK(planar_to_hwc(e, src, dev_denoiser_in, nimg, g.Hp, g.Wp, g.rpitch, g.rplane, 0, 0, 0));
+  e->pnp_pending = true;
+  return 0;
+}
+
+int lpc_admm_pnp_end(lpc_handle e, int use_dual, const real* dev_U, void* stream) {
+  LPC_OK(pnp_check(e, "lpc_admm_pnp_end"));
+  if (!dev_U) return fail("lpc_admm_pnp_end: null argument");
+  if (!e->pnp_pending) return fail("lpc_admm_pnp_end: no split iteration in flight");
+  e->stream = (lpcStream_t)stream;
+  const PlaneGeom& g = e->g;
+  const int nimg = e->cfg.batch * e->cfg.depth;
+  real *eta = e->eta0[0], *U = e->eta1[0], *X = e->eta0[1], *W = e->eta1[1];
+  LPC_OK(hwc_to_planar(e, dev_U, U, nimg, g.Hp, g.Wp, g.rpitch, g.rplane));
+  double par[4];
+  admm_params(e, e->iters_done, par);
+  const AdmmScalars sc = admm_scalars(e, par);
+  const dim3 grid = grid1d((long)g.Hp * g.Wp, 256, e->P);
+  real* Vc = e->V[e->vcur];
+  real* Vn = e->V[e->vcur ^ 1];
+  real* HVn = e->HVb[e->hcur ^ 1];
+  LPC_OK(launch_k(e, LPC_K_SPATIAL, k_pnp_pre<256>, grid, 256, 0, g, sc, use_dual ? 1 : 0, (const real*)Vc,
+                  (const real*)e->HVb[e->hcur], (const real*)e->xi, (const real*)e->rho, (const real*)U,
+                  (const real*)eta, (const real*)e->Y, X, W, e->Rsp, e->Aarr));
+  LPC_OK(admm_spectral_step(e, sc, Vn, HVn));
+  LPC_OK(launch_k(e, LPC_K_SPATIAL, k_pnp_post<256>, grid, 256, 0, g, sc, use_dual ? 1 : 0, (const real*)Vn,
+                  (const real*)HVn, (const real*)X, (const real*)W, (const real*)U, e->xi, eta, e->rho));
+  e->vcur ^= 1;
+  e->hcur ^= 1;
+  e->pnp_pending = false;
+  e->first = false;
+  ++e->iters_done;
+  return 0;
+}
+
 int lpc_form_image(lpc_handle e, real* dev_out, void* stream) {
   if (!e || !dev_out) return fail("lpc_form_image: null argument");
   e->stream = (lpcStream_t)stream;
   const PlaneGeom& g = e->g;
   const int nimg = e->cfg.batch * e->cfg.depth;
+  if (e->cfg.algo == LPC_ALGO_ADMM && e->pnp_mode) {   // explicit state: the clamp really is in place
+    LPC_OK(planar_to_hwc(e, e->V[e->vcur], dev_out, nimg, g.H, g.W, g.rpitch, g.rplane, g.sh, g.sw, 1));
+    return launch_k(e, -1, k_clamp_window_inplace<256>, grid1d((long)g.H * g.W, 256, e->P), 256, 0, g,
+                    e->V[e->vcur]);
+  }
   if (e->cfg.algo == LPC_ALGO_ADMM) {  // crop + clamp (admm.py:331-338)
     LPC_OK(planar_to_hwc(e, e->V[e->vcur], dev_out, nimg, g.H, g.W, g.rpitch, g.rplane, g.sh, g.sw, 1));
     // ... which the reference applies IN PLACE to its state: remember the clamped estimate for the
@@ -1007,6 +1087,17 @@ int lpc_get_state(lpc_handle e, const char* name, real* dev_out, void* stream) {
   auto out_padded = [&](real* src) {
     return planar_to_hwc(e, src, dev_out, nimg, g.Hp, g.Wp, g.rpitch, g.rplane, 0, 0, 0);
   };
+  if (e->pnp_mode) {   // explicit state arrays; U and eta are image-shaped here
+    if (nm == "image_est") return out_padded(e->V[e->vcur]);
+    if (nm == "forward_out") return out_padded(e->HVb[e->hcur]);
+    if (nm == "xi") return out_padded(e->xi);
+    if (nm == "rho") return out_padded(e->rho);
+    if (nm == "eta") return out_padded(e->eta0[0]);
+    if (nm == "U") return out_padded(e->eta1[0]);
+    if (nm == "X") return out_padded(e->eta0[1]);
+    if (nm == "W") return out_padded(e->eta1[1]);
+    return fail("lpc_get_state: unknown name '" + nm + "'");
+  }
   if (nm == "image_est") return out_padded(e->vw_cur ? e->Vw[0] : e->V[e->vcur]);
   if (nm == "forward_out") return out_padded(e->HVb[e->hcur]);
   // the rest needs the pending dual update applied: materialise into scratch

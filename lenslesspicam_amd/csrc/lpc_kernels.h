@@ -1058,6 +1058,65 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
 
 #endif  // !LPC_DOUBLE
 
+// ---- plug-and-play ADMM: the U-prox is an external denoiser (admm.py:126-133,235-243,266-275,300-311) ----------
+// Explicit state (U and eta are image-shaped, Psi^T is the identity), plain streaming kernels around the caller's
+// function; the reference's branch is reproduced as written, including what its conditional expression drops:
+//   use_dual:  r_k = (mu3 W - rho) + mu2 U - eta                 (no data term)
+//   else:      r_k = mu2 U + H^T (mu1 X - xi)                    (no W term)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pnp_input(real* LPC_RESTRICT out, const real* LPC_RESTRICT U,
+                                                   const real* LPC_RESTRICT eta, real mu2, long n) {
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) out[e] = U[e] + eta[e] / mu2;
+}
+
+// X, W of this iteration (kept for the dual updates) and the two inputs of the spectral step
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pnp_pre(PlaneGeom g, AdmmScalars p, int dual, const real* LPC_RESTRICT V,
+                                                 const real* LPC_RESTRICT HV, const real* LPC_RESTRICT xi,
+                                                 const real* LPC_RESTRICT rho, const real* LPC_RESTRICT U,
+                                                 const real* LPC_RESTRICT eta, const real* LPC_RESTRICT Y,
+                                                 real* LPC_RESTRICT X, real* LPC_RESTRICT W, real* LPC_RESTRICT Rsp,
+                                                 real* LPC_RESTRICT Aout) {
+  const long n = (long)g.Hp * g.Wp;
+  const long pl = blockIdx.y;
+  const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const int r = (int)(e / g.Wp), c = (int)(e - (long)r * g.Wp);
+    const long o = pl * g.rplane + (long)r * g.rpitch + c;
+    const bool inside = (r >= g.sh) && (r < g.sh + g.H) && (c >= g.sw) && (c < g.sw + g.W);
+    const real yv = inside ? Y[(long)dpl * g.uplane + (long)(r - g.sh) * g.W + (c - g.sw)] : (real)0.;
+    const real x = (inside ? p.m_in : p.m_out) * (xi[o] + p.mu1 * HV[o] + yv);   // admm.py:252-254
+    const real w = rmax(rho[o] / p.mu3 + V[o], (real)0.);                        // admm.py:256-262
+    X[o] = x;
+    W[o] = w;
+    if (dual) {
+      Rsp[o] = (p.mu3 * w - rho[o]) + p.mu2 * U[o] - eta[o];
+      Aout[o] = (real)0.;
+    } else {
+      Rsp[o] = p.mu2 * U[o];
+      Aout[o] = p.mu1 * x - xi[o];
+    }
+  }
+}
+
+// dual updates with the new image estimate (admm.py:296-311)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_pnp_post(PlaneGeom g, AdmmScalars p, int dual, const real* LPC_RESTRICT Vn,
+                                                  const real* LPC_RESTRICT HVn, const real* LPC_RESTRICT X,
+                                                  const real* LPC_RESTRICT W, const real* LPC_RESTRICT U,
+                                                  real* LPC_RESTRICT xi, real* LPC_RESTRICT eta,
+                                                  real* LPC_RESTRICT rho) {
+  const long n = (long)g.Hp * g.Wp;
+  const long pl = blockIdx.y;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const int r = (int)(e / g.Wp), c = (int)(e - (long)r * g.Wp);
+    const long o = pl * g.rplane + (long)r * g.rpitch + c;
+    xi[o] = xi[o] + p.mu1 * (HVn[o] - X[o]);
+    if (dual) eta[o] = eta[o] + p.mu2 * (Vn[o] - U[o]);
+    rho[o] = rho[o] + p.mu3 * (Vn[o] - W[o]);
+  }
+}
+
 // materialise U, W and the flushed duals for inspection (tests / get_state); no state change
 template <int NT>
 __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
@@ -1157,6 +1216,18 @@ __global__ __launch_bounds__(NT) void k_clamp_window_copy(PlaneGeom g, const rea
     real v = src[pl * g.rplane + e];
     if (r >= g.sh && r < g.sh + g.H && c >= g.sw && c < g.sw + g.W && v < (real)0.) v = (real)0.;
     dst[pl * g.rplane + e] = v;
+  }
+}
+
+// the same clamp in place (plug-and-play ADMM keeps its image estimate in one explicit array)
+template <int NT>
+__global__ __launch_bounds__(NT) void k_clamp_window_inplace(PlaneGeom g, real* x) {
+  const long n = (long)g.H * g.W;
+  const long pl = blockIdx.y;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const int r = (int)(e / g.W), c = (int)(e - (long)r * g.W);
+    const long o = pl * g.rplane + (long)(g.sh + r) * g.rpitch + (g.sw + c);
+    if (x[o] < (real)0.) x[o] = (real)0.;
   }
 }
 

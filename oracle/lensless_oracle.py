@@ -167,8 +167,10 @@ class ADMMOracle:
     """
 
     def __init__(self, psf, dtype=torch.float32, mu1=1e-6, mu2=1e-5, mu3=4e-5, tau=1e-4,
-                 initial_est=None, schedule=None):
-        """``schedule``: optional dict of per-iteration sequences mu1/mu2/mu3/tau -- the arithmetic of
+                 initial_est=None, schedule=None, denoiser=None):
+        """``denoiser``: optional (fn, noise_level, use_dual) -- the plug-and-play branch of admm.py:126-133,
+        235-243,266-275,300-311, restated as written (U and eta image-shaped, Psi^T = identity).
+        ``schedule``: optional dict of per-iteration sequences mu1/mu2/mu3/tau -- the arithmetic of
         ``lensless/recon/unrolled_admm.py:133-234`` (UnrolledADMM inference, no pre/post processors):
         iteration i uses the i-th entries everywhere, R_divmat and X_divmat included."""
         psf = _as_tensor(psf, dtype)
@@ -185,6 +187,7 @@ class ADMMOracle:
         self.gram = finite_diff_gram(self.padded_shape, dtype)  # admm.py:107
         self.initial_est = None if initial_est is None else _as_tensor(initial_est, dtype)
         self.schedule = schedule
+        self.denoiser = denoiser
         self.data = None
         self.reset()
 
@@ -217,7 +220,7 @@ class ADMMOracle:
         else:
             self.V = torch.zeros([1] + self.padded_shape, dtype=self.dtype)
         self.X = torch.zeros_like(self.V)
-        self.U = torch.zeros_like(finite_diff(self.V))
+        self.U = torch.zeros_like(self.V if self.denoiser is not None else finite_diff(self.V))  # admm.py:163-169
         self.W = torch.zeros_like(self.X)
         if self.V.max():  # admm.py:172
             self.HV = self.conv.convolve(self.V)
@@ -242,6 +245,8 @@ class ADMMOracle:
         self._set_params(self.it)
         self.it += 1
         mu1, mu2, mu3 = self.mu1, self.mu2, self.mu3
+        if self.denoiser is not None:
+            return self._step_pnp()
         self.U = soft_thresh(self.PsiV + self.eta / mu2, self.tau / mu2)          # :245-247
         self.X = self.X_divmat * (self.xi + mu1 * self.HV + g.pad(self.data))     # :252-254
         self.W = torch.maximum(self.rho / mu3 + self.V, torch.zeros_like(self.V))  # :259-261
@@ -257,6 +262,27 @@ class ADMMOracle:
         self.xi = self.xi + mu1 * (self.HV - self.X)                              # :298-300
         self.eta = self.eta + mu2 * (self.PsiV - self.U)                          # :302-308
         self.rho = self.rho + mu3 * (self.V - self.W)                             # :310-311
+
+    def _step_pnp(self):
+        """The denoiser branch.  The conditional expression of admm.py:266-275 binds as
+        ``(A + B - C) if use_dual else (D + E)``: the dual form has no data term, the other one no W term."""
+        g = self.geom
+        fn, nl, dual = self.denoiser
+        mu1, mu2, mu3 = self.mu1, self.mu2, self.mu3
+        self.U = fn(self.U + self.eta / mu2, nl) if dual else fn(self.V, nl)       # :235-243
+        self.X = self.X_divmat * (self.xi + mu1 * self.HV + g.pad(self.data))     # :252-254
+        self.W = torch.maximum(self.rho / mu3 + self.V, torch.zeros_like(self.V))  # :259-261
+        if dual:
+            rk = (mu3 * self.W - self.rho) + mu2 * self.U - self.eta
+        else:
+            rk = mu2 * self.U + self.conv.deconvolve(mu1 * self.X - self.xi)
+        freq = self.R_divmat * torch.fft.rfft2(rk, dim=(-3, -2))
+        self.V = torch.fft.irfft2(freq, dim=(-3, -2), s=(g.hp, g.wp))
+        self.HV = self.conv.convolve(self.V)                                      # :320
+        self.xi = self.xi + mu1 * (self.HV - self.X)
+        if dual:
+            self.eta = self.eta + mu2 * (self.V - self.U)                         # :304-306, only with use_dual (:326)
+        self.rho = self.rho + mu3 * (self.V - self.W)
 
     def form_image(self):
         """admm.py:331-338: crop is a view, clamp happens IN PLACE on V.  (UnrolledADMM clips out of

@@ -275,6 +275,41 @@ def hook_case(name):
     print("wrote", name, {k: float(np.abs(v).max()) for k, v in out.items() if k.endswith("final")})
 
 
+def _pnp_denoise(x, noise_level):
+    """stand-in denoiser: a 3-tap smoothing along the width + a noise-level dependent shrink (keeps the shape)"""
+    sm = 0.5 * x + 0.25 * (torch.roll(x, 1, dims=-2) + torch.roll(x, -1, dims=-2))
+    return sm * (1.0 - noise_level / 200.0)
+
+
+def admm_pnp_case(name):
+    """ADMM's plug-and-play branch (admm.py:126-133,235-243,266-275,300-311) with a stand-in denoiser: the
+    attributes the constructor would set from a denoiser dict are set by hand (the DruNet weights are a download),
+    then reset() + apply() through the public API.  Both use_dual settings, plus a continuation after the
+    in-place clamp of _form_image."""
+    out = {}
+    psf, data = make_inputs(22, 30, 3, 61)
+    out.update(psf=psf, data=data, iters=np.array(6), noise_level=np.array(12.0), params=np.array([1e-4, 2e-4, 3e-4]))
+    # the dual form has no data term: from the all-zero start it stays at zero, so both runs get a warm start
+    init = (np.random.default_rng(62).random([1, 1, 45, 60, 3]).astype(np.float32) * 0.2)
+    out["initial_est"] = init
+    for dual in (False, True):
+        rec = ADMM(t(psf), mu1=1e-4, mu2=2e-4, mu3=3e-4, initial_est=t(init.copy()))
+        assert [int(v) for v in rec._padded_shape] == [1, 45, 60, 3]
+        rec._denoiser = _pnp_denoise
+        rec._denoiser_noise_level = 12.0
+        rec._denoiser_use_dual = dual
+        rec._proj = rec._denoiser
+        rec._PsiT = lambda x: x
+        rec.set_data(t(data))
+        tag = "dual" if dual else "plain"
+        out[tag + "_final"] = rec.apply(n_iter=6, disp_iter=None, plot=False).numpy().copy()
+        for k in ("_image_est", "_U", "_X", "_W", "_xi", "_eta", "_rho"):
+            out[tag + k] = getattr(rec, k).numpy().copy()
+        out[tag + "_more"] = rec.apply(n_iter=3, disp_iter=None, plot=False, reset=False).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, {k: float(np.abs(v).max()) for k, v in out.items() if k.endswith("final") or k.endswith("more")})
+
+
 def operator_case():
     rng = np.random.default_rng(5)
     out = {}
@@ -322,6 +357,9 @@ if __name__ == "__main__":
         unrolled_admm_case("unrolled_admm_24x32x3_b3", 24, 32, 3, seed=21, n_iter=6, batch=3)
         unrolled_fista_case("unrolled_fista_24x32x3_b3", 24, 32, 3, seed=22, n_iter=7, batch=3)
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "admm_pnp":
+        admm_pnp_case("pnp_admm")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "hook":
         hook_case("pnp_hook")
         sys.exit(0)
@@ -361,3 +399,4 @@ if __name__ == "__main__":
     recon_error_case("recon_error")
     preprocess_case("preprocess")
     hook_case("pnp_hook")
+    admm_pnp_case("pnp_admm")

@@ -199,3 +199,25 @@ def test_custom_projection_and_denoiser_hook_match_reference():
     o = orc.GDOracle(g["psf"], kind="fista", proj=lambda x: torch.clamp(x, min=0) * (1.0 - nl / 100.0))
     o.set_data(g["data"])
     assert rel(o.apply(n), g["pnp_final"]) <= 1e-6
+
+
+def _pnp_denoise(x, noise_level):
+    sm = 0.5 * x + 0.25 * (torch.roll(x, 1, dims=-2) + torch.roll(x, -1, dims=-2))
+    return sm * (1.0 - noise_level / 200.0)
+
+
+@pytest.mark.parametrize("dual", [False, True])
+def test_admm_plug_and_play_branch_matches_reference(dual):
+    """admm.py:126-133,235-243,266-275,300-311 with a stand-in denoiser, both use_dual settings, including the
+    continuation after the in-place clamp of _form_image."""
+    g = np.load(os.path.join(GOLDEN, "pnp_admm.npz"))
+    mu1, mu2, mu3 = (float(v) for v in g["params"])
+    o = orc.ADMMOracle(g["psf"], mu1=mu1, mu2=mu2, mu3=mu3, initial_est=g["initial_est"].copy(),
+                       denoiser=(_pnp_denoise, float(g["noise_level"]), dual))
+    o.set_data(g["data"])
+    tag = "dual" if dual else "plain"
+    assert rel(o.apply(int(g["iters"])), g[tag + "_final"]) <= 1e-5
+    for k, a in (("_image_est", o.V), ("_U", o.U), ("_X", o.X), ("_W", o.W), ("_xi", o.xi), ("_eta", o.eta),
+                 ("_rho", o.rho)):
+        assert rel(a, g[tag + k]) <= 1e-5, k
+    assert rel(o.apply(3, reset=False), g[tag + "_more"]) <= 1e-5
