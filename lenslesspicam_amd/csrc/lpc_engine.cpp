@@ -287,7 +287,7 @@ static int build_plan(Engine* e, Fft1dPlan& p, int n) {
 }
 
 // choose the column split Hp = N1*N2 and the tile width
-static void choose_split(int Hp, int Wc, int* N1, int* N2, int* T) {
+static void choose_split(int Hp, int Wc, int* N1, int* N2, int* T, bool prefer24 = false) {
   int t = 16;
   if (const char* env = std::getenv("LPC_COL_T")) t = std::max(1, atoi(env));  // tuning knob
   while (t > 1 && t / 2 >= Wc) t /= 2;  // tiny images: do not waste lanes on empty columns
@@ -304,6 +304,12 @@ static void choose_split(int Hp, int Wc, int* N1, int* N2, int* T) {
     if ((long)n2 * 2 * t > budget / 2 || (long)n1 * t > budget / 2) continue;
     const int cost = std::max(n1, 2 * n2);
     if (cost < bestcost) { bestcost = cost; best1 = n1; best2 = n2; }
+  }
+  // ADMM: a 24-point pass B runs its two-array middle in registers (k_cols_mid_admm_reg); worth it as long as pass A
+  // stays short.  Measured (r01b_notes.md): 2160 rows 90 x 24: 72.8 vs 68.3 it/s (72 x 30); 6144 rows 256 x 24: 191
+  // vs 204 it/s (128 x 48).
+  if (prefer24 && Hp % 24 == 0 && Hp / 24 <= 128 && Hp / 24 >= 2 && (long)(Hp / 24) * t <= budget / 2) {
+    best2 = 24; best1 = Hp / 24;
   }
   if (const char* env = std::getenv("LPC_SPLIT_N2")) {  // tuning knob: force the length of the fused middle transform
     const int n2 = atoi(env);
@@ -336,7 +342,9 @@ static int setup_geometry(Engine* e) {
   e->Pdata = c.batch * c.channels;
   if (g.Wp > kMaxTilePoints)
     return fail("padded width " + std::to_string(g.Wp) + " > " + std::to_string(kMaxTilePoints) + " is not supported");
-  choose_split(g.Hp, g.Wc, &e->N1, &e->N2, &e->T);
+  // (float32 only: 2 x 24 complex128 values do not fit a lane's registers)
+  choose_split(g.Hp, g.Wc, &e->N1, &e->N2, &e->T,
+               c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && !std::getenv("LPC_MID_LDS"));
   LPC_OK(build_plan(e, e->planW, g.Wp));
   e->rows_r2 = e->planW.nst >= 2 && e->planW.radix[e->planW.nst - 1] == 2 && !std::getenv("LPC_NO_R2");
   if (e->rows_r2) {
@@ -347,10 +355,11 @@ static int setup_geometry(Engine* e) {
   }
   e->mid_reg = !std::getenv("LPC_MID_LDS");
   // Row passes: one real row per half-length complex transform (k_r*_half kernels) once the
-  // paired tile is so large that fewer than 4 workgroups fit a CU's 160 KiB of LDS.  Measured (r01b_notes.md):
-  // 8192 columns +3 % it/s; 960 columns (C4) -5 %, the short transforms leave most of a 256-thread group idle.
+  // paired tile is so large that fewer than 5 workgroups fit a CU's 160 KiB of LDS.  Measured (r01b_notes.md):
+  // 8192 columns +3 % it/s, 3840 columns (C5) +1.8 %; 960 columns (C4) -5 %: the short transforms leave most
+  // of a 256-thread group idle.
   const bool half_ok = g.Wp % 2 == 0 && g.Wp >= 4;
-  e->rows_half = half_ok && 4 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024 && !std::getenv("LPC_ROWS_PAIRED");
+  e->rows_half = half_ok && 5 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024 && !std::getenv("LPC_ROWS_PAIRED");
   if (half_ok && std::getenv("LPC_ROWS_HALF")) e->rows_half = true;   // test knob: small frames too
   if (e->rows_half) LPC_OK(build_plan(e, e->planWh, g.Wp / 2));
   LPC_OK(build_plan(e, e->planB, e->N2));
@@ -675,7 +684,7 @@ static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real
                         (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, sc.mu1, sc.mu2, sc.mu3,
                         (real)1.0 / ((real)g.Hp * (real)g.Wp));
       };
-      const int regN = (split && e->mid_reg) ? cp.N : 0;
+      const int regN = (split && e->mid_reg && sizeof(real) == 4) ? cp.N : 0;
       // two arrays per lane: only short pass-B transforms fit the register file.  Measured at 12 MP
       // (profiles/r01b_notes.md): 24 points 0.89 ms and 32 points 0.83 ms beat the LDS middle (0.99 / 0.92 ms) but
       // need a 256- / 192-point pass A that costs more than it saves; 48 points is 1.62 ms (AGPR traffic).
