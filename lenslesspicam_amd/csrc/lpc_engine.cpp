@@ -305,9 +305,9 @@ static void choose_split(int Hp, int Wc, int* N1, int* N2, int* T, bool prefer24
     const int cost = std::max(n1, 2 * n2);
     if (cost < bestcost) { bestcost = cost; best1 = n1; best2 = n2; }
   }
-  // ADMM: a 24-point pass B runs its two-array middle in registers (k_cols_mid_admm_reg); worth it as long as pass A
-  // stays short.  Measured (r01b_notes.md): 2160 rows 90 x 24: 72.8 vs 68.3 it/s (72 x 30); 6144 rows 256 x 24: 191
-  // vs 204 it/s (128 x 48).
+  // A 24-point pass B runs the fused middle in registers (k_cols_mid_admm_reg / k_cols_mid_mul_reg<8,3>) with the
+  // fewest registers; worth it as long as pass A stays short.  Measured (r01b_notes.md): 2160 rows, 90 x 24 vs
+  // 72 x 30: ADMM 72.8 vs 68.3 it/s, FISTA 2134 vs 2013 it/s; 6144 rows, 256 x 24 vs 128 x 48: ADMM 191 vs 204 it/s.
   if (prefer24 && Hp % 24 == 0 && Hp / 24 <= 128 && Hp / 24 >= 2 && (long)(Hp / 24) * t <= budget / 2) {
     best2 = 24; best1 = Hp / 24;
   }
@@ -342,9 +342,9 @@ static int setup_geometry(Engine* e) {
   e->Pdata = c.batch * c.channels;
   if (g.Wp > kMaxTilePoints)
     return fail("padded width " + std::to_string(g.Wp) + " > " + std::to_string(kMaxTilePoints) + " is not supported");
-  // (float32 only: 2 x 24 complex128 values do not fit a lane's registers)
+  // (ADMM in float32 only: 2 x 24 complex128 values do not fit a lane's registers)
   choose_split(g.Hp, g.Wc, &e->N1, &e->N2, &e->T,
-               c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && !std::getenv("LPC_MID_LDS"));
+               (c.algo != LPC_ALGO_ADMM || sizeof(real) == 4) && !std::getenv("LPC_MID_LDS"));
   LPC_OK(build_plan(e, e->planW, g.Wp));
   e->rows_r2 = e->planW.nst >= 2 && e->planW.radix[e->planW.nst - 1] == 2 && !std::getenv("LPC_NO_R2");
   if (e->rows_r2) {
