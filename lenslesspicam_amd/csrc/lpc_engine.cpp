@@ -359,7 +359,10 @@ static int setup_geometry(Engine* e) {
   // 8192 columns +3 % it/s, 3840 columns (C5) +1.8 %; 960 columns (C4) -5 %: the short transforms leave most
   // of a 256-thread group idle.
   const bool half_ok = g.Wp % 2 == 0 && g.Wp >= 4;
-  e->rows_half = half_ok && 5 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024 && !std::getenv("LPC_ROWS_PAIRED");
+  // The gradient-descent family switches earlier (its irfft -> residual -> rfft kernel runs two transforms per
+  // workgroup): 2048 columns FISTA +6.8 %, ADMM -1 %.
+  const bool wide = c.algo == LPC_ALGO_ADMM ? 5 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024 : g.Wp >= 2048;
+  e->rows_half = half_ok && wide && !std::getenv("LPC_ROWS_PAIRED");
   if (half_ok && std::getenv("LPC_ROWS_HALF")) e->rows_half = true;   // test knob: small frames too
   if (e->rows_half) LPC_OK(build_plan(e, e->planWh, g.Wp / 2));
   LPC_OK(build_plan(e, e->planB, e->N2));
