@@ -692,7 +692,14 @@ static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real
       // (profiles/r01b_notes.md): 24 points 0.89 ms and 32 points 0.83 ms beat the LDS middle (0.99 / 0.92 ms) but
       // need a 256- / 192-point pass A that costs more than it saves; 48 points is 1.62 ms (AGPR traffic).
       if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_admm_reg<8, 3>)); }
-      else
+      else if (cp.N * cp.T * 2 > 8192 && cp.N * cp.T * 2 <= 9216) {
+        // just above 8192 points (C1 / C4: 540 rows x 8 columns x 2 arrays = 8640): 512 threads x 18 points keeps
+        // TWO workgroups per CU inside the 128-VGPR budget; 1024 x 16 is one 16-wave workgroup per CU in lock-step
+        // at every barrier (C4: middle 1.435 -> 1.331 ms, 17.5k -> 18.0k frame-it/s)
+        LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<512, 18>, grid, 512, (size_t)cp.N * cp.T * 2 * sizeof(real2),
+                        g, e->planB, cp, SA, SB, (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr,
+                        (const real2*)e->phc, t2, sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
+      } else
       LPC_OK(dispatch_cfg(cp.N * cp.T * 2, [&](auto NTc, auto EM) {
         constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
         return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<nt, em>, grid, nt,
