@@ -63,8 +63,12 @@ def parse():
                          "batch of 64 DiffuserCam frames (270x480x3) block-sharded over the ranks, ADMM 20 it, one "
                          "all-gather (strong scaling; reported separately, never as the headline value)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-iters", type=int, default=3,
+                    help="timed CPU-oracle iterations (SURVEY 8d: >= 3); two more are spent choosing the thread count")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--parity-iters", type=int, default=5)
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the short C1 / C3 / C4 / C5 legs reported under 'other_configs'")
     return ap.parse_args()
 
 
@@ -88,16 +92,18 @@ def run_c4(args, rank, world, dev, dist):
     """BASELINE config 4: 64 frames 270x480x3 sharing one PSF, ADMM 20 iterations, frames block-sharded over
     the ranks (lenslesspicam_amd.dist), ONE all-gather of the results per step.  Strong scaling."""
     import lenslesspicam_amd as lpa
-    from lenslesspicam_amd.dist import reconstruct_sharded
-
     B, H, W, C, n_iter = 64, 270, 480, 3, 20
     g = torch.Generator(device=dev).manual_seed(0)
     psf = torch.rand((1, H, W, C), device=dev, generator=g) ** 12
     psf /= psf.norm()
     frames = torch.rand((B, H, W, C), device=dev, generator=g)       # same on every rank (same seed)
 
+    from lenslesspicam_amd.dist import ShardedReconstructor
+
+    sharded = ShardedReconstructor(lpa.ADMM, psf)      # the solver (handle, PSF spectrum, workspace) is built ONCE
+
     def step():
-        return reconstruct_sharded(lpa.ADMM, psf, frames, n_iter=n_iter)
+        return sharded(frames, n_iter=n_iter)
 
     for _ in range(max(args.warmup, 1)):
         step()
@@ -123,12 +129,92 @@ def run_c4(args, rank, world, dev, dist):
             "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "C4: 64 frames 270x480x3, ADMM-TV 20 iterations, frames block-sharded over the "
-                                   "ranks, one all-gather per step (includes solver construction per step)",
+                                   "ranks, one all-gather per step (solver built once, outside the timed region)",
                        "frames_per_gpu": -(-B // world)},
         }), flush=True)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def kernel_table(handle, prof):
+    """per-kernel mean launch time (HIP events on the solver's stream) and algorithmic GB/s"""
+    from lenslesspicam_amd import _native
+
+    kernels = {}
+    for i, name in enumerate(_native.KERNEL_NAMES):
+        ms, n = prof[name]
+        if n:
+            b = handle.kernel_bytes(i)
+            kernels[name] = {"ms": round(ms, 4), "launches": n, "alg_GB": round(b / 1e9, 3),
+                             "GBps": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                             "frac_of_peak": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
+    return kernels
+
+
+def timed_config(name, rec, call, units_per_call, unit, reps, note):
+    """One BASELINE config other than the headline: `reps` timed calls after one warm-up call, events on."""
+    call()
+    torch.cuda.synchronize()
+    rec._handle.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        call()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    prof = rec._handle.profile_read()
+    rec._handle.profile_enable(False)
+    kern = kernel_table(rec._handle, prof)
+    alg = sum(v["alg_GB"] * v["launches"] for v in kern.values()) / reps       # algorithmic GB per call
+    busy = sum(v["ms"] * v["launches"] for v in kern.values()) / reps           # kernel ms per call
+    return {"config": name, "value": round(units_per_call / dt, 2), "unit": unit, "ms_per_call": round(dt * 1e3, 3),
+            "alg_GB_per_call": round(alg, 3),
+            "whole_call_frac_of_peak": round(alg / dt / HBM_PEAK_GBS, 4),       # algorithmic bytes / wall time / 8 TB/s
+            "kernel_ms_per_call": round(busy, 3), "kernels": kern, "note": note}
+
+
+def other_configs(dev):
+    """Short legs for the BASELINE configs bench.py's headline does not cover (C1, C3, C4, C5), one GPU, synthetic
+    inputs of SURVEY 8(d)'s shapes (random frames: timing does not depend on the pixel values)."""
+    import lenslesspicam_amd as lpa
+
+    def rand_inputs(D, H, W, C, B, seed=0):
+        g = torch.Generator(device=dev).manual_seed(seed)
+        psf = torch.rand((D, H, W, C), device=dev, generator=g) ** 12
+        psf /= psf.norm()
+        return psf, torch.rand((B, H, W, C), device=dev, generator=g)
+
+    out = []
+    psf, y = rand_inputs(1, 270, 480, 3, 1)
+    rec = lpa.ADMM(psf)
+    rec.set_data(y[0])
+    out.append(timed_config("C1: 270x480x3 ADMM 5 iterations (apply = reset + 5 it + read-out)", rec,
+                            lambda: rec.apply(n_iter=5, disp_iter=None), 5, "iterations/s", 20, "profile/admm.py size"))
+    del rec
+    psf, y = rand_inputs(1, 3040, 4056, 3, 1)
+    fis = lpa.FISTA(psf)
+    fis.set_data(y[0])
+    out.append(timed_config("C3: 3040x4056x3 FISTA, 60 of the 300 iterations", fis,
+                            lambda: fis.apply(n_iter=60, disp_iter=None), 60, "iterations/s", 1,
+                            "iteration cost is constant: 300 it = 5x this call"))
+    del fis
+    torch.cuda.empty_cache()
+    psf, y = rand_inputs(1, 270, 480, 3, 64)
+    r4 = lpa.ADMM(psf)
+    r4.set_data(y[:, None])
+    out.append(timed_config("C4: batch of 64 x 270x480x3, ADMM 20 iterations, ONE GPU (8 GPUs: 8 frames each)", r4,
+                            lambda: r4.apply_batch(n_iter=20), 64 * 20, "frame-iterations/s", 3,
+                            "solver built once; sharded form: bench.py --config c4"))
+    del r4
+    psf, y = rand_inputs(16, 1080, 1920, 3, 1)
+    r5 = lpa.ADMM(psf)
+    r5.set_data(y[0])
+    out.append(timed_config("C5: 16 depth planes x 1080x1920x3, ADMM 50 iterations", r5,
+                            lambda: r5.apply(n_iter=50, disp_iter=None), 50, "iterations/s", 1,
+                            f"{r5._handle.workspace_bytes() / 1e9:.1f} GB of HBM"))
+    del r5
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -228,20 +314,18 @@ def main():
         kbytes = rec._handle.kernel_bytes(kid)
         k_ms, k_n = prof["spatial"]
         achieved = kbytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_src = None, None
         tf = os.path.join(ROOT, "profiles", "k1_traffic.json")
         if os.path.exists(tf) and args.algo == "admm" and (H, W) == (3040, 4056):
             try:
-                traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tf))
+                traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = ("read from profiles/k1_traffic.json (separate rocprofv3 --pmc passes of "
+                               f"{tj.get('kernel', 'the kernel')}, snapshot {tj.get('snapshot', '?')}; PMC counters cannot "
+                               "be collected inside this run)")
             except Exception:
                 traffic = None
-        kernels = {}
-        for i, name in enumerate(_native.KERNEL_NAMES):
-            ms, n = prof[name]
-            if n:
-                b = rec._handle.kernel_bytes(i)
-                kernels[name] = {"ms": round(ms, 4), "launches": n, "alg_GB": round(b / 1e9, 3),
-                                 "GBps": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+        kernels = kernel_table(rec._handle, prof)
         result = {
             "metric": "ADMM iterations/sec at 4056x3040x3, 100 iters" if args.algo == "admm"
             else "FISTA iterations/sec at 4056x3040x3",
@@ -264,14 +348,18 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_admm_spatial (fused prox/update)" if args.algo == "admm" else "k_rinv_gd_update",
+                "kernel": "fused ADMM prox / dual-update kernel (LPC_K_SPATIAL)" if args.algo == "admm"
+                else "k_rinv_gd_update (inverse rows + fused projected update)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "alg_bytes_per_launch": kbytes, "avg_launch_ms": round(k_ms, 4), "launches_timed": k_n,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_src,
             },
             "kernels": kernels,
             "alg_GB_per_iteration": round(sum(v["alg_GB"] for v in kernels.values()), 3),
+            "survey_model_GB_per_iteration": round(rec._handle.model_bytes() / 1e9, 3),
+            "whole_iteration_frac_of_peak": round(rec._handle.model_bytes() * total_iters / world / elapsed / 1e9
+                                                  / HBM_PEAK_GBS, 4),
             "device_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
             "hbm_workspace_GB": round(rec._handle.workspace_bytes() / 1e9, 2),
         }
@@ -281,7 +369,6 @@ def main():
         import psutil
 
         cores = os.cpu_count() or 1
-        torch.set_num_threads(cores)
         avail_gb = psutil.virtual_memory().available / 1e9
         need_gb = 32.0 * hp * wp * C * 4 / 1e9  # ~32 padded float32 arrays incl. complex spectra + temporaries
         bH, bW, note = H, W, ""
@@ -293,32 +380,60 @@ def main():
         else:
             psf_c = orc.synthetic_psf(1, bH, bW, C, seed=0)
             y_c = np.random.default_rng(0).random((bH, bW, C), dtype=np.float32)
-        log(f"cpu baseline: oracle set-up at {bH}x{bW} on {cores} threads")
+        torch.set_num_threads(min(cores, 64))
+        log(f"cpu baseline: oracle set-up at {bH}x{bW}")
         o = orc.ADMMOracle(psf_c)
         o.set_data(y_c)
-        log("cpu baseline: timing iterations")
+        # thread count: every host thread over-subscribes the FFTs of a 12-MP frame (round 1: 256 threads were slower
+        # than 8) -- one iteration each at 64 threads and at all of them decides; both count as iterations 1 and 2
+        trial = {}
+        for nt in sorted({min(cores, 64), cores}):
+            torch.set_num_threads(nt)
+            t0 = time.perf_counter()
+            o.step()
+            trial[nt] = time.perf_counter() - t0
+        best = min(trial, key=trial.get)
+        torch.set_num_threads(best)
+        log(f"cpu baseline: 1 iteration took {', '.join(f'{v:.1f} s at {k} threads' for k, v in trial.items())}; "
+            f"timing {args.cpu_iters} iterations at {best}")
         t0 = time.perf_counter()
         for _ in range(args.cpu_iters):
             o.step()
         cpu_s = time.perf_counter() - t0
         cpu_ips = args.cpu_iters / cpu_s
+        cpu_done = len(trial) + args.cpu_iters
         log(f"cpu baseline: {cpu_s:.1f} s for {args.cpu_iters} iterations")
         result["cpu_baseline"] = {
-            "value": round(cpu_ips, 5), "unit": "iterations/s", "cores": torch.get_num_threads(),
+            "value": round(cpu_ips, 5), "unit": "iterations/s", "cores": best, "host_threads": cores,
             "kind": "port",
-            "sample": f"{args.cpu_iters} ADMM iterations of the same {bH}x{bW}x{C} frame (oracle: torch-CPU float32 "
-                      f"restatement of the reference, set-up excluded){note}",
+            "sample": f"{args.cpu_iters} ADMM iterations (the 3rd..{cpu_done}th) of the same {bH}x{bW}x{C} frame; oracle = "
+                      f"torch-CPU float32 restatement of the reference, set-up excluded; thread count = the faster of "
+                      f"{sorted(trial)} on a 1-iteration trial{note}",
         }
         result["speedup_vs_cpu"] = round(result["value"] / cpu_ips, 1) if (bH, bW) == (H, W) else None
         if not args.no_parity:
             parity = {}
             if (bH, bW) == (H, W):
-                got = rec.apply(n_iter=args.cpu_iters, disp_iter=None)       # (D,H,W,C), formed image
-                ref = o.form_image()[0]                                      # same _form_image on the oracle
-                parity["full_size_rel_err_after_sample"] = float(
-                    (got.cpu() - ref).abs().max() / ref.abs().max())
-                parity["full_size_iters"] = args.cpu_iters
-            del o
+                # full size: engine vs the float32 oracle after the iterations the baseline just ran, and vs the
+                # float64 oracle (truth: the float32 CPU backend itself drifts ~4e-5 at this size) after parity_iters
+                got = rec.apply(n_iter=cpu_done, disp_iter=None)
+                ref = o.form_image()[0]
+                parity["full_size_rel_err_vs_float32_oracle"] = float((got.cpu() - ref).abs().max() / ref.abs().max())
+                parity["full_size_iters_float32"] = cpu_done
+                del o
+                log(f"parity: {args.parity_iters} iterations of the float64 oracle at full size")
+                o64 = orc.ADMMOracle(psf_c, dtype=torch.float64)
+                o64.set_data(y_c)
+                t64 = o64.apply(args.parity_iters)
+                del o64
+                got = rec.apply(n_iter=args.parity_iters, disp_iter=None).cpu()
+                parity["full_size_rel_err_vs_float64_oracle"] = float((got.double() - t64).abs().max() / t64.abs().max())
+                parity["full_size_iters_float64"] = args.parity_iters
+                sc = scene.cpu().numpy()
+                parity["full_size_psnr_delta_db"] = orc.psnr(got[0].numpy(), sc) - orc.psnr(t64[0].float().numpy(), sc)
+                del t64
+            else:
+                del o
             # PSNR delta after the full iteration count on the DiffuserCam-sized frame
             torch.set_num_threads(min(cores, 16))  # small FFTs: 256 threads only thrash
             log("parity: 100-iteration oracle run at 270x480x3")
@@ -336,6 +451,13 @@ def main():
             parity["rel_err_270x480_100it"] = float(np.abs(g2 - c2).max() / np.abs(c2).max())
             result["parity"] = parity
             log("parity done")
+
+    if rank == 0 and world == 1 and not args.no_other_configs and args.algo == "admm" and args.dtype == "float32":
+        log("other BASELINE configs (C1, C3, C4, C5)")
+        del rec
+        torch.cuda.empty_cache()
+        result["other_configs"] = other_configs(dev)
+        log("other configs done")
 
     if rank == 0:
         print(json.dumps(result), flush=True)

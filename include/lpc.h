@@ -86,13 +86,17 @@ int lpc_padded_shape(lpc_handle h, int* Hp, int* Wp, int* start_h, int* start_w)
 int lpc_set_psf(lpc_handle h, const lpc_real* dev_psf, void* stream);
 
 /* out = ifftshift(irfft2(rfft2(pad?(x)) * H or conj(H))) cropped if cfg.pad.
- * x, out: (n, D, Hx, Wx, C) with (Hx,Wx) = (H,W) if cfg.pad else (Hp,Wp); n <= cfg.batch.
+ * x: (n, D, Hx, Wx, x_channels), out: (n, D, Hx, Wx, C) with (Hx,Wx) = (H,W) if cfg.pad else (Hp,Wp);
+ * n <= cfg.batch.  x_channels is C, or 1 (a grayscale input against an RGB PSF broadcasts over the channels like
+ * the reference's `vpad[...] = v`, rfft_convolve.py:96-99); anything else is refused (it would be read out of bounds).
  * adjoint = 0: convolve (rfft_convolve.py:133-176); 1: deconvolve (:178-223). */
-int lpc_convolve(lpc_handle h, const lpc_real* dev_x, lpc_real* dev_out, int n, int adjoint, void* stream);
+int lpc_convolve(lpc_handle h, const lpc_real* dev_x, lpc_real* dev_out, int n, int x_channels, int adjoint,
+                 void* stream);
 
 /* ---- solver state: set_data / _set_initial_estimate / reset ------------------------ */
-/* dev_data: (B,H,W,C) with B == cfg.batch.  recon.py:352-381 */
-int lpc_set_data(lpc_handle h, const lpc_real* dev_data, void* stream);
+/* dev_data: (B,H,W,data_channels) with B == cfg.batch; data_channels is C, or 1 (broadcast over the PSF's channels,
+ * as `self._convolver._pad(self._data)` does, admm.py:253 / `- self._data`, gd.py:129).  recon.py:352-381 */
+int lpc_set_data(lpc_handle h, const lpc_real* dev_data, int data_channels, void* stream);
 /* dev_est: image-estimate shape (see top) or NULL to clear.  Takes effect at the next
  * lpc_reset(), like recon.py:383-413. */
 int lpc_set_initial_estimate(lpc_handle h, const lpc_real* dev_est, void* stream);
@@ -205,6 +209,11 @@ int lpc_profile_enable(lpc_handle h, int on);
 int lpc_profile_read(lpc_handle h, double* avg_ms, long* launches);
 /* algorithmic HBM bytes one launch of kernel k moves */
 int lpc_kernel_bytes(lpc_handle h, int kernel_id, double* bytes);
+/* SURVEY.md section 8(d)'s algorithmic bytes of ONE solver iteration of all frames of the handle (the yardstick the
+ * whole iteration is scored against): ADMM 19R + R0 + 13.5S, Nesterov / FISTA 8R0 + 14S, vanilla GD 6R0 + 14S, with
+ * R = padded real array, S = half spectrum, R0 = un-padded array (all planes).  Independent of how many passes the
+ * engine really makes. */
+int lpc_model_bytes(lpc_handle h, double* bytes);
 /* bytes of HBM the handle owns */
 int lpc_workspace_bytes(lpc_handle h, size_t* bytes);
 

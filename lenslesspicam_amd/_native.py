@@ -74,8 +74,8 @@ class Lib:
             "lpc_destroy": [vp],
             "lpc_padded_shape": [vp, ip, ip, ip, ip],
             "lpc_set_psf": [vp, fp, vp],
-            "lpc_convolve": [vp, fp, fp, C.c_int, C.c_int, vp],
-            "lpc_set_data": [vp, fp, vp],
+            "lpc_convolve": [vp, fp, fp, C.c_int, C.c_int, C.c_int, vp],
+            "lpc_set_data": [vp, fp, C.c_int, vp],
             "lpc_set_initial_estimate": [vp, fp, vp],
             "lpc_reset": [vp, vp],
             "lpc_set_momentum": [vp, C.c_double, C.c_double, C.c_double],
@@ -93,6 +93,7 @@ class Lib:
             "lpc_profile_read": [vp, C.POINTER(C.c_double), C.POINTER(C.c_long)],
             "lpc_kernel_bytes": [vp, C.c_int, C.POINTER(C.c_double)],
             "lpc_workspace_bytes": [vp, C.POINTER(C.c_size_t)],
+            "lpc_model_bytes": [vp, C.POINTER(C.c_double)],
             "lpc_reconstruction_error": [vp, fp, fp, C.c_int, fp, vp],
             "lpc_image_metrics": [fp, fp, C.c_long, C.c_int, C.c_int, fp, vp],
             "lpc_preprocess_frames": [C.POINTER(PrepConfig), vp, C.c_int, fp, fp, vp],
@@ -165,11 +166,11 @@ class Handle:
     def set_psf(self, ptr, stream=0):
         self._c(self.lib.dll.lpc_set_psf(self.h, ptr, stream))
 
-    def convolve(self, x_ptr, out_ptr, n, adjoint, stream=0):
-        self._c(self.lib.dll.lpc_convolve(self.h, x_ptr, out_ptr, n, int(adjoint), stream))
+    def convolve(self, x_ptr, out_ptr, n, x_channels, adjoint, stream=0):
+        self._c(self.lib.dll.lpc_convolve(self.h, x_ptr, out_ptr, n, int(x_channels), int(adjoint), stream))
 
-    def set_data(self, ptr, stream=0):
-        self._c(self.lib.dll.lpc_set_data(self.h, ptr, stream))
+    def set_data(self, ptr, channels, stream=0):
+        self._c(self.lib.dll.lpc_set_data(self.h, ptr, int(channels), stream))
 
     def set_initial_estimate(self, ptr, stream=0):
         self._c(self.lib.dll.lpc_set_initial_estimate(self.h, ptr, stream))
@@ -232,6 +233,11 @@ class Handle:
     def kernel_bytes(self, kid):
         b = C.c_double()
         self._c(self.lib.dll.lpc_kernel_bytes(self.h, kid, C.byref(b)))
+        return b.value
+
+    def model_bytes(self):
+        b = C.c_double()
+        self._c(self.lib.dll.lpc_model_bytes(self.h, C.byref(b)))
         return b.value
 
     def workspace_bytes(self):

@@ -47,7 +47,7 @@ class ADMM(ReconstructionAlgorithm):
                 raise NotImplementedError(
                     f"Unsupported denoiser: {denoiser['network']!r} (pretrained networks are outside the hot "
                     "path; pass the denoising function itself as denoiser['network'])")
-            self._pnp = (denoiser["network"], denoiser["noise_level"], bool(denoiser["use_dual"]))   # admm.py:128
+            self._pnp = (denoiser["network"], denoiser["noise_level"], bool(denoiser.get("use_dual", False)))
         super().__init__(psf, dtype, pad=False, norm=norm, denoiser=None, reset=False, **kwargs)
         if self._pnp is not None:
             self._denoiser, self._denoiser_noise_level, self._denoiser_use_dual = self._pnp
@@ -87,10 +87,21 @@ class ADMM(ReconstructionAlgorithm):
     _forward_out = property(lambda self: self._padded_state("forward_out"))
 
 
-def apply_admm(psf, data, n_iter, verbose=False, **kwargs):
-    """Array-level counterpart of ``lensless.recon.admm.apply_admm`` (admm.py:400-419); file
-    loading stays with the caller (``lensless.utils.io.load_data`` is out of scope)."""
-    recon = ADMM(psf, n_iter=n_iter, **kwargs)
+def apply_admm(psf_fp, data_fp, n_iter, verbose=False, **kwargs):
+    """``lensless.recon.admm.apply_admm`` (admm.py:400-419): ``load_data(psf_fp, data_fp, plot=False, **kwargs)`` ->
+    ``ADMM(psf, n_iter=n_iter)`` -> ``set_data`` -> timed ``apply(plot=False)``.  The two paths name ``.npy`` /
+    ``.npz`` files (``prep.load_data``; the keywords are ``load_data``'s).  Additive: when arrays are passed instead
+    of paths they are taken as the prepared ``psf`` / ``data`` and the keywords go to the ``ADMM`` constructor."""
+    import os
+
+    if isinstance(psf_fp, (str, os.PathLike)):
+        from .prep import load_data
+
+        psf, data = load_data(psf_fp=psf_fp, data_fp=data_fp, plot=False, **kwargs)
+        recon = ADMM(psf, n_iter=n_iter)
+    else:
+        psf, data = psf_fp, data_fp
+        recon = ADMM(psf, n_iter=n_iter, **kwargs)
     recon.set_data(data)
     start = time.time()
     res = recon.apply(plot=False)

@@ -126,6 +126,7 @@ struct lpc_engine {
   // unrolled FISTA (unrolled_fista.py:91-106): per-iteration step alpha[i][c] and momentum factor coef[i]
   std::vector<real> fista_coef;
   real* galpha_sched = nullptr;  // device [n][C]
+  size_t galpha_sched_cap = 0;   // elements allocated for it (re-used by later schedules that fit)
   int fista_sched_n = 0;
   // common
   real* Y = nullptr;         // data planes, un-padded [Pdata][H][W]
@@ -156,12 +157,16 @@ static int dev_alloc(Engine* e, Tp** out, size_t count) {
 // generic launcher (+ optional event bracketing of hot-loop kernels)
 template <class K, class... A>
 static int launch_k(Engine* e, int kid, K kernel, dim3 grid, int nt, size_t smem, A... args) {
-  static thread_local std::unordered_set<const void*> big_smem_done;
+  // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of the function: remember (device, function)
+  static thread_local std::unordered_set<uint64_t> big_smem_done;
   if (smem > 48 * 1024) {
     const void* fn = (const void*)kernel;
-    if (!big_smem_done.count(fn)) {
+    int dev = 0;
+    LPC_RT(rt::current_device(&dev));
+    const uint64_t key = (uint64_t)(uintptr_t)fn ^ ((uint64_t)(dev + 1) << 56);
+    if (!big_smem_done.count(key)) {
       LPC_RT(rt::set_max_dyn_smem(fn, smem > 65536 ? 160 * 1024 : 65536));
-      big_smem_done.insert(fn);
+      big_smem_done.insert(key);
     }
   }
 #if !defined(LPC_SIMT_EMU)
@@ -235,7 +240,9 @@ static int plan_from_radices(Engine* e, Fft1dPlan& p, int n, const std::vector<i
   if (std::getenv("LPC_NO_SKEW")) p.skew_ok = 0;
   // diagnostic only (results are garbage): no butterflies at all, every pass degenerates to "tile in, tile out"
   // through LDS -- times the memory access pattern of the passes alone (profiles/r01b_notes.md)
+#ifdef LPC_DEBUG_KNOBS   // never in the product build: the results are garbage by construction
   if (std::getenv("LPC_DEBUG_NOFFT")) p.nst = 0;
+#endif
   real2* tw = nullptr;
   LPC_OK(make_twiddles(e, n, &tw));
   p.tw = tw;
@@ -562,10 +569,17 @@ static int convolve_planar(Engine* e, const real* xin, real* xout, int nplanes, 
 
 // ------------------------------------------------------------------ layout helpers --
 static int hwc_to_planar(Engine* e, const real* src, real* dst, int nimg, int rows, int cols, int pitch,
-                         long dplane) {
+                         long dplane, int src_channels = 0) {
   const long n = (long)rows * cols * e->cfg.channels;
   return launch_k(e, -1, k_hwc_to_planar<256>, grid1d(n, 256, nimg), 256, 0, src, dst, rows, cols,
-                  e->cfg.channels, pitch, dplane);
+                  e->cfg.channels, pitch, dplane, src_channels > 0 ? src_channels : e->cfg.channels);
+}
+// channel count of a caller's buffer: the handle's own, or 1 (broadcast) -- anything else would make the kernels
+// read past the end of the buffer
+static int check_channels(const Engine* e, int ch, const char* who) {
+  if (ch == e->cfg.channels || ch == 1) return 0;
+  return fail(std::string(who) + ": buffer has " + std::to_string(ch) + " channel(s), the PSF " +
+              std::to_string(e->cfg.channels) + " (only 1 -> C broadcasts)");
 }
 static int planar_to_hwc(Engine* e, real* src, real* dst, int nimg, int rows, int cols, int pitch, long splane,
                          int row0, int col0, int clamp) {
@@ -873,8 +887,9 @@ int lpc_set_psf(lpc_handle e, const real* dev_psf, void* stream) {
   return 0;
 }
 
-int lpc_convolve(lpc_handle e, const real* dev_x, real* dev_out, int n, int adjoint, void* stream) {
+int lpc_convolve(lpc_handle e, const real* dev_x, real* dev_out, int n, int x_channels, int adjoint, void* stream) {
   if (!e || !dev_x || !dev_out) return fail("lpc_convolve: null argument");
+  LPC_OK(check_channels(e, x_channels, "lpc_convolve"));
   if (!e->psf_set) return fail("lpc_convolve: PSF not set");
   if (n < 1 || n > e->cfg.batch) return fail("lpc_convolve: n exceeds the configured batch");
   if (e->cfg.algo != LPC_ALGO_CONV) return fail("lpc_convolve: handle was not created with LPC_ALGO_CONV");
@@ -887,23 +902,24 @@ int lpc_convolve(lpc_handle e, const real* dev_x, real* dev_out, int n, int adjo
   real* xout = (real*)e->gx;
   const int nimg = n * e->cfg.depth;
   if (padded_io) {
-    LPC_OK(hwc_to_planar(e, dev_x, xin, nimg, g.Hp, g.Wp, g.rpitch, g.rplane));
+    LPC_OK(hwc_to_planar(e, dev_x, xin, nimg, g.Hp, g.Wp, g.rpitch, g.rplane, x_channels));
     LPC_OK(convolve_planar(e, xin, xout, nplanes, true, adjoint != 0));
     LPC_OK(planar_to_hwc(e, xout, dev_out, nimg, g.Hp, g.Wp, g.rpitch, g.rplane, 0, 0, 0));
   } else {
-    LPC_OK(hwc_to_planar(e, dev_x, xin, nimg, g.H, g.W, g.W, g.uplane));
+    LPC_OK(hwc_to_planar(e, dev_x, xin, nimg, g.H, g.W, g.W, g.uplane, x_channels));
     LPC_OK(convolve_planar(e, xin, xout, nplanes, false, adjoint != 0));
     LPC_OK(planar_to_hwc(e, xout, dev_out, nimg, g.H, g.W, g.W, g.uplane, 0, 0, 0));
   }
   return 0;
 }
 
-int lpc_set_data(lpc_handle e, const real* dev_data, void* stream) {
+int lpc_set_data(lpc_handle e, const real* dev_data, int data_channels, void* stream) {
   if (!e || !dev_data) return fail("lpc_set_data: null argument");
   if (e->cfg.algo == LPC_ALGO_CONV) return fail("lpc_set_data: operator-only handle");
+  LPC_OK(check_channels(e, data_channels, "lpc_set_data"));
   e->stream = (lpcStream_t)stream;
   const PlaneGeom& g = e->g;
-  LPC_OK(hwc_to_planar(e, dev_data, e->Y, e->cfg.batch, g.H, g.W, g.W, g.uplane));
+  LPC_OK(hwc_to_planar(e, dev_data, e->Y, e->cfg.batch, g.H, g.W, g.W, g.uplane, data_channels));
   e->data_set = true;
   return 0;
 }
@@ -964,7 +980,17 @@ int lpc_set_fista_schedule(lpc_handle e, int n, const real* alpha, const real* c
   if (n <= 0) return 0;
   if (!alpha || !coef) return fail("lpc_set_fista_schedule: null array");
   const int C = e->cfg.channels;
-  LPC_OK(dev_alloc(e, &e->galpha_sched, (size_t)n * C));
+  if (e->galpha_sched && e->galpha_sched_cap < (size_t)n * C) {   // grown: give the old table back
+    (void)rt::stream_sync(e->stream);
+    e->allocs.erase(std::remove(e->allocs.begin(), e->allocs.end(), (void*)e->galpha_sched), e->allocs.end());
+    e->total_bytes -= e->galpha_sched_cap * sizeof(real);
+    (void)rt::dev_free(e->galpha_sched);
+    e->galpha_sched = nullptr;
+  }
+  if (!e->galpha_sched) {
+    LPC_OK(dev_alloc(e, &e->galpha_sched, (size_t)n * C));
+    e->galpha_sched_cap = (size_t)n * C;
+  }
   LPC_OK(upload(e, e->galpha_sched, alpha, (size_t)n * C * sizeof(real)));
   e->fista_coef.assign(coef, coef + n);
   e->fista_sched_n = n;
@@ -1071,6 +1097,13 @@ int lpc_form_image(lpc_handle e, real* dev_out, void* stream) {
   e->stream = (lpcStream_t)stream;
   const PlaneGeom& g = e->g;
   const int nimg = e->cfg.batch * e->cfg.depth;
+  if (e->cfg.algo == LPC_ALGO_ADMM && e->has_init && e->iters_done == 0 && e->init_est) {
+    // Right after reset() the reference's state still ALIASES the stored initial estimate (admm.py:154-155,
+    // `self._image_est = self._initial_est`), so this read-out's in-place clamp (admm.py:337) lands in the initial
+    // estimate too: every later reset() starts from the clamped one.  (apply(plot/save=...) does exactly this
+    // before its loop, recon.py:563-566.)
+    LPC_OK(launch_k(e, -1, k_clamp_window_inplace<256>, grid1d((long)g.H * g.W, 256, e->P), 256, 0, g, e->init_est));
+  }
   if (e->cfg.algo == LPC_ALGO_ADMM && e->pnp_mode) {   // explicit state: the clamp really is in place
     LPC_OK(planar_to_hwc(e, e->V[e->vcur], dev_out, nimg, g.H, g.W, g.rpitch, g.rplane, g.sh, g.sw, 1));
     return launch_k(e, -1, k_clamp_window_inplace<256>, grid1d((long)g.H * g.W, 256, e->P), 256, 0, g,
@@ -1348,6 +1381,17 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
     return fail("lpc_kernel_bytes: operator-only handle");
   }
   *bytes = b;
+  return 0;
+}
+
+int lpc_model_bytes(lpc_handle e, double* bytes) {
+  if (!e || !bytes) return fail("null argument");
+  const PlaneGeom& g = e->g;
+  const double eb = (double)sizeof(real);
+  const double R = eb * g.Hp * g.Wp * e->P, S = 2 * eb * g.Hp * g.Wc * e->P;
+  if (e->cfg.algo == LPC_ALGO_ADMM) *bytes = 19.0 * R + eb * g.H * g.W * e->Pdata + 13.5 * S;
+  else if (e->cfg.algo >= LPC_ALGO_GD) *bytes = (e->cfg.algo == LPC_ALGO_GD ? 6.0 : 8.0) * eb * g.H * g.W * e->P + 14.0 * S;
+  else return fail("lpc_model_bytes: operator-only handle");
   return 0;
 }
 

@@ -1167,17 +1167,20 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
 
 // ========================================================= layout / setup kernels ==
 // channels-last (n, rows, cols, C) <-> planar (n*C planes)[rows][pitch]
+// Csrc: channels of the source, C or 1 (a one-channel source is broadcast over the C planes, the way the
+// reference's `vpad[...] = v` / `rfft2(x) * H` broadcast a grayscale input against an RGB PSF)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_hwc_to_planar(const real* LPC_RESTRICT src, real* LPC_RESTRICT dst,
-                                                       int rows, int cols, int C, int pitch, long dplane) {
+                                                       int rows, int cols, int C, int pitch, long dplane, int Csrc) {
   const long n = (long)rows * cols * C;
+  const long nsrc = (long)rows * cols * Csrc;
   const long img = blockIdx.y;
   for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
     const int c = (int)(e % C);
     const long rc = e / C;
     const int col = (int)(rc % cols);
     const int row = (int)(rc / cols);
-    dst[(img * C + c) * dplane + (long)row * pitch + col] = src[img * n + e];
+    dst[(img * C + c) * dplane + (long)row * pitch + col] = src[img * nsrc + (Csrc == C ? e : rc)];
   }
 }
 

@@ -73,6 +73,7 @@ static inline lpcError_t copy_d2h_async(void* d, const void* s, size_t n, lpcStr
 static inline lpcError_t stream_sync(lpcStream_t) { return 0; }
 static inline lpcError_t last_error() { return 0; }
 static inline lpcError_t device_count(int* n) { *n = 1; return 0; }
+static inline lpcError_t current_device(int* d) { *d = 0; return 0; }
 static inline lpcError_t set_max_dyn_smem(const void*, size_t) { return 0; }
 static inline const char* backend_name() { return "simt-emu(test-only)"; }
 }  // namespace rt
@@ -109,6 +110,7 @@ static inline lpcError_t copy_d2h_async(void* d, const void* s, size_t n, lpcStr
 static inline lpcError_t stream_sync(lpcStream_t s) { return hipStreamSynchronize(s); }
 static inline lpcError_t last_error() { return hipGetLastError(); }
 static inline lpcError_t device_count(int* n) { return hipGetDeviceCount(n); }
+static inline lpcError_t current_device(int* d) { return hipGetDevice(d); }
 static inline lpcError_t set_max_dyn_smem(const void* fn, size_t bytes) {
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }

@@ -111,6 +111,11 @@ class NesterovGradientDescent(GradientDescent):
         if p != 0 or mu != 0.9:
             self._handle.set_momentum(float(p), float(mu), 0.0)
 
+    def _after_new_handle(self):
+        # a reset(p, mu) override survives a change of the batch size, like the reference's attributes do
+        if self._p != 0 or self._mu != 0.9:
+            self._handle.set_momentum(float(self._p), float(self._mu), 0.0)
+
 
 class FISTA(GradientDescent):
     _ALGO = _native.ALGO_FISTA
@@ -129,10 +134,25 @@ class FISTA(GradientDescent):
         if tk:
             self._handle.set_momentum(0.0, 0.9, float(tk))
 
+    def _after_new_handle(self):
+        if getattr(self, "_tk", self._initial_tk) != self._initial_tk:     # a reset(tk) override, see above
+            self._handle.set_momentum(0.0, 0.9, float(self._tk))
 
-def apply_gradient_descent(psf, data, n_iter, verbose=False, proj=non_neg, **kwargs):
-    """Array-level counterpart of gd.py:244-263."""
-    recon = GradientDescent(psf, n_iter=n_iter, proj=proj, **kwargs)
+
+def apply_gradient_descent(psf_fp, data_fp, n_iter, verbose=False, proj=non_neg, **kwargs):
+    """``lensless.recon.gd.apply_gradient_descent`` (gd.py:244-263), file-path form for ``.npy`` / ``.npz`` inputs
+    (keywords = ``load_data``'s); arrays instead of paths are taken as prepared ``psf`` / ``data`` (keywords then go
+    to the constructor), see ``apply_admm``."""
+    import os
+
+    if isinstance(psf_fp, (str, os.PathLike)):
+        from .prep import load_data
+
+        psf, data = load_data(psf_fp=psf_fp, data_fp=data_fp, plot=False, **kwargs)
+        recon = GradientDescent(psf, n_iter=n_iter, proj=proj)
+    else:
+        psf, data = psf_fp, data_fp
+        recon = GradientDescent(psf, n_iter=n_iter, proj=proj, **kwargs)
     recon.set_data(data)
     start = time.time()
     res = recon.apply(plot=False)

@@ -101,16 +101,24 @@ def preprocess_psf(raw, bg_pix=(5, 25), flip=False, flip_ud=False, flip_lr=False
 
 
 def preprocess_data(raw_psf, raw_data, bg_pix=(5, 25), flip=False, flip_ud=False, flip_lr=False, gray=False,
-                    single_psf=False, normalize=False, bgr_input=False, dtype=None, return_bg=False):
+                    single_psf=False, normalize=False, bgr_input=False, dtype=None, return_bg=False,
+                    flip_psf=False):
     """``load_data`` (io.py:462-552) on arrays: the PSF's background level (as a fraction of full scale) is
     re-scaled to the frame's bit depth and removed from the frame; both come back as float device tensors,
-    psf (D,H,W,C') and data (1,H,W,C') [or (B,H,W,C') for a batch of frames]."""
+    psf (D,H,W,C') and data (1,H,W,C') [or (B,H,W,C') for a batch of frames].
+
+    ``flip_psf``: ``load_data`` hands ``flip`` / ``flip_ud`` / ``flip_lr`` (and ``bgr_input``) to ``load_psf`` too
+    (io.py:487-489), which applies them only when the PSF is an IMAGE file (through ``load_image``, io.py:293-304) and
+    ignores them for ``.npy`` / ``.npz`` stacks (io.py:272-291).  False (default) is the ``.npy`` branch the golden
+    vectors cover; pass True for a raw PSF that came out of an image file, so that PSF and frame keep the same
+    orientation."""
     dtype = dtype or "float32"
     if dtype not in ("float32", "float64"):
         raise ValueError("dtype must be float32 or float64")
     c_data = 1 if raw_data.ndim == 2 else int(raw_data.shape[-1])
+    pf = dict(flip=flip, flip_ud=flip_ud, flip_lr=flip_lr, bgr_input=bgr_input) if flip_psf else {}
     psf, bg = preprocess_psf(raw_psf, bg_pix=bg_pix, single_psf=single_psf, gray=gray, out_channels=c_data,
-                             return_bg=True, dtype=dtype)
+                             return_bg=True, dtype=dtype, **pf)
     data = preprocess_frames(raw_data, bg=bg if bg_pix is not None else None, flip=flip, flip_ud=flip_ud,
                              flip_lr=flip_lr, bgr_input=bgr_input, normalize=normalize, gray=gray, dtype=dtype)
     if data.shape[-1] != psf.shape[-1]:
@@ -119,3 +127,58 @@ def preprocess_data(raw_psf, raw_data, bg_pix=(5, 25), flip=False, flip_ud=False
         elif data.shape[-1] == 1:    # io.py:561-567
             data = data.repeat(1, 1, 1, psf.shape[-1])
     return (psf, data, bg) if return_bg else (psf, data)
+
+
+def _load_array(fp):
+    """``.npy`` / ``.npz`` only (io.py:122-123, 272-291): image decoding (cv2 / rawpy) is in front of the hot path."""
+    import os
+
+    fp = os.fspath(fp)
+    if fp.endswith(".npy"):
+        return np.load(fp)
+    if fp.endswith(".npz"):
+        archive = np.load(fp)
+        if len(archive.files) == 0:
+            raise ValueError("No arrays in .npz archive")
+        return archive[archive.files[0]]
+    raise NotImplementedError(
+        f"{fp}: only .npy / .npz inputs are read here; decoding image files (cv2 / rawpy in the reference's "
+        "load_image) is outside the accelerated path -- decode with your loader and call preprocess_data()")
+
+
+def load_data(psf_fp, data_fp, background_fp=None, return_bg=False, remove_background=True, return_float=True,
+              downsample=None, bg_pix=(5, 25), plot=True, flip=False, flip_ud=False, flip_lr=False, bayer=False,
+              blue_gain=None, red_gain=None, gamma=None, gray=False, dtype=None, single_psf=False, shape=None,
+              use_torch=False, torch_device="cpu", normalize=False, bgr_input=True):
+    """File-path form of the preparation step with ``lensless.utils.io.load_data``'s signature (io.py:388-412), for
+    ``.npy`` / ``.npz`` inputs: what ``scripts/recon/admm.py:30-51`` and ``apply_admm`` (admm.py:400-403) call.
+    Arithmetic on the device (``preprocess_data``); ``use_torch=True, torch_device="cuda"`` keeps PSF and frame in
+    HBM, otherwise NumPy arrays come back like the reference's default.  ``plot`` / ``gamma`` are accepted and
+    ignored (display only).  Not supported, each with an explicit error: image files, ``bayer=True``,
+    ``background_fp`` (a second capture), ``return_float=False``, ``shape=`` and ``downsample != 1`` unless the
+    arrays already have the PSF's size (resizing is cv2 / torchvision in the reference: no oracle here)."""
+    if shape is None:
+        assert downsample is not None                                     # io.py:465-466
+    if bayer or blue_gain is not None or red_gain is not None:
+        raise NotImplementedError("Bayer demosaicing / colour gains are in front of the accelerated path")
+    if background_fp is not None:
+        raise NotImplementedError("background_fp: pass the background to apply(background=...) instead")
+    if not return_float:
+        raise NotImplementedError("return_float=False (integer outputs) is not a solver input")
+    if shape is not None or (downsample is not None and downsample != 1):
+        raise NotImplementedError("resizing (downsample != 1 / shape=) has no oracle here (cv2 / torchvision absent); "
+                                  "resize in your loader, or capture at the reconstruction size")
+    raw_psf, raw_data = _load_array(psf_fp), _load_array(data_fp)
+    if raw_psf.ndim == 3:                       # io.py:316-319 with use_3d (a .npy PSF): a 3-D stack is (D,H,W), gray
+        raw_psf = raw_psf[..., None]
+    assert raw_psf.ndim == 4, "a .npy / .npz PSF is a depth stack (D,H,W[,C]) (io.py:315-321)"
+    res = preprocess_data(raw_psf, raw_data, bg_pix=bg_pix, flip=flip, flip_ud=flip_ud, flip_lr=flip_lr, gray=gray,
+                          single_psf=single_psf, normalize=normalize, bgr_input=bgr_input, dtype=dtype, return_bg=True)
+    psf, data, bg = res
+    if bg_pix is None:
+        bg = torch.zeros((4,), dtype=psf.dtype, device=psf.device)         # io.py:338 (np.zeros(len(psf.shape)))
+    if use_torch:
+        out = tuple(a.to(torch_device) for a in (psf, data, bg))
+    else:
+        out = tuple(a.cpu().numpy() for a in (psf, data, bg))
+    return out if return_bg else out[:2]

@@ -130,6 +130,10 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
             self._handle.set_psf(self._psf_dev.data_ptr(), self._stream())
             if self._initial_est is not None:
                 self._push_initial_estimate()
+            self._after_new_handle()
+
+    def _after_new_handle(self):
+        """Solver-specific state a fresh handle does not know yet (momentum overrides)."""
 
     # -- reference API ------------------------------------------------------------------
     def reset(self):
@@ -142,6 +146,7 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
             assert isinstance(data, np.ndarray)
         assert len(data.shape) >= 3, "Data must be at least 3D: [..., width, height, channel]."
         assert np.all(self._psf_shape[-3:-1] == np.array(data.shape)[-3:-1]), "PSF and data shape mismatch"
+        self._check_channels(data.shape[-1], "data")
         if len(data.shape) == 3:
             self._data = data[None, None, ...]
         elif len(data.shape) == 4:
@@ -150,13 +155,21 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
             self._data = data
         self._upload_data()
 
+    def _check_channels(self, ch, what):
+        """The reference broadcasts a one-channel array against an RGB PSF (``vpad[...] = v``, rfft_convolve.py:96-99;
+        ``- self._data``, gd.py:129) and fails on three channels against a grayscale PSF (the same assignment cannot
+        broadcast 3 -> 1).  Same rule here, checked up front: the engine reads exactly B*H*W*ch values."""
+        C = int(self._psf_shape[-1])
+        if int(ch) != C and int(ch) != 1:
+            raise ValueError(f"{what} has {int(ch)} channels, the PSF {C}: could not broadcast (only 1 -> {C} does)")
+
     def _upload_data(self):
         d = self._to_dev(self._data)
         assert d.shape[1] == 1, "data must have depth 1 (the measurement is 2-D)"
         B = int(d.shape[0])
         self._ensure_handle(B)
         self._data_dev = d[:, 0].contiguous()
-        self._handle.set_data(self._data_dev.data_ptr(), self._stream())
+        self._handle.set_data(self._data_dev.data_ptr(), int(d.shape[-1]), self._stream())
 
     def _check_est(self, image_est):
         if self.is_torch:
@@ -167,6 +180,10 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
             "Image estimate must be at least 4D: [..., depth, width, height, channel]."
         assert np.all(self._image_est_shape[-3:-1] == np.array(image_est.shape)[-3:-1]), \
             f"Image estimate must be of shape (..., width, height, channel): {self._image_est_shape[-3:-1]}"
+        assert int(image_est.shape[-1]) == int(self._psf_shape[-1]), \
+            f"Image estimate must have the PSF's {int(self._psf_shape[-1])} channel(s)"
+        assert int(image_est.shape[-4]) == int(self._psf_shape[0]), \
+            f"Image estimate must have the PSF's depth {int(self._psf_shape[0])}"
         return image_est[None, ...] if len(image_est.shape) == 4 else image_est
 
     def _set_initial_estimate(self, image_est):
@@ -250,6 +267,11 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
             self.reset()
         if n_iter is None:
             n_iter = self._n_iter
+        # recon.py:563-592: with `plot` or `save` set and `disp_iter` not None, an image is formed BEFORE the loop (when
+        # no `ax` is handed in) and after every iteration i with `(i + 1) % disp_iter == 0` -- Python's modulo, so the
+        # default disp_iter=-1 means EVERY iteration.  Each of those `_form_image()` calls is observable for ADMM,
+        # whose read-out clamps its state in place (admm.py:331-338).  Iterations between two displays run as one
+        # native launch sequence.
         show = (plot or save) and disp_iter is not None
         if show:
             from .plot import plot_image  # optional dependency (matplotlib)
@@ -257,15 +279,16 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
             if ax is None:
                 ax = plot_image(self._get_numpy_data(self._form_image()[0]), gamma=gamma)
             done = 0
-            while done < n_iter:
-                step = min(disp_iter - (done % disp_iter), n_iter - done) if disp_iter > 0 else n_iter - done
-                self._iterate(step)
-                done += step
-                if disp_iter > 0 and done % disp_iter == 0:
-                    self._progress()
-                    ax = plot_image(self._get_numpy_data(self._form_image()[0]), ax=ax, gamma=gamma,
-                                    title=f"Reconstruction after iteration {done}", save=save, name=f"{done}.png",
-                                    pause=plot_pause if plot else None)
+            for k in range(1, n_iter + 1):
+                if k % disp_iter != 0:
+                    continue
+                self._iterate(k - done)
+                done = k
+                self._progress()
+                ax = plot_image(self._get_numpy_data(self._form_image()[0]), ax=ax, gamma=gamma,
+                                title=f"Reconstruction after iteration {k}", save=save, name=f"{k}.png",
+                                pause=plot_pause if plot else None)
+            self._iterate(n_iter - done)
         else:
             ax = None
             self._iterate(n_iter)
@@ -292,8 +315,14 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
         if pred.dim() == 4:
             pred = pred[None]
         y = self._to_dev(lensless)
-        y = y.reshape((-1,) + tuple(y.shape[-3:])).contiguous()          # (B,1,H,W,C) | (H,W,C) -> (B,H,W,C)
+        y = y.reshape((-1,) + tuple(y.shape[-3:]))                       # (B,1,H,W,C) | (H,W,C) -> (B,H,W,C)
         B = int(pred.shape[0])
+        D, H, W, C = (int(v) for v in self._psf_shape)
+        assert tuple(pred.shape[1:]) == (D, H, W, C), \
+            f"prediction must be (..., {D}, {H}, {W}, {C}), got {tuple(pred.shape)}"
+        assert tuple(y.shape[1:3]) == (H, W), "PSF and data shape mismatch"
+        self._check_channels(y.shape[-1], "lensless")
+        y = y.expand(-1, -1, -1, C).contiguous()                         # 1 -> C broadcast, like `- lensless`
         assert y.shape[0] == B, "prediction and lensless must have the same batch size"
         own = psfs is None and B == self._handle_batch
         if own:

@@ -76,19 +76,35 @@ class RealFFTConvolve2D(_Boundary):
                 "permuted (four-step) order and does not export them"
             )
         was_torch = isinstance(x, torch.Tensor)
+        if len(x.shape) not in (4, 5):
+            raise ValueError("Expected 4D or 5D tensor")                     # rfft_convolve.py:91
         xd = self._to_dev(x)
         lead = xd.shape[:-4]
-        D = int(self._psf_shape[0])
+        D, C = int(self._psf_shape[0]), int(self._psf_shape[-1])
+        want = tuple(int(v) for v in (self._psf_shape[-3:-1] if self.pad else self._padded_shape[-3:-1]))
+        if tuple(int(v) for v in xd.shape[-3:-1]) != want:
+            raise ValueError(f"input of spatial size {tuple(xd.shape[-3:-1])}, the operator works on {want}")
         x5 = xd.reshape((-1,) + tuple(xd.shape[-4:]))
         if x5.shape[1] != D:  # broadcasting of depth, like `rfft2(x) * H`
             assert x5.shape[1] == 1, "depth of the input must be 1 or match the PSF"
             x5 = x5.expand(-1, D, -1, -1, -1)
+        Cx = int(x5.shape[-1])
+        split3 = False
+        if Cx != C and Cx != 1:
+            # three channels against a grayscale PSF: `vpad[...] = v` cannot broadcast 3 -> 1 (rfft_convolve.py:96-99),
+            # while the un-padded operator's `rfft2(x) * H` does: every channel is convolved with the one PSF
+            if self.pad or C != 1:
+                raise ValueError(f"could not broadcast an input with {Cx} channels against a PSF with {C}")
+            x5 = x5.permute(0, 4, 1, 2, 3).reshape((-1,) + tuple(x5.shape[1:4]) + (1,))    # channels -> batch items
+            split3 = True
         x5 = x5.contiguous()
         n = int(x5.shape[0])
         if n > self._handle_batch:
             self._make(n)
-        out = torch.empty_like(x5)
-        self._handle.convolve(x5.data_ptr(), out.data_ptr(), n, adjoint, self._stream())
+        out = self._empty(tuple(x5.shape[:-1]) + (C,))      # a 1-channel input broadcasts over the PSF's channels
+        self._handle.convolve(x5.data_ptr(), out.data_ptr(), n, int(x5.shape[-1]), adjoint, self._stream())
+        if split3:
+            out = out.reshape((-1, Cx) + tuple(out.shape[1:4])).permute(0, 2, 3, 4, 1).contiguous()
         out = out.reshape(tuple(lead) + tuple(out.shape[1:]))
         if was_torch:
             return out.to(x.device)

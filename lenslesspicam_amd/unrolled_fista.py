@@ -24,8 +24,10 @@ class UnrolledFISTA(FISTA):
         for i in range(n_iter):
             tks.append((1 + np.sqrt(1 + 4 * tks[i] ** 2)) / 2)
         self._tk_p = torch.Tensor(tks)
+        self._sched_dirty = True
 
     def set_parameters(self, alpha=None, tk=None):
+        self._sched_dirty = True
         if alpha is not None:
             a = torch.as_tensor(np.asarray(alpha, dtype=np.float32))
             assert tuple(a.shape) == tuple(self._alpha_p.shape)
@@ -40,10 +42,15 @@ class UnrolledFISTA(FISTA):
                             tk=state["_tk_p"].detach().cpu().numpy() if "_tk_p" in state else None)
 
     def _push_schedule(self):
+        """Hands the schedule to the handle -- only when the parameters changed or the handle is new (an upload
+        is a blocking host -> device copy; ``forward()`` calls ``reset()`` for every batch)."""
+        if getattr(self, "_pushed_to", None) is self._handle and not self._sched_dirty:
+            return
         alpha = torch.abs(self._alpha_p).to(torch.float32)     # unrolled_fista.py:98-100 (positivity)
         tk = torch.abs(self._tk_p).to(torch.float32)
         coef = (tk[:-1] - 1) / tk[1:]                           # float32 arithmetic, like :104
         self._handle.set_fista_schedule(alpha.tolist(), coef.tolist(), self._stream())
+        self._pushed_to, self._sched_dirty = self._handle, False
 
     def reset(self, tk=None, batch_size=None):
         if getattr(self, "_alpha_p", None) is not None:

@@ -293,16 +293,26 @@ class ADMMOracle:
         img[img < 0] = 0
         return img
 
-    def apply(self, n_iter, reset=True, background=None):
-        """recon.py:547-576,594: exactly n_iter updates, returns (D,H,W,C)."""
+    def apply(self, n_iter, reset=True, background=None, show=False, disp_iter=-1, ax=None):
+        """recon.py:547-594: exactly n_iter updates, returns (D,H,W,C).  ``show`` stands for ``plot or save``: the
+        image is then formed before the loop (when no ``ax`` is handed in) and after every iteration i with
+        ``(i + 1) % disp_iter == 0`` (recon.py:563-584; Python's modulo: disp_iter=-1 is every iteration) -- each of
+        those read-outs clamps V in place, and right after ``reset()`` V still aliases the initial estimate."""
         assert self.data is not None and self.data.shape[0] == 1
         if background is not None:  # recon.py:553-555
             self.data = self.data - _as_tensor(background, self.dtype)
             self.data[self.data < 0] = 0
         if reset:
             self.reset()
-        for _ in range(n_iter):
+        if show and disp_iter is not None:          # recon.py:563-566
+            if ax is None:
+                self.form_image()
+        else:                                       # recon.py:568-570
+            disp_iter = n_iter + 1
+        for i in range(n_iter):
             self.step()
+            if show and (i + 1) % disp_iter == 0:   # recon.py:580-582
+                self.form_image()
         return self.form_image()[0]
 
 

@@ -310,6 +310,85 @@ def admm_pnp_case(name):
     print("wrote", name, {k: float(np.abs(v).max()) for k, v in out.items() if k.endswith("final") or k.endswith("more")})
 
 
+def display_case(name):
+    """apply() with `save=` set (recon.py:563-592): an image is formed before the loop and after every iteration i
+    with `(i + 1) % disp_iter == 0` -- Python's modulo, so the default disp_iter=-1 displays EVERY iteration -- and
+    each ADMM read-out clamps the state in place (admm.py:331-338).  Right after reset() the state still ALIASES the
+    initial estimate (admm.py:154-155), so the pre-loop read-out clamps the stored initial estimate as well and every
+    later reset() starts from the clamped one.  Needs matplotlib (Agg) for the reference's plot_image."""
+    import tempfile
+
+    os.environ.setdefault("MPLBACKEND", "Agg")
+    out = {}
+    psf, data = make_inputs(24, 32, 3, 71)
+    kw = dict(tau=2e-6, mu2=1e-4)
+    rec = ADMM(t(psf), **kw)
+    init = ((np.random.default_rng(72).random([1] + [int(v) for v in rec._padded_shape]).astype(np.float32) - 0.5)
+            * 0.4)                                                # warm start WITH negative entries
+    out.update(psf=psf, data=data, initial_est=init.copy(), params=np.array([2e-6, 1e-4]))
+    rec._set_initial_estimate(t(init.copy()))
+    rec.set_data(t(data))
+    tmp = tempfile.mkdtemp()
+    out["run1_n9_dispm1"] = rec.apply(n_iter=9, save=tmp, disp_iter=-1).numpy().copy()
+    out["run1_state"] = rec._image_est.numpy().copy()
+    out["run1_files"] = np.array(sorted(int(f[:-4]) for f in os.listdir(tmp)))
+    out["initial_est_after"] = rec._initial_est.numpy().copy()     # clamped in place by the pre-loop read-out
+    out["run2_n7_disp3"] = rec.apply(n_iter=7, save=tempfile.mkdtemp(), disp_iter=3).numpy().copy()
+    out["run3_n8_dispm3"] = rec.apply(n_iter=8, save=tempfile.mkdtemp(), disp_iter=-3).numpy().copy()
+    out["run4_n5_none"] = rec.apply(n_iter=5, disp_iter=None).numpy().copy()
+    # the same calls from a cold start (zeros): here the displays leave the trajectory alone
+    rec0 = ADMM(t(psf), **kw)
+    rec0.set_data(t(data))
+    out["cold_n9_dispm1"] = rec0.apply(n_iter=9, save=tempfile.mkdtemp(), disp_iter=-1).numpy().copy()
+    # gradient-descent family: the read-out is not in place (gd.py:136-140)
+    fis = FISTA(t(psf))
+    fis.set_data(t(data))
+    out["fista_n6_dispm1"] = fis.apply(n_iter=6, save=tempfile.mkdtemp(), disp_iter=-1).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, {k: float(np.abs(v).max()) for k, v in out.items() if k.startswith("run") or "disp" in k})
+
+
+def caller_flow_case(name):
+    """The flow of scripts/recon/admm.py:22-130 on .npy inputs (no cv2 call is reached with downsample=1, no Bayer):
+    load_data(...) -> ADMM(psf, **config.admm) with the FULL key set of configs/recon/defaults.yaml:63-82 -> set_data
+    -> apply(disp_iter=None, save=False, gamma=None, plot=False); plus the file-path convenience wrappers
+    apply_admm / apply_gradient_descent (admm.py:400-419, gd.py:244-263)."""
+    import tempfile
+
+    from lensless.recon.admm import apply_admm
+    from lensless.recon.gd import apply_gradient_descent
+    from lensless.utils.io import load_data
+
+    rng = np.random.default_rng(81)
+    tmp = tempfile.mkdtemp()
+    h, w = 36, 48
+    raw_psf = (rng.random((1, h, w, 3)) ** 8 * 3500 + rng.random((1, h, w, 3)) * 60 + 90).astype(np.uint16)
+    raw_dat = (rng.random((h, w, 3)) * 3000 + 150).astype(np.uint16)
+    pf, df = os.path.join(tmp, "psf.npy"), os.path.join(tmp, "dat.npy")
+    np.save(pf, raw_psf)
+    np.save(df, raw_dat)
+    out = dict(raw_psf=raw_psf, raw_data=raw_dat)
+    admm_cfg = dict(n_iter=5, mu1=1e-6, mu2=1e-5, mu3=4e-5, tau=0.0001, denoiser=None, unrolled=False,
+                    checkpoint_fp=None, pre_process_model=dict(network=None, depth=2),
+                    post_process_model=dict(network=None, depth=2))
+    for tag, use_torch in (("np", False), ("torch", True)):
+        psf, data = load_data(psf_fp=pf, data_fp=df, background_fp=None, dtype="float32", downsample=1, bayer=False,
+                              blue_gain=None, red_gain=None, plot=False, flip=False, gamma=None, gray=False,
+                              single_psf=False, shape=None, use_torch=use_torch, torch_device="cpu", bg_pix=[5, 25],
+                              normalize=True, bgr_input=False)
+        rec = ADMM(psf, **admm_cfg)
+        rec.set_data(data)
+        res = rec.apply(disp_iter=None, save=False, gamma=None, plot=False)
+        out[f"script_{tag}_psf"] = np.asarray(psf)
+        out[f"script_{tag}_data"] = np.asarray(data)
+        out[f"script_{tag}_res"] = np.asarray(res)
+    out["apply_admm_n4_flip_gray"] = np.asarray(apply_admm(pf, df, 4, downsample=1, flip=True, gray=True,
+                                                           normalize=True, bgr_input=False))
+    out["apply_gd_n6"] = np.asarray(apply_gradient_descent(pf, df, 6, downsample=1, normalize=True, bgr_input=False))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, {k: (v.shape, str(v.dtype)) for k, v in out.items()})
+
+
 def operator_case():
     rng = np.random.default_rng(5)
     out = {}
@@ -366,6 +445,13 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "preprocess":
         preprocess_case("preprocess")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "display":
+        display_case("apply_display")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "caller_flow":
+        caller_flow_case("caller_flow")
+        gd_case("fista_profile_gray", FISTA, 38, 50, 1, seed=18, iters=[300])
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "recon_error":
         recon_error_case("recon_error")
         sys.exit(0)
@@ -400,3 +486,7 @@ if __name__ == "__main__":
     preprocess_case("preprocess")
     hook_case("pnp_hook")
     admm_pnp_case("pnp_admm")
+    display_case("apply_display")
+    caller_flow_case("caller_flow")
+    # profile/gradient_descent.py settings (n_iter=300, gray, float32) at reduced size
+    gd_case("fista_profile_gray", FISTA, 38, 50, 1, seed=18, iters=[300])

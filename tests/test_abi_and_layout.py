@@ -112,3 +112,32 @@ def test_reference_api_surface_and_errors(backend):
     out = res.apply(disp_iter=None, plot=False)                 # n_iter from the constructor
     assert out.shape == (1, 10, 12, 3) and out.dtype == np.float32
     assert lpa.GradientDescentUpdate.all_values() == ["fista", "nesterov", "vanilla"]
+
+
+@pytest.mark.gpu
+def test_integration_md_stub_runs_verbatim():
+    """INTEGRATION.md section B is documentation a maintainer would paste: execute its first code block as written
+    (only the library path is made absolute) against liblpc.so and compare with the package's own ADMM."""
+    import re
+
+    import lenslesspicam_amd as lpa
+    from lenslesspicam_amd import _native
+    from oracle import lensless_oracle as orc
+
+    md = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = md[md.index("## B."):]
+    code = re.search(r"```python\n(.*?)```", sec, re.S).group(1)
+    assert 'C.CDLL("liblpc.so")' in code
+    _native.default_lib("float32")                       # builds the library on a fresh checkout
+    code = code.replace('C.CDLL("liblpc.so")', f"C.CDLL({_native.DEFAULT_LIB!r})")
+    ns = {}
+    exec(compile(code, "INTEGRATION.md#B", "exec"), ns)
+    psf = torch.from_numpy(orc.synthetic_psf(1, 40, 56, 3, seed=1)).cuda()
+    y = torch.rand((1, 40, 56, 3), device="cuda")
+    native = ns["NativeADMM"](psf, 1e-6, 1e-5, 4e-5, 1e-4)
+    got = native.run(y, 7)
+    torch.cuda.synchronize()
+    rec = lpa.ADMM(psf)
+    rec.set_data(y[0])
+    assert torch.equal(got, rec.apply(n_iter=7, disp_iter=None))
+    del native

@@ -1,0 +1,201 @@
+"""Caller-side behaviour of the mirrored API against vectors produced by the imported reference
+(tests/golden/gen_golden.py `display` / `caller_flow`):
+
+  * apply(save=..., disp_iter=...) -- the reference's modulo rule (recon.py:563-592; disp_iter=-1 = every iteration),
+    the in-place clamp of every ADMM read-out (admm.py:331-338) and the aliasing of the initial estimate;
+  * the flow of scripts/recon/admm.py (load_data -> ADMM(psf, **config.admm) -> apply) through tools/recon_admm.py;
+  * the file-path convenience wrappers apply_admm / apply_gradient_descent (admm.py:400-419, gd.py:244-263);
+  * channel broadcasting rules at the boundary (1 -> C broadcasts, anything else is refused before it reaches HBM).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import lenslesspicam_amd as lpa
+from oracle import lensless_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def rel(a, b):
+    a = a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    b = b.detach().cpu().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+    return float(np.max(np.abs(a.astype(np.float64) - b.astype(np.float64))) / max(np.max(np.abs(b)), 1e-300))
+
+
+# ------------------------------------------------------------------------------- display loop --
+def test_oracle_display_loop_matches_reference():
+    g = np.load(os.path.join(GOLDEN, "apply_display.npz"))
+    tau, mu2 = [float(v) for v in g["params"]]
+    o = orc.ADMMOracle(g["psf"], tau=tau, mu2=mu2, initial_est=g["initial_est"].copy())
+    o.set_data(g["data"])
+    assert rel(o.apply(9, show=True, disp_iter=-1), g["run1_n9_dispm1"]) <= 5e-6
+    assert rel(o.V, g["run1_state"]) <= 5e-6
+    assert rel(o.initial_est, g["initial_est_after"]) == 0.0            # clamped in place through the alias
+    assert rel(o.apply(7, show=True, disp_iter=3), g["run2_n7_disp3"]) <= 5e-6
+    assert rel(o.apply(8, show=True, disp_iter=-3), g["run3_n8_dispm3"]) <= 5e-6
+    assert rel(o.apply(5), g["run4_n5_none"]) <= 5e-6
+    # the aliasing matters: from the un-clamped initial estimate the later calls give something else
+    o2 = orc.ADMMOracle(g["psf"], tau=tau, mu2=mu2, initial_est=g["initial_est"].copy())
+    o2.set_data(g["data"])
+    assert rel(o2.apply(5), g["run4_n5_none"]) > 1e-3
+
+
+def test_apply_display_loop_golden(backend, tmp_path):
+    g = np.load(os.path.join(GOLDEN, "apply_display.npz"))
+    tau, mu2 = [float(v) for v in g["params"]]
+    rec = lpa.ADMM(g["psf"], tau=tau, mu2=mu2)
+    rec._set_initial_estimate(g["initial_est"].copy())
+    rec.set_data(g["data"])
+    d1 = tmp_path / "run1"
+    out = rec.apply(n_iter=9, save=str(d1), disp_iter=-1)               # recon.py:580: (i+1) % -1 == 0 always
+    assert isinstance(out, np.ndarray)                                  # `save` alone returns the image (recon.py:604)
+    assert rel(out, g["run1_n9_dispm1"]) <= 1e-5
+    assert rel(rec._image_est, g["run1_state"]) <= 1e-5
+    assert sorted(int(f[:-4]) for f in os.listdir(d1)) == [int(v) for v in g["run1_files"]]
+    assert rel(rec.apply(n_iter=7, save=str(tmp_path / "run2"), disp_iter=3), g["run2_n7_disp3"]) <= 1e-5
+    assert sorted(os.listdir(tmp_path / "run2")) == ["3.png", "6.png"]
+    assert rel(rec.apply(n_iter=8, save=str(tmp_path / "run3"), disp_iter=-3), g["run3_n8_dispm3"]) <= 1e-5
+    assert rel(rec.apply(n_iter=5, disp_iter=None), g["run4_n5_none"]) <= 1e-5
+    cold = lpa.ADMM(g["psf"], tau=tau, mu2=mu2)
+    cold.set_data(g["data"])
+    assert rel(cold.apply(n_iter=9, save=str(tmp_path / "cold"), disp_iter=-1), g["cold_n9_dispm1"]) <= 1e-5
+    fis = lpa.FISTA(g["psf"])
+    fis.set_data(g["data"])
+    assert rel(fis.apply(n_iter=6, save=str(tmp_path / "fista"), disp_iter=-1), g["fista_n6_dispm1"]) <= 5e-6
+    assert len(os.listdir(tmp_path / "fista")) == 6
+    img, ax = fis.apply(n_iter=2, plot=True, disp_iter=None, plot_pause=0.001)      # plot=True returns (image, ax)
+    assert img.shape == (1, 24, 32, 3) and ax is not None
+    with pytest.raises(ZeroDivisionError):                              # `(i + 1) % 0`, exactly like the reference
+        fis.apply(n_iter=2, save=str(tmp_path / "z"), disp_iter=0)
+
+
+# -------------------------------------------------------------------------------- caller flow --
+ADMM_CFG = dict(n_iter=5, mu1=1e-6, mu2=1e-5, mu3=4e-5, tau=0.0001, denoiser=None, unrolled=False, checkpoint_fp=None,
+                pre_process_model=dict(network=None, depth=2), post_process_model=dict(network=None, depth=2))
+
+
+@pytest.fixture
+def flow_files(tmp_path):
+    g = np.load(os.path.join(GOLDEN, "caller_flow.npz"))
+    pf, df = str(tmp_path / "psf.npy"), str(tmp_path / "dat.npy")
+    np.save(pf, g["raw_psf"])
+    np.save(df, g["raw_data"])
+    return g, pf, df
+
+
+def test_script_flow_golden(backend, flow_files, tmp_path):
+    """load_data(...) -> ADMM(psf, **config.admm) -> apply(disp_iter=None, save=False, gamma=None, plot=False)"""
+    from lenslesspicam_amd.prep import load_data
+
+    g, pf, df = flow_files
+    psf, data = load_data(psf_fp=pf, data_fp=df, background_fp=None, dtype="float32", downsample=1, bayer=False,
+                          blue_gain=None, red_gain=None, plot=False, flip=False, gamma=None, gray=False,
+                          single_psf=False, shape=None, use_torch=False, bg_pix=[5, 25], normalize=True,
+                          bgr_input=False)
+    assert isinstance(psf, np.ndarray) and psf.dtype == np.float32
+    assert rel(psf, g["script_np_psf"]) <= 1e-6 and rel(data, g["script_np_data"]) <= 1e-6
+    rec = lpa.ADMM(psf, **ADMM_CFG)                                     # the full key set of defaults.yaml:63-82
+    rec.set_data(data)
+    res = rec.apply(disp_iter=None, save=False, gamma=None, plot=False)
+    assert res.shape == g["script_np_res"].shape and rel(res, g["script_np_res"]) <= 5e-6
+    assert rel(res, g["script_torch_res"]) <= 5e-6
+    # the same through the tool (tools/recon_admm.py), result written like scripts/recon/admm.py:148
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import recon_admm as tool
+
+    cfg = tool.merge({}, tool.DEFAULTS)
+    for item in (f"input.psf={pf}", f"input.data={df}", "preprocess.downsample=1", "display.disp=-1",
+                 "torch=False" if backend.kind == "emu" else "torch=True"):
+        tool.override(cfg, item)
+    img, tm = tool.run(cfg, out_dir=str(tmp_path / "out"))
+    saved = np.load(tmp_path / "out" / "final_reconstruction.npy")
+    assert saved.shape == (36, 48, 3) and np.array_equal(saved, img)    # res[0] with plot=False: first depth plane
+    assert rel(saved, g["script_np_res"][0]) <= 5e-6
+    with pytest.raises(NotImplementedError, match="resiz"):
+        load_data(pf, df, downsample=4)                                 # no oracle for cv2 / torchvision resizing
+    with pytest.raises(AssertionError):
+        load_data(pf, df)                                               # io.py:465-466: downsample or shape required
+
+
+def test_apply_admm_and_gd_file_path_form(backend, flow_files):
+    g, pf, df = flow_files
+    res = lpa.apply_admm(pf, df, 4, downsample=1, flip=True, gray=True, normalize=True, bgr_input=False)
+    assert res.shape == g["apply_admm_n4_flip_gray"].shape
+    assert rel(res, g["apply_admm_n4_flip_gray"]) <= 5e-6
+    res = lpa.apply_gradient_descent(pf, df, 6, downsample=1, normalize=True, bgr_input=False)
+    assert rel(res, g["apply_gd_n6"]) <= 5e-6
+    # additive array form: prepared arrays instead of paths, keywords go to the constructor
+    arr = lpa.apply_admm(g["script_np_psf"], g["script_np_data"], 5)
+    assert rel(arr, g["script_np_res"]) <= 5e-6
+
+
+# ------------------------------------------------------------------------- channel broadcasting --
+def test_channel_broadcast_rules(backend):
+    rng = np.random.default_rng(4)
+    psf3 = orc.synthetic_psf(1, 12, 16, 3, seed=1)
+    psf1 = np.ascontiguousarray(psf3[..., :1])
+    y1 = rng.random((12, 16, 1), dtype=np.float32)
+    y3 = np.repeat(y1, 3, axis=-1)
+    # RGB PSF + one-channel data: broadcast (the reference's `vpad[...] = v`), equal to explicitly repeated data
+    a = lpa.ADMM(psf3, tau=2e-6, mu2=1e-4)
+    a.set_data(y1)
+    b = lpa.ADMM(psf3, tau=2e-6, mu2=1e-4)
+    b.set_data(y3)
+    assert np.array_equal(a.apply(n_iter=3, disp_iter=None), b.apply(n_iter=3, disp_iter=None))
+    o = orc.ADMMOracle(psf3, tau=2e-6, mu2=1e-4)
+    o.set_data(y1)                                                       # the oracle broadcasts like the reference
+    assert rel(a.apply(n_iter=3, disp_iter=None), o.apply(3)) <= 5e-6
+    f = lpa.FISTA(psf3)
+    f.set_data(y1)
+    of = orc.GDOracle(psf3, kind="fista")
+    of.set_data(y1)
+    assert rel(f.apply(n_iter=4, disp_iter=None), of.apply(4)) <= 5e-6
+    assert rel(f.reconstruction_error(lensless=y1), f.reconstruction_error(lensless=y3)) <= 1e-6
+    # grayscale PSF + RGB data cannot broadcast 3 -> 1
+    gr = lpa.ADMM(psf1)
+    with pytest.raises(ValueError, match="broadcast"):
+        gr.set_data(y3)
+    with pytest.raises(AssertionError):
+        gr._set_initial_estimate(np.zeros((1, 23, 32, 3), np.float32))
+    # operator: 1 -> 3 broadcasts, 3 -> 1 is refused when padding, allowed (per-channel) on the padded frame
+    x1 = rng.standard_normal((2, 1, 12, 16, 1)).astype(np.float32)
+    cv3 = lpa.RealFFTConvolve2D(psf3, pad=True)
+    got = cv3.convolve(x1)
+    assert got.shape == (2, 1, 12, 16, 3)
+    assert np.array_equal(got, cv3.convolve(np.repeat(x1, 3, axis=-1)))
+    cv1 = lpa.RealFFTConvolve2D(psf1, pad=True)
+    with pytest.raises(ValueError, match="broadcast"):
+        cv1.convolve(np.repeat(x1, 3, axis=-1))
+    cvn = lpa.RealFFTConvolve2D(psf1, pad=False)
+    xp = rng.standard_normal([2] + cvn._padded_shape[:3] + [3]).astype(np.float32)
+    full = cvn.convolve(xp)
+    assert full.shape == xp.shape
+    for c in range(3):
+        assert np.array_equal(full[..., c:c + 1], cvn.convolve(np.ascontiguousarray(xp[..., c:c + 1])))
+    with pytest.raises(ValueError, match="spatial size"):
+        cv3.convolve(np.zeros((1, 1, 13, 16, 3), np.float32))
+    # the C ABI itself refuses a channel count it cannot read safely
+    from lenslesspicam_amd._native import NativeError
+
+    with pytest.raises(NativeError, match="channel"):
+        a._handle.set_data(0x1000, 2, 0)
+
+
+def test_momentum_override_survives_batch_change(backend):
+    psf = orc.synthetic_psf(1, 12, 16, 3, seed=3)
+    ys = np.random.default_rng(3).random((2, 1, 12, 16, 3), dtype=np.float32)
+    nes = lpa.NesterovGradientDescent(psf)
+    nes.set_data(ys[0, 0])
+    nes.reset(p=0, mu=0.5)
+    nes.set_data(ys)                                                     # new batch size -> new native handle
+    got = nes.apply_batch(n_iter=5, reset=False)
+    for b in range(2):
+        o = orc.GDOracle(psf, kind="nesterov")
+        o.set_data(ys[b, 0])
+        o.reset(p=0.0, mu=0.5)
+        assert rel(got[b], o.apply(5, reset=False)) <= 5e-6

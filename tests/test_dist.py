@@ -38,6 +38,21 @@ def _worker(rank, world, port, emu_path, out_dir):
         assert np.array_equal(full[b], ref), (rank, b)          # ... bit-identical to un-sharded runs
     fis = reconstruct_sharded(lpa.FISTA, torch.from_numpy(psf), torch.from_numpy(frames), n_iter=4)
     assert isinstance(fis, torch.Tensor) and fis.shape == (3, 1, 12, 16, 3)
+    # one solver kept alive over batches of different sizes: even (4 = 2 + 2), uneven (5 = 3 + 2) and a batch
+    # smaller than the world (1 frame: rank 1 has an EMPTY shard and only takes part in the gather)
+    from lenslesspicam_amd.dist import ShardedReconstructor
+
+    sr = ShardedReconstructor(lpa.ADMM, psf, tau=2e-6, mu2=1e-4)
+    more = rng.random((5, 12, 16, 3), dtype=np.float32)
+    for nb in (4, 5, 1, 5):
+        got = sr(more[:nb], n_iter=3)
+        assert got.shape == (nb, 1, 12, 16, 3)
+        for b in range(nb):
+            single = lpa.ADMM(psf, tau=2e-6, mu2=1e-4)
+            single.set_data(more[b])
+            assert np.array_equal(got[b], single.apply(n_iter=3, disp_iter=None)), (rank, nb, b)
+    reused = reconstruct_sharded(lpa.ADMM, psf, frames, n_iter=6, solver=sr.rec)      # solver= skips construction
+    assert np.array_equal(reused, full)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), full)
     dist.barrier()
     dist.destroy_process_group()
