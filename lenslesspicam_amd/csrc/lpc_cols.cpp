@@ -1,0 +1,113 @@
+// lpc_cols.cpp -- launches of every column pass (see lpc_engine.h for the split of the library)
+#include "lpc_engine.h"
+
+// column pass A (only when split) over nplanes planes; inverse => conj twiddles before FFT
+int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1, int kid,
+                      bool crop_rows_only) {
+  if (e->N1 == 1) return 0;
+  const PlaneGeom& g = e->g;
+  ColPass cp = e->passA;
+  cp.tw_mode = inverse ? 2 : 1;
+  cp.zr0 = zr0; cp.zr1 = zr1;
+  if (inverse && crop_rows_only) {   // the row pass that follows reads spectrum rows (sh + u + Hp/2) mod Hp, u < H
+    cp.need0 = (g.sh + g.Hp / 2) % g.Hp;
+    cp.needn = g.H;
+  }
+  const dim3 grid(cp.G * cp.ntile_c, nplanes);
+  return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
+    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+    const size_t smem = (size_t)cp.N * cp.T * sizeof(real2);
+    if (inverse) return launch_k(e, kid, k_cols<nt, em, true>, grid, nt, smem, g, e->planA, cp, S);
+    return launch_k(e, kid, k_cols<nt, em, false>, grid, nt, smem, g, e->planA, cp, S);
+  });
+}
+
+// plain forward pass B (setup transforms only)
+int cols_passB_fwd(Engine* e, real2* S, int nplanes, int zr0, int zr1) {
+  const PlaneGeom& g = e->g;
+  ColPass cp = e->passB;
+  cp.tw_mode = 0;
+  cp.zr0 = zr0; cp.zr1 = zr1;
+  const dim3 grid(cp.G * cp.ntile_c, nplanes);
+  return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
+    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+    return launch_k(e, -1, k_cols<nt, em, false>, grid, nt, (size_t)cp.N * cp.T * sizeof(real2), g, e->planB,
+                    cp, S);
+  });
+}
+
+// middle of a convolution on S (nplanes): [A] -> B fwd * H * B inv -> [A inv]
+int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, int zr1,
+                       bool crop_rows_only) {
+  const PlaneGeom& g = e->g;
+  const bool split = e->N1 > 1;
+  if (split) LPC_OK(cols_passA(e, S, nplanes, false, zr0, zr1, LPC_K_COL_A_FWD));
+  ColPass cp = e->passB;
+  cp.zr0 = split ? 0 : zr0;
+  cp.zr1 = split ? g.Hp : zr1;
+  const dim3 grid(cp.G * cp.ntile_c, nplanes);
+  const real hscale = (real)1.0 / ((real)g.Hp * (real)g.Wp);
+  // one lane = one whole pass-B column transform in registers, for the lengths choose_split produces most
+  auto reg_mid = [&](auto kernel) {
+    const dim3 rgrid((g.Wc + 63) / 64, cp.G, nplanes);
+    return launch_k(e, LPC_K_COL_MID, kernel, rgrid, 64, 0, g, e->planB, cp, S, (const real2*)e->Hs,
+                    adjoint ? 1 : 0, hscale, e->Ppsf);
+  };
+  const int regN = (split && e->mid_reg) ? cp.N : 0;
+  if (regN == 48) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 6>)); }
+  else if (regN == 40) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 5>)); }
+  else if (regN == 36) { LPC_OK(reg_mid(k_cols_mid_mul_reg<6, 6>)); }
+  else if (regN == 32) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 4>)); }
+  else if (regN == 30) { LPC_OK(reg_mid(k_cols_mid_mul_reg<6, 5>)); }
+  else if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 3>)); }
+  else
+  LPC_OK(dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
+    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+    return launch_k(e, LPC_K_COL_MID, k_cols_mid_mul<nt, em>, grid, nt, (size_t)cp.N * cp.T * sizeof(real2), g,
+                    e->planB, cp, S, (const real2*)e->Hs, adjoint ? 1 : 0, hscale, e->Ppsf);
+  }));
+  if (split) LPC_OK(cols_passA(e, S, nplanes, true, 0, g.Hp, LPC_K_COL_A_INV, crop_rows_only));
+  return 0;
+}
+
+// ---- ADMM: [pass A] -> fused middle (V-hat, H V-hat) -> [inverse pass A] on the two work spectra ----------------
+int admm_cols(Engine* e, const AdmmScalars& sc) {
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  const bool split = e->N1 > 1;
+  if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, false, 0, g.Hp, LPC_K_COL_A_FWD));
+  {
+    ColPass cp = e->passB;
+    const dim3 grid(cp.G * cp.ntile_c, e->P);
+    const FastDiv t2 = make_fastdiv((unsigned)(2 * cp.T));
+    auto reg_mid = [&](auto kernel) {
+      const dim3 rgrid((g.Wc + 63) / 64, cp.G, e->P);
+      return launch_k(e, LPC_K_COL_MID, kernel, rgrid, 64, 0, g, e->planB, cp, SA, SB, (const real2*)e->Hs,
+                      (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, sc.mu1, sc.mu2, sc.mu3,
+                      (real)1.0 / ((real)g.Hp * (real)g.Wp));
+    };
+    const int regN = (split && e->mid_reg && sizeof(real) == 4) ? cp.N : 0;
+    // two arrays per lane: only short pass-B transforms fit the register file.  Measured at 12 MP
+    // (profiles/r01b_notes.md): 24 points 0.89 ms and 32 points 0.83 ms beat the LDS middle (0.99 / 0.92 ms) but
+    // need a 256- / 192-point pass A that costs more than it saves; 48 points is 1.62 ms (AGPR traffic).
+    if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_admm_reg<8, 3>)); }
+    else if (cp.N * cp.T * 2 > 8192 && cp.N * cp.T * 2 <= 9216) {
+      // just above 8192 points (C1 / C4: 540 rows x 8 columns x 2 arrays = 8640): 512 threads x 18 points keeps
+      // TWO workgroups per CU inside the 128-VGPR budget; 1024 x 16 is one 16-wave workgroup per CU in lock-step
+      // at every barrier (C4: middle 1.435 -> 1.331 ms, 17.5k -> 18.0k frame-it/s)
+      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<512, 18>, grid, 512, (size_t)cp.N * cp.T * 2 * sizeof(real2),
+                      g, e->planB, cp, SA, SB, (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr,
+                      (const real2*)e->phc, t2, sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
+    } else
+    LPC_OK(dispatch_cfg(cp.N * cp.T * 2, [&](auto NTc, auto EM) {
+      constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
+      return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<nt, em>, grid, nt,
+                      (size_t)cp.N * cp.T * 2 * sizeof(real2), g, e->planB, cp, SA, SB, (const real2*)e->Hs,
+                      (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2, sc.mu1, sc.mu2,
+                      sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp));
+    }));
+  }
+  if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, true, 0, g.Hp, LPC_K_COL_A_INV));
+  return 0;
+}

@@ -1,35 +1,18 @@
 // lpc_engine.cpp -- host side of the engine: plans, HBM workspace, launch sequences and the
 // C ABI declared in include/lpc.h.  Compiled as HIP for gfx950 (product) or, for the CPU
-// test-suite only, as plain C++ with -DLPC_SIMT_EMU (see lpc_rt.h).
-#include "lpc_kernels.h"
+// test-suite only, as plain C++ with -DLPC_SIMT_EMU (see lpc_rt.h).  The row / column / gradient-descent
+// launches live in lpc_rows.cpp, lpc_cols.cpp and lpc_gd.cpp (see lpc_engine.h).
+#include "lpc_engine.h"
 #include "lpc_gd_kernels.h"
 #include "lpc_metric_kernels.h"
 #include "lpc_prep_kernels.h"
-#include "lpc.h"
-
-#include <algorithm>
-#include <string>
-#include <type_traits>
-#include <unordered_set>
-#include <vector>
 
 // --------------------------------------------------------------------------- errors --
 static thread_local std::string g_last_error;
-static int fail(const std::string& msg) {
+int fail(const std::string& msg) {
   g_last_error = msg;
   return 1;
 }
-#define LPC_RT(expr)                                                                      \
-  do {                                                                                    \
-    lpcError_t e_ = (expr);                                                               \
-    if (e_ != lpcSuccess)                                                                 \
-      return fail(std::string(#expr) + " failed: " + rt::err_string(e_));                 \
-  } while (0)
-#define LPC_OK(expr)          \
-  do {                        \
-    int r_ = (expr);          \
-    if (r_) return r_;        \
-  } while (0)
 
 // -------------------------------------------------------------------------- helpers --
 static int next_5smooth(int n) {  // scipy.fftpack.next_fast_len (rfft_convolve.py:112)
@@ -43,162 +26,6 @@ static int next_5smooth(int n) {  // scipy.fftpack.next_fast_len (rfft_convolve.
   }
 }
 
-// Workgroup shape for an FFT tile of `nelem` complex points: NT threads x EMAX points per thread:
-// the fewest threads that hold the tile with <= 16 points per thread.  Measured on MI355X
-// (profiles/r01b_notes.md): the alternatives "twice the threads, half the points" (same LDS, twice
-// the waves) and "half the threads, 32 points" are both slower.
-// LDS holds 160 KiB per workgroup: 16384 complex64 points (128 KiB) or 8192 complex128 points
-static constexpr int kMaxTilePoints = (int)(131072 / sizeof(real2));
-template <class F>
-static int dispatch_cfg(int nelem, F&& f) {
-  using std::integral_constant;
-  if (nelem <= 1024) return f(integral_constant<int, 256>{}, integral_constant<int, 4>{});
-  if (nelem <= 2048) return f(integral_constant<int, 256>{}, integral_constant<int, 8>{});
-  if (nelem <= 4096) return f(integral_constant<int, 256>{}, integral_constant<int, 16>{});
-  if (nelem <= 8192) return f(integral_constant<int, 512>{}, integral_constant<int, 16>{});
-  if (nelem <= kMaxTilePoints) return f(integral_constant<int, 1024>{}, integral_constant<int, 16>{});
-  return fail("FFT tile of " + std::to_string(nelem) + " points exceeds the LDS budget (" +
-              std::to_string(kMaxTilePoints) + ")");
-}
-
-// row kernels: (NT, EMAX) by row length, the LDS-skew flag and the radix-2-folding flag of the plan
-template <class F>
-static int dispatch_row(int Wp, int skew, bool r2, F&& f) {
-  using std::integral_constant;
-  return dispatch_cfg(Wp, [&](auto NT, auto EM) {
-    if (skew && r2) return f(NT, EM, integral_constant<bool, true>{}, integral_constant<bool, true>{});
-    if (skew) return f(NT, EM, integral_constant<bool, true>{}, integral_constant<bool, false>{});
-    if (r2) return f(NT, EM, integral_constant<bool, false>{}, integral_constant<bool, true>{});
-    return f(NT, EM, integral_constant<bool, false>{}, integral_constant<bool, false>{});
-  });
-}
-
-struct KernelTimer {
-#if !defined(LPC_SIMT_EMU)
-  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[LPC_K_COUNT];
-  size_t used[LPC_K_COUNT] = {0};
-#endif
-  bool on = false;
-};
-
-struct lpc_engine {
-  lpc_config cfg{};
-  PlaneGeom g{};
-  int N1 = 1, N2 = 1;  // column split Hp = N1*N2 (N1 == 1: single pass)
-  int T = 16;          // image columns per column-pass tile
-  Fft1dPlan planW{}, planA{}, planB{};
-  Fft1dPlan planWi{};   // inverse-row plan with the radix-2 stage FIRST (rows_r2 only)
-  Fft1dPlan planWh{};   // length Wp/2: ADMM rows, one real row per half-length transform (rows_half)
-  bool rows_half = false;
-  bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (LPC_MID_LDS=1: off)
-  bool rows_r2 = false; // row plans end in a radix-2 stage: fold it into the Hermitian (un)tangling
-  ColPass passA{}, passB{};
-  int P = 0, Ppsf = 0, Pdata = 0;
-  std::vector<void*> allocs;
-  size_t total_bytes = 0;
-
-  // spectral constants
-  real2* Hs = nullptr;     // [Ppsf] PSF spectrum, permuted row order, norm applied
-  real* Gabs = nullptr;    // ADMM: |PsiT Psi| spectrum, ONE plane (identical for every channel)
-  std::vector<double> sched[4];  // optional per-iteration mu1, mu2, mu3, tau (unrolled ADMM)
-  double last_par[4] = {0, 0, 0, 0};  // parameters of the most recent iteration
-  real2* phr = nullptr;    // [Hp] ifftshift phase, stored row order
-  real2* phc = nullptr;    // [Wc]
-  real2* twH = nullptr;
-  // work spectra: [2][P] planes (ADMM uses both halves, others the first)
-  real2* S = nullptr;
-  // ADMM state (padded real planes)
-  real *V[2] = {nullptr, nullptr}, *HVb[2] = {nullptr, nullptr}, *xi = nullptr, *rho = nullptr,
-        *Rsp = nullptr, *Aarr = nullptr;
-  real *eta0[2] = {nullptr, nullptr}, *eta1[2] = {nullptr, nullptr};  // ping-pong (halo reads)
-  int vcur = 0, ecur = 0, hcur = 0;  // HVb[hcur] = H V of the current estimate, HVb[hcur^1] = of the previous one
-  // the reference clamps the image estimate IN PLACE whenever _form_image runs (admm.py:331-338);
-  // only the W-update ever sees that clamped copy: Vw[0] = V as seen by the next iteration's W,
-  // Vw[1] = V as seen by the previous iteration's W (needed to recompute W_old).  Null = same as V.
-  real* Vw[2] = {nullptr, nullptr};
-  bool vw_cur = false, vw_old = false;
-  // GD family state (un-padded planes)
-  real *gx = nullptr, *gaux = nullptr;  // x and (p | xk_prev)
-  real* galpha = nullptr;               // [C] device
-  real* gx0 = nullptr;                  // [C] default start value per channel
-  real2* S2 = nullptr;                  // second spectrum buffer (row-inverse+forward is out of place)
-  double tk = 1.0, nest_mu = 0.9, nest_p = 0.0;
-  // unrolled FISTA (unrolled_fista.py:91-106): per-iteration step alpha[i][c] and momentum factor coef[i]
-  std::vector<real> fista_coef;
-  real* galpha_sched = nullptr;  // device [n][C]
-  size_t galpha_sched_cap = 0;   // elements allocated for it (re-used by later schedules that fit)
-  int fista_sched_n = 0;
-  // common
-  real* Y = nullptr;         // data planes, un-padded [Pdata][H][W]
-  real* init_est = nullptr;  // planar copy of the initial estimate (or null)
-  real* psf_planar = nullptr;
-  bool has_init = false, psf_set = false, data_set = false, first = true;
-  bool split_pending = false;  // lpc_iterate_begin ran, lpc_iterate_end has not yet
-  // plug-and-play ADMM (lpc_admm_pnp_begin / _end): explicit state in the arrays the fused path uses for the TV duals
-  //   eta0[0] = eta, eta1[0] = U, eta0[1] = X, eta1[1] = W   (all image-shaped)
-  bool pnp_mode = false, pnp_pending = false;
-  long iters_done = 0;
-  KernelTimer timer;
-  lpcStream_t stream = nullptr;
-};
-typedef lpc_engine Engine;
-
-template <class Tp>
-static int dev_alloc(Engine* e, Tp** out, size_t count) {
-  void* p = nullptr;
-  size_t bytes = count * sizeof(Tp);
-  LPC_RT(rt::dev_malloc(&p, bytes));
-  e->allocs.push_back(p);
-  e->total_bytes += bytes;
-  *out = (Tp*)p;
-  return 0;
-}
-
-// generic launcher (+ optional event bracketing of hot-loop kernels)
-template <class K, class... A>
-static int launch_k(Engine* e, int kid, K kernel, dim3 grid, int nt, size_t smem, A... args) {
-  // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of the function: remember (device, function)
-  static thread_local std::unordered_set<uint64_t> big_smem_done;
-  if (smem > 48 * 1024) {
-    const void* fn = (const void*)kernel;
-    int dev = 0;
-    LPC_RT(rt::current_device(&dev));
-    const uint64_t key = (uint64_t)(uintptr_t)fn ^ ((uint64_t)(dev + 1) << 56);
-    if (!big_smem_done.count(key)) {
-      LPC_RT(rt::set_max_dyn_smem(fn, smem > 65536 ? 160 * 1024 : 65536));
-      big_smem_done.insert(key);
-    }
-  }
-#if !defined(LPC_SIMT_EMU)
-  const bool timed = e->timer.on && kid >= 0;
-  size_t slot = 0;
-  if (timed) {
-    auto& v = e->timer.ev[kid];
-    slot = e->timer.used[kid]++;
-    if (slot >= v.size()) {
-      hipEvent_t a, b;
-      LPC_RT(hipEventCreate(&a));
-      LPC_RT(hipEventCreate(&b));
-      v.push_back({a, b});
-    }
-    LPC_RT(hipEventRecord(v[slot].first, e->stream));
-  }
-  hipLaunchKernelGGL(kernel, grid, dim3(nt), smem, e->stream, args...);
-  if (timed) LPC_RT(hipEventRecord(e->timer.ev[kid][slot].second, e->stream));
-#else
-  (void)kid;
-  lpc_emu::launch(grid, dim3(nt), smem, [=]() { kernel(args...); });
-#endif
-  LPC_RT(rt::last_error());
-  return 0;
-}
-
-static dim3 grid1d(long n, int nt, long planes = 1) {
-  long b = (n + nt - 1) / nt;
-  if (b > 4096) b = 4096;
-  if (b < 1) b = 1;
-  return dim3((unsigned)b, (unsigned)planes, 1);
-}
 
 // ------------------------------------------------------------------------ FFT plans --
 static int upload(Engine* e, void* dst, const void* src, size_t bytes) {
@@ -372,6 +199,9 @@ static int setup_geometry(Engine* e) {
   e->rows_half = half_ok && wide && !std::getenv("LPC_ROWS_PAIRED");
   if (half_ok && std::getenv("LPC_ROWS_HALF")) e->rows_half = true;   // test knob: small frames too
   if (e->rows_half) LPC_OK(build_plan(e, e->planWh, g.Wp / 2));
+  // float4 lanes and half-length rows: r_sp and a are computed by the row workgroups themselves (float32 build)
+  e->fuse_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && e->rows_half && g.Wp % 4 == 0 &&
+                 !std::getenv("LPC_NO_FUSE_ROWS") && !std::getenv("LPC_K1_SCALAR");
   LPC_OK(build_plan(e, e->planB, e->N2));
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
@@ -401,61 +231,6 @@ static int setup_geometry(Engine* e) {
   return 0;
 }
 
-// ------------------------------------------------------------- 2-D transform pieces --
-// forward rows of ONE real source (pairs of rows) into spectrum S (planes = nplanes)
-static int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int kid) {
-  const PlaneGeom& g = e->g;
-  if (e->rows_half)
-    return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NT, auto EM, auto SK, auto) {
-      constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-      constexpr bool sk = decltype(SK)::value;
-      return launch_k(e, kid, k_rfwd_rows_half<nt, em, sk>, dim3(src.nrows, nplanes), nt,
-                      LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, src, S);
-    });
-  const int nblk = (src.nrows + 1) / 2;
-  return dispatch_row(g.Wp, e->planW.skew_ok, e->rows_r2, [&](auto NT, auto EM, auto SK, auto R2) {
-    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
-    return launch_k(e, kid, k_rfwd_rows<nt, em, sk, r2>, dim3(nblk, nplanes), nt, LPC_ROW_SMEM_BYTES(g.Wp, sk), g,
-                    e->planW, src, S);
-  });
-}
-
-// column pass A (only when split) over nplanes planes; inverse => conj twiddles before FFT
-static int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1, int kid,
-                      bool crop_rows_only = false) {
-  if (e->N1 == 1) return 0;
-  const PlaneGeom& g = e->g;
-  ColPass cp = e->passA;
-  cp.tw_mode = inverse ? 2 : 1;
-  cp.zr0 = zr0; cp.zr1 = zr1;
-  if (inverse && crop_rows_only) {   // the row pass that follows reads spectrum rows (sh + u + Hp/2) mod Hp, u < H
-    cp.need0 = (g.sh + g.Hp / 2) % g.Hp;
-    cp.needn = g.H;
-  }
-  const dim3 grid(cp.G * cp.ntile_c, nplanes);
-  return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
-    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    const size_t smem = (size_t)cp.N * cp.T * sizeof(real2);
-    if (inverse) return launch_k(e, kid, k_cols<nt, em, true>, grid, nt, smem, g, e->planA, cp, S);
-    return launch_k(e, kid, k_cols<nt, em, false>, grid, nt, smem, g, e->planA, cp, S);
-  });
-}
-
-// plain forward pass B (setup transforms only)
-static int cols_passB_fwd(Engine* e, real2* S, int nplanes, int zr0, int zr1) {
-  const PlaneGeom& g = e->g;
-  ColPass cp = e->passB;
-  cp.tw_mode = 0;
-  cp.zr0 = zr0; cp.zr1 = zr1;
-  const dim3 grid(cp.G * cp.ntile_c, nplanes);
-  return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
-    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    return launch_k(e, -1, k_cols<nt, em, false>, grid, nt, (size_t)cp.N * cp.T * sizeof(real2), g, e->planB,
-                    cp, S);
-  });
-}
-
 // full forward 2-D transform of a real source into S (used for the PSF and the TV gram)
 static int fft2_forward_setup(Engine* e, const RealSrc& src, real2* S, int nplanes) {
   const PlaneGeom& g = e->g;
@@ -468,88 +243,6 @@ static int fft2_forward_setup(Engine* e, const RealSrc& src, real2* S, int nplan
     LPC_OK(cols_passB_fwd(e, S, nplanes, zr0, zr1));
   }
   return 0;
-}
-
-// middle of a convolution on S (nplanes): [A] -> B fwd * H * B inv -> [A inv]
-static int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, int zr1,
-                       bool crop_rows_only = false) {
-  const PlaneGeom& g = e->g;
-  const bool split = e->N1 > 1;
-  if (split) LPC_OK(cols_passA(e, S, nplanes, false, zr0, zr1, LPC_K_COL_A_FWD));
-  ColPass cp = e->passB;
-  cp.zr0 = split ? 0 : zr0;
-  cp.zr1 = split ? g.Hp : zr1;
-  const dim3 grid(cp.G * cp.ntile_c, nplanes);
-  const real hscale = (real)1.0 / ((real)g.Hp * (real)g.Wp);
-  // one lane = one whole pass-B column transform in registers, for the lengths choose_split produces most
-  auto reg_mid = [&](auto kernel) {
-    const dim3 rgrid((g.Wc + 63) / 64, cp.G, nplanes);
-    return launch_k(e, LPC_K_COL_MID, kernel, rgrid, 64, 0, g, e->planB, cp, S, (const real2*)e->Hs,
-                    adjoint ? 1 : 0, hscale, e->Ppsf);
-  };
-  const int regN = (split && e->mid_reg) ? cp.N : 0;
-  if (regN == 48) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 6>)); }
-  else if (regN == 40) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 5>)); }
-  else if (regN == 36) { LPC_OK(reg_mid(k_cols_mid_mul_reg<6, 6>)); }
-  else if (regN == 32) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 4>)); }
-  else if (regN == 30) { LPC_OK(reg_mid(k_cols_mid_mul_reg<6, 5>)); }
-  else if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_mul_reg<8, 3>)); }
-  else
-  LPC_OK(dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
-    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    return launch_k(e, LPC_K_COL_MID, k_cols_mid_mul<nt, em>, grid, nt, (size_t)cp.N * cp.T * sizeof(real2), g,
-                    e->planB, cp, S, (const real2*)e->Hs, adjoint ? 1 : 0, hscale, e->Ppsf);
-  }));
-  if (split) LPC_OK(cols_passA(e, S, nplanes, true, 0, g.Hp, LPC_K_COL_A_INV, crop_rows_only));
-  return 0;
-}
-
-static int rows_inv_single(Engine* e, const real2* S, const RealDst& dst, int nplanes, int kid) {
-  const PlaneGeom& g = e->g;
-  if (e->rows_half)
-    return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NT, auto EM, auto SK, auto) {
-      constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-      constexpr bool sk = decltype(SK)::value;
-      return launch_k(e, kid, k_rinv_rows_half<nt, em, sk>, dim3(dst.nrows, nplanes), nt,
-                      LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, S, dst);
-    });
-  const int nblk = (dst.nrows + 1) / 2;
-  const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
-  return dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NT, auto EM, auto SK, auto R2) {
-    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
-    constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
-    return launch_k(e, kid, k_rinv_rows<nt, em, sk, r2>, dim3(nblk, nplanes), nt, LPC_ROW_SMEM_BYTES(g.Wp, sk), g,
-                    pinv, S, dst);
-  });
-}
-
-static RealSrc src_unpadded(const Engine* e, const real* base) {
-  const PlaneGeom& g = e->g;
-  RealSrc s;
-  s.base = base; s.plane_stride = g.uplane; s.pitch = g.W; s.nrows = g.H; s.ncols = g.W; s.col0 = g.sw;
-  s.out_row0 = g.sh;
-  return s;
-}
-static RealSrc src_padded(const Engine* e, const real* base) {
-  const PlaneGeom& g = e->g;
-  RealSrc s;
-  s.base = base; s.plane_stride = g.rplane; s.pitch = g.rpitch; s.nrows = g.Hp; s.ncols = g.Wp; s.col0 = 0;
-  s.out_row0 = 0;
-  return s;
-}
-static RealDst dst_padded(const Engine* e, real* base) {
-  const PlaneGeom& g = e->g;
-  RealDst d;
-  d.base = base; d.plane_stride = g.rplane; d.pitch = g.rpitch; d.nrows = g.Hp; d.row0 = 0; d.col0 = 0;
-  d.ncols = g.Wp;
-  return d;
-}
-static RealDst dst_cropped(const Engine* e, real* base) {
-  const PlaneGeom& g = e->g;
-  RealDst d;
-  d.base = base; d.plane_stride = g.uplane; d.pitch = g.W; d.nrows = g.H; d.row0 = g.sh; d.col0 = g.sw;
-  d.ncols = g.W;
-  return d;
 }
 
 // planar real (padded or not) -> convolution with H / H* -> planar real, same kind
@@ -611,6 +304,8 @@ static AdmmScalars admm_scalars(const Engine* e, const double cur[4]) {
   p.thrp = (real)(prev[3] / prev[1]);
   p.m_in_p = (real)1.0 / ((real)1.0 + p.mu1p);
   p.m_out_p = (real)1.0 / ((real)0.0 + p.mu1p);
+  p.r_mu2 = (real)(1.0 / (double)p.mu2); p.r_mu3 = (real)(1.0 / (double)p.mu3);      // RN(1/d): see div_by
+  p.r_mu2p = (real)(1.0 / (double)p.mu2p); p.r_mu3p = (real)(1.0 / (double)p.mu3p);
   return p;
 }
 
@@ -670,77 +365,12 @@ static int admm_reset(Engine* e) {
 
 // (r_sp, a) in e->Rsp / e->Aarr  ->  Vout = irfft2(R_div (rfft2 r_sp + s H* rfft2 a)),  HVout = H Vout:
 // forward rows, [pass A], fused middle, [inverse pass A], inverse rows
-static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real* HVout) {
-  const PlaneGeom& g = e->g;
-  real2* SA = e->S;
-  real2* SB = e->S + (size_t)e->P * g.cplane;
-  const bool split = e->N1 > 1;
-    if (e->rows_half) {
-      LPC_OK(dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
-        constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
-        constexpr bool sk = decltype(SK)::value;
-        return launch_k(e, LPC_K_ROW_FWD, k_rfwd_half<nt, em, sk>, dim3(2 * g.Hp, e->P), nt,
-                        LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real*)e->Rsp,
-                        (const real*)e->Aarr, SA, SB);
-      }));
-    } else
-    LPC_OK(dispatch_row(g.Wp, e->planW.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
-      constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
-      constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
-      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<nt, em, sk, r2>, dim3(g.Hp, e->P), nt,
-                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
-    }));
-    if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, false, 0, g.Hp, LPC_K_COL_A_FWD));
-    {
-      ColPass cp = e->passB;
-      const dim3 grid(cp.G * cp.ntile_c, e->P);
-      const FastDiv t2 = make_fastdiv((unsigned)(2 * cp.T));
-      auto reg_mid = [&](auto kernel) {
-        const dim3 rgrid((g.Wc + 63) / 64, cp.G, e->P);
-        return launch_k(e, LPC_K_COL_MID, kernel, rgrid, 64, 0, g, e->planB, cp, SA, SB, (const real2*)e->Hs,
-                        (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, sc.mu1, sc.mu2, sc.mu3,
-                        (real)1.0 / ((real)g.Hp * (real)g.Wp));
-      };
-      const int regN = (split && e->mid_reg && sizeof(real) == 4) ? cp.N : 0;
-      // two arrays per lane: only short pass-B transforms fit the register file.  Measured at 12 MP
-      // (profiles/r01b_notes.md): 24 points 0.89 ms and 32 points 0.83 ms beat the LDS middle (0.99 / 0.92 ms) but
-      // need a 256- / 192-point pass A that costs more than it saves; 48 points is 1.62 ms (AGPR traffic).
-      if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_admm_reg<8, 3>)); }
-      else if (cp.N * cp.T * 2 > 8192 && cp.N * cp.T * 2 <= 9216) {
-        // just above 8192 points (C1 / C4: 540 rows x 8 columns x 2 arrays = 8640): 512 threads x 18 points keeps
-        // TWO workgroups per CU inside the 128-VGPR budget; 1024 x 16 is one 16-wave workgroup per CU in lock-step
-        // at every barrier (C4: middle 1.435 -> 1.331 ms, 17.5k -> 18.0k frame-it/s)
-        LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<512, 18>, grid, 512, (size_t)cp.N * cp.T * 2 * sizeof(real2),
-                        g, e->planB, cp, SA, SB, (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr,
-                        (const real2*)e->phc, t2, sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
-      } else
-      LPC_OK(dispatch_cfg(cp.N * cp.T * 2, [&](auto NTc, auto EM) {
-        constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
-        return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<nt, em>, grid, nt,
-                        (size_t)cp.N * cp.T * 2 * sizeof(real2), g, e->planB, cp, SA, SB, (const real2*)e->Hs,
-                        (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2, sc.mu1, sc.mu2,
-                        sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp));
-      }));
-    }
-    if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, true, 0, g.Hp, LPC_K_COL_A_INV));
-    const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
-    if (e->rows_half) {
-      LPC_OK(dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
-        constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
-        constexpr bool sk = decltype(SK)::value;
-        return launch_k(e, LPC_K_ROW_INV, k_rinv_half<nt, em, sk>, dim3(2 * g.Hp, e->P), nt,
-                        LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real2*)SA,
-                        (const real2*)SB, Vout, HVout);
-      }));
-    } else
-    LPC_OK(dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
-      constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
-      constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
-      return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em, sk, r2>, dim3(g.Hp, e->P), nt,
-                      LPC_ROW_SMEM_BYTES(g.Wp, sk), g, pinv, (const real2*)SA, (const real2*)SB, Vout, HVout);
-    }));
-  return 0;
+static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real* HVout, bool rows_done = false) {
+  if (!rows_done) LPC_OK(admm_rows_fwd(e));   // else k_admm_rows_fused has already written the row spectra
+  LPC_OK(admm_cols(e, sc));
+  return admm_rows_inv(e, Vout, HVout);
 }
+
 
 static int admm_iterate(Engine* e, int n_iter) {
   const PlaneGeom& g = e->g;
@@ -766,8 +396,12 @@ static int admm_iterate(Engine* e, int n_iter) {
     double par[4];
     admm_params(e, e->iters_done, par);
     AdmmScalars sc = admm_scalars(e, par);
+    bool rows_done = false;
 #ifndef LPC_DOUBLE
-    if (vec4)
+    if (e->fuse_rows) {
+      LPC_OK(admm_rows_fused(e, sc, (const real*)Vc, (const real*)Vo));
+      rows_done = true;
+    } else if (vec4)
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT>, k1_grid4, NT, k1_smem4, g, sc, (const real*)Vc,
                       (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
                       (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
@@ -785,7 +419,7 @@ static int admm_iterate(Engine* e, int n_iter) {
     e->vw_cur = false;
     e->ecur ^= 1;
     e->first = false;
-    LPC_OK(admm_spectral_step(e, sc, Vo, e->HVb[e->hcur ^ 1]));
+    LPC_OK(admm_spectral_step(e, sc, Vo, e->HVb[e->hcur ^ 1], rows_done));
     e->vcur ^= 1;  // Vo now holds the new image estimate
     e->hcur ^= 1;  // ... and the other H V buffer its forward model
     for (int k = 0; k < 4; ++k) e->last_par[k] = par[k];
@@ -1366,9 +1000,11 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
   double b = 0.0;
   if (e->cfg.algo == LPC_ALGO_ADMM) {
     switch (kid) {
-      case LPC_K_SPATIAL: b = 15.0 * R + R0; break;  // SURVEY 8(d) figure (reads 8R+R0, writes 7R); the kernel itself
-                                                     // moves 14R + R0: X is recomputed instead of stored
-      case LPC_K_ROW_FWD: b = 2.0 * R + 2.0 * S; break;
+      // SURVEY 8(d) figure for the stand-alone kernel (reads 8R+R0, writes 7R; the kernel itself moves 14R + R0: X is
+      // recomputed instead of stored).  Fused into the forward rows it reads 8R + R0 (V, V_old, HV, HV_old, xi, eta0,
+      // eta1, rho; y) and writes xi, eta0, eta1, rho (4R) + the two row spectra (2S): r_sp and a never reach HBM.
+      case LPC_K_SPATIAL: b = e->fuse_rows ? 12.0 * R + R0 + 2.0 * S : 15.0 * R + R0; break;
+      case LPC_K_ROW_FWD: b = e->fuse_rows ? 0.0 : 2.0 * R + 2.0 * S; break;
       case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
       case LPC_K_COL_MID: b = 4.0 * S + Sc + eb * g.Hp * g.Wc; break;  // + H (complex) + |G| (real, one plane)
       case LPC_K_COL_A_INV: b = split ? 4.0 * S : 0.0; break;

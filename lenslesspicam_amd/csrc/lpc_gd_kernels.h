@@ -265,7 +265,7 @@ __global__ __launch_bounds__(NT) void k_plane_minmax(PlaneGeom g, const real2* L
 
 // final per-channel combine over depth planes and blocks (gd.py:100-112 flatten (D,H,W) per channel):
 // mode 0: out[c] = lip_fact / max;  mode 1: out[c] = (max + min) / 2
-__global__ void k_channel_finish(const real* LPC_RESTRICT partial, int nblk, int D, int C, int mode, real lip,
+static __global__ void k_channel_finish(const real* LPC_RESTRICT partial, int nblk, int D, int C, int mode, real lip,
                                  real* LPC_RESTRICT out) {
   const int c = threadIdx.x;
   if (c >= C) return;

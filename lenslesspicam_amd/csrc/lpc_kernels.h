@@ -781,11 +781,41 @@ struct AdmmScalars {
   // Equal to the current ones for plain ADMM; differ for unrolled ADMM (unrolled_admm.py:171-211)
   real mu1p, mu2p, mu3p, thrp;
   real m_in_p, m_out_p;  // X_divmat of the previous iteration (its X is recomputed, never stored)
+  // correctly rounded reciprocals of the step sizes the kernels divide by (see div_by)
+  real r_mu2, r_mu3, r_mu2p, r_mu3p;
 };
 
-static __device__ __forceinline__ real soft_thresh_dev(real a, real thr) {
+// x / d for a wave-uniform divisor d whose reciprocal r = RN(1 / d) was rounded on the host: one Newton step on
+// q0 = RN(x r) with the exact residual (Markstein's sequence), q = RN(q0 + RN(x - d q0) r), is the correctly
+// rounded quotient -- what the reference's `eta / mu2` computes -- in 3 VALU operations; the compiler's IEEE
+// division expands to ~10 (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup), which made up 47 % of the
+// image-domain kernel's instruction stream (34 divisions per 4 pixels).  No scaling / fix-up: the operands are image
+// values and duals far away from the overflow and denormal ranges.
+static __device__ __forceinline__ real div_by(real x, real d, real r) {
+#if defined(LPC_SIMT_EMU)
+  (void)r;
+  return x / d;
+#else
+  const real q = x * r;
+#ifdef LPC_DOUBLE
+  const real e = fma(-d, q, x);
+  return fma(e, r, q);
+#else
+  const real e = fmaf(-d, q, x);
+  return fmaf(e, r, q);
+#endif
+#endif
+}
+
+static __device__ __forceinline__ real soft_thresh_dev(real a, real thr) {   // sign(a) max(|a| - thr, 0), admm.py:341-346
   const real m = rmax(rabs(a) - thr, (real)0.);
+#if defined(LPC_SIMT_EMU)
   return a > (real)0. ? m : (a < (real)0. ? -m : (real)0.);
+#elif defined(LPC_DOUBLE)
+  return copysign(m, a);     // a == 0 gives m == 0: the sign of that zero never reaches a result
+#else
+  return copysignf(m, a);
+#endif
 }
 
 template <int TH, int TW, int NT>
@@ -850,10 +880,10 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
       const real psi = sV[li - VW] - vc;
       if (!p.first) {
         const real psio = sO[li - VW] - oc;
-        const real uo = soft_thresh_dev(psio + e0 / p.mu2p, p.thrp);
+        const real uo = soft_thresh_dev(psio + div_by(e0, p.mu2p, p.r_mu2p), p.thrp);
         e0 = e0 + p.mu2p * (psi - uo);
       }
-      const real un = soft_thresh_dev(psi + e0 / p.mu2, p.thr);
+      const real un = soft_thresh_dev(psi + div_by(e0, p.mu2, p.r_mu2), p.thr);
       sQ0[ly * TW + lx] = p.mu2 * un - e0;
       if (own) eta0_out[o] = e0;
     }
@@ -862,10 +892,10 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
       const real psi = sV[li - 1] - vc;
       if (!p.first) {
         const real psio = sO[li - 1] - oc;
-        const real uo = soft_thresh_dev(psio + e1 / p.mu2p, p.thrp);
+        const real uo = soft_thresh_dev(psio + div_by(e1, p.mu2p, p.r_mu2p), p.thrp);
         e1 = e1 + p.mu2p * (psi - uo);
       }
-      const real un = soft_thresh_dev(psi + e1 / p.mu2, p.thr);
+      const real un = soft_thresh_dev(psi + div_by(e1, p.mu2, p.r_mu2), p.thr);
       sQ1[ly * (TW + 1) + lx] = p.mu2 * un - e1;
       if (own) eta1_out[o] = e1;
     }
@@ -890,11 +920,11 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
       // X of the previous iteration, recomputed bit-for-bit from what it was computed from (admm.py:252-254)
       const real xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * HVold[o] + yv);
       xiv = xiv + p.mu1p * (hv - xo);
-      const real wo = rmax(rhov / p.mu3p + (VWo ? VWo[o] : sO[li]), (real)0);
+      const real wo = rmax(div_by(rhov, p.mu3p, p.r_mu3p) + (VWo ? VWo[o] : sO[li]), (real)0);
       rhov = rhov + p.mu3p * (vc - wo);
     }
     const real xn = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
-    const real wn = rmax(rhov / p.mu3 + (VWc ? VWc[o] : vc), (real)0);
+    const real wn = rmax(div_by(rhov, p.mu3, p.r_mu3) + (VWc ? VWc[o] : vc), (real)0);
     const real d1 = sQ0[(ly + 1) * TW + lx] - sQ0[ly * TW + lx];
     const real d2 = sQ1[ly * (TW + 1) + lx + 1] - sQ1[ly * (TW + 1) + lx];
     xi[o] = xiv;
@@ -919,10 +949,10 @@ static __device__ __forceinline__ void tv_component(const AdmmScalars& p, float 
                                                      float eta, float& eta_new, float& q) {
   const float psi = vn - vc;                       // finite_diff: roll(+1) - x   (admm.py:349-359)
   if (!p.first) {
-    const float uo = soft_thresh_dev((on - oc) + eta / p.mu2p, p.thrp);
+    const float uo = soft_thresh_dev((on - oc) + div_by(eta, p.mu2p, p.r_mu2p), p.thrp);
     eta = eta + p.mu2p * (psi - uo);               // pending eta update of the previous iteration
   }
-  const float un = soft_thresh_dev(psi + eta / p.mu2, p.thr);
+  const float un = soft_thresh_dev(psi + div_by(eta, p.mu2, p.r_mu2), p.thr);
   eta_new = eta;
   q = p.mu2 * un - eta;
 }
@@ -1036,11 +1066,11 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
       if (!p.first) {
         const float xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
         xiv = xiv + p.mu1p * (hv - xo);
-        const float wo = fmaxf(rhov / p.mu3p + (VWo ? vwos[i] : ocs[i + 1]), 0.f);
+        const float wo = fmaxf(div_by(rhov, p.mu3p, p.r_mu3p) + (VWo ? vwos[i] : ocs[i + 1]), 0.f);
         rhov = rhov + p.mu3p * (vc - wo);
       }
       const float xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
-      const float wn = fmaxf(rhov / p.mu3 + (VWc ? vwcs[i] : vc), 0.f);
+      const float wn = fmaxf(div_by(rhov, p.mu3, p.r_mu3) + (VWc ? vwcs[i] : vc), 0.f);
       const float d1 = q0d - q0c;
       const float d2 = q1[i + 1] - q1[i];
       xin[i] = xiv; rhn[i] = rhov;
@@ -1054,6 +1084,151 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
     st4(Rsp + o, make_float4(rs[0], rs[1], rs[2], rs[3]));
     st4(Aout + o, make_float4(as[0], as[1], as[2], as[3]));
   }
+}
+
+// ---- K1 fused into the forward row pass (wide frames, one real row per half-length transform) -------------------
+// The image-domain half of an ADMM iteration never needs more than rows r-1, r, r+1 of V, so the workgroup that is
+// about to transform row r of `r_sp` (or of `a`) can COMPUTE that row instead of reading it: `r_sp` and `a` never
+// exist in HBM (-4R per iteration: 2.4 GB of 22 at 12 MP) and one launch disappears.  The two outputs separate
+// cleanly:  r_sp = (mu3 W - rho') + Psi^T(mu2 U - eta')  depends on V, V_old, eta, rho only,
+//           a    = mu1 X - xi'                           depends on xi, HV, HV_old, y only,
+// so block (row, 0) does the TV / W part (reads V x3 rows, V_old x3, eta0 x2, eta1, rho; writes eta0', eta1', rho')
+// and block (row, 1) the X part (reads xi, HV, HV_old, y; writes xi').  Same arithmetic, statement for statement, as
+// k_admm_spatial_v4.  The rows above / below are re-read from L2: blocks are handed out
+// in an XCD-aware order (block b runs on XCD b % 8: each XCD gets a contiguous band of rows), so rows r and r+1 are
+// in flight together on ONE L2.  grid = (2 * Hp, planes); `plan` has length Wp/2, `twW` is the length-Wp table.
+template <int NT, int EMAX, bool SK, int UNR = 1>
+__global__ __launch_bounds__(NT) void k_admm_rows_fused(PlaneGeom g, AdmmScalars p, Fft1dPlan plan,
+                                                         const real2* LPC_RESTRICT twW,
+                                                         const float* LPC_RESTRICT V, const float* LPC_RESTRICT Vold,
+                                                         const float* LPC_RESTRICT HV, const float* LPC_RESTRICT HVold,
+                                                         float* LPC_RESTRICT xi, const float* LPC_RESTRICT eta0,
+                                                         const float* LPC_RESTRICT eta1, float* LPC_RESTRICT eta0_out,
+                                                         float* LPC_RESTRICT eta1_out, float* LPC_RESTRICT rho,
+                                                         const float* LPC_RESTRICT Y, real2* LPC_RESTRICT SA,
+                                                         real2* LPC_RESTRICT SB, const float* LPC_RESTRICT VWc,
+                                                         const float* LPC_RESTRICT VWo) {
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int tid = threadIdx.x;
+  const unsigned nblk = gridDim.x, bid = blockIdx.x;   // XCD-aware order (see k_admm_spatial)
+  const unsigned qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+  const unsigned tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+  const int gr = (int)(tile >> 1), arr = (int)(tile & 1);
+  const long pl = blockIdx.y;
+  const long poff = pl * g.rplane;
+  const long o_row = poff + (long)gr * g.rpitch;
+  const int n4 = g.Wp >> 2;
+  if (arr == 0) {
+    const long o_up = poff + (long)(gr == 0 ? g.Hp - 1 : gr - 1) * g.rpitch;
+    const long o_dn = poff + (long)(gr + 1 == g.Hp ? 0 : gr + 1) * g.rpitch;
+#pragma unroll UNR
+    for (int q = tid; q < n4; q += NT) {
+      const int gc = 4 * q;
+      const int cl = gc == 0 ? g.Wp - 1 : gc - 1, cr = gc + 4 == g.Wp ? 0 : gc + 4;
+      const float4 vm4 = ld4(V + o_up + gc), vc4 = ld4(V + o_row + gc), vp4 = ld4(V + o_dn + gc);
+      const float vl = V[o_row + cl], vr = V[o_row + cr];
+      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 om4 = z4, oc4 = z4, op4 = z4;
+      float ol = 0.f, orr = 0.f;
+      if (!p.first) {
+        om4 = ld4(Vold + o_up + gc); oc4 = ld4(Vold + o_row + gc); op4 = ld4(Vold + o_dn + gc);
+        ol = Vold[o_row + cl]; orr = Vold[o_row + cr];
+      }
+      const float4 e04 = ld4(eta0 + o_row + gc), e0d4 = ld4(eta0 + o_dn + gc), e14 = ld4(eta1 + o_row + gc);
+      const float e1r = eta1[o_row + cr];
+      const float4 rho4 = ld4(rho + o_row + gc);
+      float4 vwc4 = z4, vwo4 = z4;
+      if (VWc) vwc4 = ld4(VWc + o_row + gc);
+      if (VWo) vwo4 = ld4(VWo + o_row + gc);
+      const float vwcs[4] = {vwc4.x, vwc4.y, vwc4.z, vwc4.w}, vwos[4] = {vwo4.x, vwo4.y, vwo4.z, vwo4.w};
+      const float vcs[6] = {vl, vc4.x, vc4.y, vc4.z, vc4.w, vr};       // cols gc-1 .. gc+4 of row gr
+      const float ocs[6] = {ol, oc4.x, oc4.y, oc4.z, oc4.w, orr};
+      const float vms[4] = {vm4.x, vm4.y, vm4.z, vm4.w}, vps[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
+      const float oms[4] = {om4.x, om4.y, om4.z, om4.w}, ops[4] = {op4.x, op4.y, op4.z, op4.w};
+      const float rhs[4] = {rho4.x, rho4.y, rho4.z, rho4.w};
+      const float e0s[4] = {e04.x, e04.y, e04.z, e04.w}, e0ds[4] = {e0d4.x, e0d4.y, e0d4.z, e0d4.w};
+      const float e1s[5] = {e14.x, e14.y, e14.z, e14.w, e1r};
+      float q1[5], e1n[5];
+#pragma unroll
+      for (int i = 0; i < 5; ++i)   // column-difference component at cols gc .. gc+4 (the 5th only for q)
+        tv_component(p, vcs[i + 1], vcs[i], ocs[i + 1], ocs[i], e1s[i], e1n[i], q1[i]);
+      float e0n[4], rhn[4], rs[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float q0c, q0d, dummy;
+        tv_component(p, vcs[i + 1], vms[i], ocs[i + 1], oms[i], e0s[i], e0n[i], q0c);   // this pixel
+        tv_component(p, vps[i], vcs[i + 1], ops[i], ocs[i + 1], e0ds[i], dummy, q0d);   // the pixel below
+        const float vc = vcs[i + 1];
+        float rhov = rhs[i];
+        if (!p.first) {
+          const float wo = fmaxf(div_by(rhov, p.mu3p, p.r_mu3p) + (VWo ? vwos[i] : ocs[i + 1]), 0.f);
+          rhov = rhov + p.mu3p * (vc - wo);
+        }
+        const float wn = fmaxf(div_by(rhov, p.mu3, p.r_mu3) + (VWc ? vwcs[i] : vc), 0.f);
+        const float d1 = q0d - q0c;
+        const float d2 = q1[i + 1] - q1[i];
+        rhn[i] = rhov;
+        rs[i] = (p.mu3 * wn - rhov) + (d1 + d2);
+      }
+      st4(rho + o_row + gc, make_float4(rhn[0], rhn[1], rhn[2], rhn[3]));
+      st4(eta0_out + o_row + gc, make_float4(e0n[0], e0n[1], e0n[2], e0n[3]));
+      st4(eta1_out + o_row + gc, make_float4(e1n[0], e1n[1], e1n[2], e1n[3]));
+      s[lds_slot<SK>(2 * q)] = make_real2(rs[0], rs[1]);          // z[j] = (x[2j], x[2j+1])
+      s[lds_slot<SK>(2 * q + 1)] = make_real2(rs[2], rs[3]);
+    }
+  } else {
+    const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
+    const bool row_in = (gr >= g.sh) && (gr < g.sh + g.H);
+    const float* y = Y + (long)dpl * g.uplane + (long)(gr - g.sh) * g.W;     // dereferenced only when row_in
+    const bool y4 = ((g.sw | g.W) & 3) == 0;                                 // window and pitch allow float4 loads of y
+#pragma unroll UNR
+    for (int q = tid; q < n4; q += NT) {
+      const int gc = 4 * q;
+      const float4 hv4 = ld4(HV + o_row + gc), xi4 = ld4(xi + o_row + gc);
+      float4 ho4 = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!p.first) ho4 = ld4(HVold + o_row + gc);
+      float ys[4] = {0.f, 0.f, 0.f, 0.f};
+      bool ins[4] = {false, false, false, false};
+      if (row_in) {
+        if (y4) {
+          if (gc >= g.sw && gc < g.sw + g.W) {
+            const float4 yv = ld4(y + (gc - g.sw));
+            ys[0] = yv.x; ys[1] = yv.y; ys[2] = yv.z; ys[3] = yv.w;
+            ins[0] = ins[1] = ins[2] = ins[3] = true;
+          }
+        } else {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            const int cc = gc + i;
+            ins[i] = (cc >= g.sw) && (cc < g.sw + g.W);
+            if (ins[i]) ys[i] = y[cc - g.sw];
+          }
+        }
+      }
+      const float hvs[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, xis[4] = {xi4.x, xi4.y, xi4.z, xi4.w};
+      const float hos[4] = {ho4.x, ho4.y, ho4.z, ho4.w};
+      float xin[4], as[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float xiv = xis[i];
+        const float hv = hvs[i], yv = ys[i];
+        if (!p.first) {
+          const float xo = (ins[i] ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
+          xiv = xiv + p.mu1p * (hv - xo);
+        }
+        const float xnew = (ins[i] ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
+        xin[i] = xiv;
+        as[i] = p.mu1 * xnew - xiv;
+      }
+      st4(xi + o_row + gc, make_float4(xin[0], xin[1], xin[2], xin[3]));
+      s[lds_slot<SK>(2 * q)] = make_real2(as[0], as[1]);
+      s[lds_slot<SK>(2 * q + 1)] = make_real2(as[2], as[3]);
+    }
+  }
+  __syncthreads();
+  fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
+  untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, (arr ? SB : SA) + pl * g.cplane + (long)gr * g.cpitch, tid);
 }
 
 #endif  // !LPC_DOUBLE
@@ -1086,7 +1261,7 @@ __global__ __launch_bounds__(NT) void k_pnp_pre(PlaneGeom g, AdmmScalars p, int 
     const bool inside = (r >= g.sh) && (r < g.sh + g.H) && (c >= g.sw) && (c < g.sw + g.W);
     const real yv = inside ? Y[(long)dpl * g.uplane + (long)(r - g.sh) * g.W + (c - g.sw)] : (real)0.;
     const real x = (inside ? p.m_in : p.m_out) * (xi[o] + p.mu1 * HV[o] + yv);   // admm.py:252-254
-    const real w = rmax(rho[o] / p.mu3 + V[o], (real)0.);                        // admm.py:256-262
+    const real w = rmax(div_by(rho[o], p.mu3, p.r_mu3) + V[o], (real)0.);                        // admm.py:256-262
     X[o] = x;
     W[o] = w;
     if (dual) {
@@ -1146,9 +1321,9 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
       const real yv = inside ? Y[(long)dpl * g.uplane + (long)(r - g.sh) * g.W + (c - g.sw)] : (real)0.;
       x = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * HVold[o] + yv);   // X of the last iteration
       const real oc = Vold[o], vc = V[o];
-      u0 = soft_thresh_dev((Vold[ou] - oc) + e0 / p.mu2p, p.thrp);
-      u1 = soft_thresh_dev((Vold[ol] - oc) + e1 / p.mu2p, p.thrp);
-      w = rmax(rh / p.mu3p + (VWo ? VWo[o] : oc), (real)0.);
+      u0 = soft_thresh_dev((Vold[ou] - oc) + div_by(e0, p.mu2p, p.r_mu2p), p.thrp);
+      u1 = soft_thresh_dev((Vold[ol] - oc) + div_by(e1, p.mu2p, p.r_mu2p), p.thrp);
+      w = rmax(div_by(rh, p.mu3p, p.r_mu3p) + (VWo ? VWo[o] : oc), (real)0.);
       xiv = xiv + p.mu1p * (HV[o] - x);
       e0 = e0 + p.mu2p * ((V[ou] - vc) - u0);
       e1 = e1 + p.mu2p * ((V[ol] - vc) - u1);

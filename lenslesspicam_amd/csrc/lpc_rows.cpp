@@ -1,0 +1,115 @@
+// lpc_rows.cpp -- launches of every row pass (see lpc_engine.h for the split of the library)
+#include "lpc_engine.h"
+
+// ------------------------------------------------------------- 2-D transform pieces --
+// forward rows of ONE real source (pairs of rows) into spectrum S (planes = nplanes)
+int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int kid) {
+  const PlaneGeom& g = e->g;
+  if (e->rows_half)
+    return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NT, auto EM, auto SK, auto) {
+      constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+      constexpr bool sk = decltype(SK)::value;
+      return launch_k(e, kid, k_rfwd_rows_half<nt, em, sk>, dim3(src.nrows, nplanes), nt,
+                      LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, src, S);
+    });
+  const int nblk = (src.nrows + 1) / 2;
+  return dispatch_row(g.Wp, e->planW.skew_ok, e->rows_r2, [&](auto NT, auto EM, auto SK, auto R2) {
+    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+    constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
+    return launch_k(e, kid, k_rfwd_rows<nt, em, sk, r2>, dim3(nblk, nplanes), nt, LPC_ROW_SMEM_BYTES(g.Wp, sk), g,
+                    e->planW, src, S);
+  });
+}
+
+int rows_inv_single(Engine* e, const real2* S, const RealDst& dst, int nplanes, int kid) {
+  const PlaneGeom& g = e->g;
+  if (e->rows_half)
+    return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NT, auto EM, auto SK, auto) {
+      constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+      constexpr bool sk = decltype(SK)::value;
+      return launch_k(e, kid, k_rinv_rows_half<nt, em, sk>, dim3(dst.nrows, nplanes), nt,
+                      LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, S, dst);
+    });
+  const int nblk = (dst.nrows + 1) / 2;
+  const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
+  return dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NT, auto EM, auto SK, auto R2) {
+    constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
+    constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
+    return launch_k(e, kid, k_rinv_rows<nt, em, sk, r2>, dim3(nblk, nplanes), nt, LPC_ROW_SMEM_BYTES(g.Wp, sk), g,
+                    pinv, S, dst);
+  });
+}
+
+// ---- ADMM: rows of r_sp and a (e->Rsp, e->Aarr) -> the two work spectra --------------------------------------
+int admm_rows_fwd(Engine* e) {
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  if (e->rows_half)
+    return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
+      constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
+      constexpr bool sk = decltype(SK)::value;
+      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_half<nt, em, sk>, dim3(2 * g.Hp, e->P), nt,
+                      LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real*)e->Rsp,
+                      (const real*)e->Aarr, SA, SB);
+    });
+  return dispatch_row(g.Wp, e->planW.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
+    constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
+    constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
+    return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<nt, em, sk, r2>, dim3(g.Hp, e->P), nt,
+                    LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
+  });
+}
+
+// ---- ADMM: the image-domain kernel fused into the forward rows (float32, half-length rows, Wp % 4 == 0) -------
+int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real* Vo) {
+#ifdef LPC_DOUBLE
+  (void)sc; (void)Vc; (void)Vo;
+  return fail("internal: the fused ADMM rows are float32-only");
+#else
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  static int unr = -1;     // tuning knob: chunks of a row in flight per thread (12-MP shape only)
+  if (unr < 0) unr = std::getenv("LPC_FUSED_UNROLL") ? atoi(std::getenv("LPC_FUSED_UNROLL")) : 1;
+  return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
+    constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
+    constexpr bool sk = decltype(SK)::value;
+    auto go = [&](auto kernel) {
+      return launch_k(e, LPC_K_SPATIAL, kernel, dim3(2 * g.Hp, e->P), nt,
+                      LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, sc, e->planWh, (const real2*)e->planW.tw, Vc, Vo,
+                      (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi,
+                      (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
+                      e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB,
+                      (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr));
+    };
+    if constexpr (nt == 256 && em == 16 && sk) {
+      if (unr == 2) return go(k_admm_rows_fused<nt, em, sk, 2>);
+      if (unr == 4) return go(k_admm_rows_fused<nt, em, sk, 4>);
+    }
+    return go(k_admm_rows_fused<nt, em, sk, 1>);
+  });
+#endif
+}
+
+// ---- ADMM: the two work spectra -> V and H V (padded, no shift) ------------------------------------------------
+int admm_rows_inv(Engine* e, real* Vout, real* HVout) {
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
+  if (e->rows_half)
+    return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
+      constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
+      constexpr bool sk = decltype(SK)::value;
+      return launch_k(e, LPC_K_ROW_INV, k_rinv_half<nt, em, sk>, dim3(2 * g.Hp, e->P), nt,
+                      LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real2*)SA,
+                      (const real2*)SB, Vout, HVout);
+    });
+  return dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
+    constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
+    constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
+    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em, sk, r2>, dim3(g.Hp, e->P), nt,
+                    LPC_ROW_SMEM_BYTES(g.Wp, sk), g, pinv, (const real2*)SA, (const real2*)SB, Vout, HVout);
+  });
+}

@@ -199,3 +199,10 @@ def test_momentum_override_survives_batch_change(backend):
         o.set_data(ys[b, 0])
         o.reset(p=0.0, mu=0.5)
         assert rel(got[b], o.apply(5, reset=False)) <= 5e-6
+
+
+def test_apply_display_loop_golden_fused_rows(backend, monkeypatch, tmp_path):
+    """The same vectors through the 12-MP code path (half-length rows with the image-domain kernel fused into them):
+    the clamped copies of the estimate that the W-update sees after a read-out travel through k_admm_rows_fused."""
+    monkeypatch.setenv("LPC_ROWS_HALF", "1")
+    test_apply_display_loop_golden(backend, tmp_path)

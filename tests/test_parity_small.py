@@ -310,12 +310,17 @@ def test_forced_four_step_column_split(backend, monkeypatch, h, hp, n2):
     assert rel(conv.deconvolve(x), of.conv.deconvolve(x)) <= 2e-6
 
 
-@pytest.mark.parametrize("name", ["admm_24x32x3_tv", "admm_47x29x3_tv"])
-def test_admm_half_length_row_kernels(backend, monkeypatch, name):
-    """ADMM's row passes switch to one real row per half-length complex transform (k_rfwd_half / k_rinv_half) for
-    wide frames only; LPC_ROWS_HALF forces them on the golden-vector sizes (row transforms of 32 and 30 points,
-    the second one without the LDS skew): same trajectory checks as the regular golden test."""
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
+@pytest.mark.parametrize("name", ["admm_24x32x3_tv", "admm_47x29x3_tv", "admm_24x32x3_init_bg", "admm_24x32x3_default"])
+def test_admm_half_length_row_kernels(backend, monkeypatch, name, fused):
+    """ADMM's row passes switch to one real row per half-length complex transform for wide frames only;
+    LPC_ROWS_HALF forces them on the golden-vector sizes (row transforms of 32 and 30 points, the second one without
+    the LDS skew): same trajectory checks as the regular golden test.  `fused`: the image-domain kernel computes the
+    rows of r_sp and a inside the forward row workgroups (k_admm_rows_fused) -- the 12-MP code path; LPC_NO_FUSE_ROWS
+    selects the stand-alone kernels (k_admm_spatial_v4 + k_rfwd_half) instead."""
     monkeypatch.setenv("LPC_ROWS_HALF", "1")
+    if not fused:
+        monkeypatch.setenv("LPC_NO_FUSE_ROWS", "1")
     test_admm_matches_reference_golden(backend, name)
 
 

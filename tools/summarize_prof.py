@@ -43,7 +43,7 @@ lines = [f"# rocprofv3 PMC summary ({tag})", "",
          "Separate `--pmc` passes (FETCH_SIZE | WRITE_SIZE | SQ_*), `bench.py --n-iter 4`, mean per dispatch.",
          "FETCH_SIZE / WRITE_SIZE are KiB; `HBM GB` = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction, guide section HBM).", ""]
 cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
-        "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT"]
+        "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "TCC_HIT_sum", "TCC_MISS_sum"]
 lines.append("| kernel | wg | LDS B | VGPR | SGPR | n | HBM GB | " + " | ".join(cols) + " |")
 lines.append("|---|---|---|---|---|---|---|" + "---|" * len(cols))
 traffic = {}
@@ -63,8 +63,9 @@ for k in sorted(agg):
     lines[-1] += " | ".join(f"{mean[c]:.3g}" if mean.get(c) is not None else "-" for c in cols) + " |"
 open(os.path.join(out, f"{tag}_counters.md"), "w").write("\n".join(lines) + "\n")
 for k, v in traffic.items():
-    if k.startswith("k_admm_spatial"):
-        json.dump({"kernel": k, "hbm_bytes_per_launch": v, "source": f"profiles/{tag}_counters.md",
+    if k.startswith("k_admm_rows_fused") or (k.startswith("k_admm_spatial") and not any(
+            q.startswith("k_admm_rows_fused") for q in traffic)):
+        json.dump({"kernel": k, "hbm_bytes_per_launch": v, "source": f"profiles/{tag}_counters.md", "snapshot": tag,
                    "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes"},
                   open(os.path.join(out, "k1_traffic.json"), "w"), indent=1)
 print("\n".join(lines))
