@@ -14,6 +14,12 @@ int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1,
     cp.needn = g.H;
   }
   const dim3 grid(cp.G * cp.ntile_c, nplanes);
+  if (e->static_cols) {   // 128-point pass A, 16 columns per tile: 2048 points = 256 threads x 8
+    const size_t smem = (size_t)128 * 16 * sizeof(real2);
+    const SPlanArg<ColPlan128> pa = splan_arg<ColPlan128>(e->planA);
+    if (inverse) return launch_k(e, kid, k_cols<256, 8, true, SPlanArg<ColPlan128>, 16>, grid, 256, smem, g, pa, cp, S);
+    return launch_k(e, kid, k_cols<256, 8, false, SPlanArg<ColPlan128>, 16>, grid, 256, smem, g, pa, cp, S);
+  }
   return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
     const size_t smem = (size_t)cp.N * cp.T * sizeof(real2);
@@ -92,6 +98,12 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
     // (profiles/r01b_notes.md): 24 points 0.89 ms and 32 points 0.83 ms beat the LDS middle (0.99 / 0.92 ms) but
     // need a 256- / 192-point pass A that costs more than it saves; 48 points is 1.62 ms (AGPR traffic).
     if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_admm_reg<8, 3>)); }
+    else if (e->static_cols) {   // 48-point middle, 2 x 16 tile columns: 1536 points = 256 threads x 6
+      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<256, 8, SPlanArg<ColPlan48>, 32>, grid, 256,
+                      (size_t)48 * 32 * sizeof(real2), g, splan_arg<ColPlan48>(e->planB), cp, SA, SB,
+                      (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2,
+                      sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
+    }
     else if (cp.N * cp.T * 2 > 8192 && cp.N * cp.T * 2 <= 9216) {
       // just above 8192 points (C1 / C4: 540 rows x 8 columns x 2 arrays = 8640): 512 threads x 18 points keeps
       // TWO workgroups per CU inside the 128-VGPR budget; 1024 x 16 is one 16-wave workgroup per CU in lock-step

@@ -199,11 +199,17 @@ static int setup_geometry(Engine* e) {
   e->rows_half = half_ok && wide && !std::getenv("LPC_ROWS_PAIRED");
   if (half_ok && std::getenv("LPC_ROWS_HALF")) e->rows_half = true;   // test knob: small frames too
   if (e->rows_half) LPC_OK(build_plan(e, e->planWh, g.Wp / 2));
+  if (e->rows_half && RowPlan4096::matches(e->planWh) && e->planWh.skew_ok && !std::getenv("LPC_NO_STATIC"))
+    e->static_rows = 4096;
+
   // float4 lanes and half-length rows: r_sp and a are computed by the row workgroups themselves (float32 build)
   e->fuse_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && e->rows_half && g.Wp % 4 == 0 &&
                  !std::getenv("LPC_NO_FUSE_ROWS") && !std::getenv("LPC_K1_SCALAR");
   LPC_OK(build_plan(e, e->planB, e->N2));
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
+  e->static_sk = !std::getenv("LPC_ROWS_NOSKEW");
+  e->static_cols = e->N1 == 128 && e->N2 == 48 && e->T == 16 && ColPlan128::matches(e->planA) &&
+                   ColPlan48::matches(e->planB) && !std::getenv("LPC_NO_STATIC") && !std::getenv("LPC_NO_STATIC_COLS");
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
   const int ntc = (g.Wc + e->T - 1) / e->T;
   ColPass& A = e->passA;

@@ -79,6 +79,9 @@ struct lpc_engine {
   Fft1dPlan planWi{};   // inverse-row plan with the radix-2 stage FIRST (rows_r2 only)
   Fft1dPlan planWh{};   // length Wp/2: ADMM rows, one real row per half-length transform (rows_half)
   bool rows_half = false;
+  bool static_sk = true;   // static-plan row kernels: LDS skew on (tuning knob LPC_ROWS_NOSKEW: 32 KiB tiles, 5 per CU)
+  bool static_cols = false;  // 128 x 48 split with T = 16 served by compile-time plans
+  int static_rows = 0;     // length of the half-row transform when a compile-time plan serves it (lpc_sfft.h), else 0
   bool fuse_rows = false;  // ADMM: the image-domain kernel is fused into the forward row pass (k_admm_rows_fused)
   bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (LPC_MID_LDS=1: off)
   bool rows_r2 = false; // row plans end in a radix-2 stage: fold it into the Hermitian (un)tangling
@@ -217,6 +220,17 @@ static inline RealDst dst_cropped(const Engine* e, real* base) {
   d.base = base; d.plane_stride = g.uplane; d.pitch = g.W; d.nrows = g.H; d.row0 = g.sh; d.col0 = g.sw;
   d.ncols = g.W;
   return d;
+}
+
+// static-plan shapes (lpc_sfft.h).  4096 = 8.8.8.8: the half-row transform of 8192-column padded frames (12 MP)
+typedef SPlan<8, 8, 8, 8> RowPlan4096;
+typedef SPlanArg<RowPlan4096> RowArg4096;
+// 12 MP's column split 6144 = 128 x 48 with 16-column tiles: pass A 128 = 8.8.2, fused middle 48 = 8.6
+typedef SPlan<8, 8, 2> ColPlan128;
+typedef SPlan<8, 6> ColPlan48;
+template <class F>
+static inline int with_sk(bool sk, F&& f) {
+  return sk ? f(std::integral_constant<bool, true>{}) : f(std::integral_constant<bool, false>{});
 }
 
 // ---- host functions that cross translation units ------------------------------------------------------------

@@ -132,8 +132,8 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan pl
 }
 
 // ---- the same two kernels with one real row per half-length transform (wide frames, see k_rfwd_half) ----
-template <int NT, int EMAX, bool SK>
-__global__ __launch_bounds__(NT) void k_rinv_gd_mid_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+__global__ __launch_bounds__(NT) void k_rinv_gd_mid_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                           const real2* LPC_RESTRICT Sin,
                                                           real2* LPC_RESTRICT Sout,
                                                           const real* LPC_RESTRICT Y) {
@@ -161,8 +161,8 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid_half(PlaneGeom g, Fft1dPlan 
   untangle_half_store<NT, SK>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
 }
 
-template <int NT, int EMAX, bool SK>
-__global__ __launch_bounds__(NT) void k_rinv_gd_update_half(PlaneGeom g, Fft1dPlan plan,
+template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+__global__ __launch_bounds__(NT) void k_rinv_gd_update_half(PlaneGeom g, PL plan,
                                                              const real2* LPC_RESTRICT twW,
                                                              const real2* LPC_RESTRICT Sin, real* LPC_RESTRICT X,
                                                              real* LPC_RESTRICT AUX, const real* LPC_RESTRICT alpha,

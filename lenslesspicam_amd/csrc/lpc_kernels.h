@@ -14,7 +14,7 @@
 // constant (H, |PsiT Psi|, phase tables) is generated in the same order, so no transpose
 // or reordering pass ever touches HBM.
 #pragma once
-#include "lpc_fft.h"
+#include "lpc_sfft.h"
 
 struct PlaneGeom {
   int H, W;        // un-padded spatial size
@@ -198,8 +198,8 @@ static __device__ __forceinline__ void untangle_half_store(const real2* s, int M
   }
 }
 
-template <int NT, int EMAX, bool SK>
-__global__ __launch_bounds__(NT) void k_rfwd_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+__global__ __launch_bounds__(NT) void k_rfwd_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                    const real* LPC_RESTRICT A, const real* LPC_RESTRICT B,
                                                    real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
@@ -243,8 +243,8 @@ static __device__ __forceinline__ void tangle_half_load(real2* s, int M, const r
   }
 }
 
-template <int NT, int EMAX, bool SK>
-__global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+__global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                    const real2* LPC_RESTRICT SA, const real2* LPC_RESTRICT SB,
                                                    real* LPC_RESTRICT A, real* LPC_RESTRICT B) {
   LPC_DYN_SMEM(smem);
@@ -292,8 +292,8 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, R
 }
 
 // one real row per half-length transform (see k_rfwd_half), generic source with pad on load
-template <int NT, int EMAX, bool SK>
-__global__ __launch_bounds__(NT) void k_rfwd_rows_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+__global__ __launch_bounds__(NT) void k_rfwd_rows_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                         RealSrc src, real2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
@@ -385,8 +385,8 @@ __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
 }
 
 // one real row per half-length transform, generic sink with ifftshift (+ crop)
-template <int NT, int EMAX, bool SK>
-__global__ __launch_bounds__(NT) void k_rinv_rows_half(PlaneGeom g, Fft1dPlan plan, const real2* LPC_RESTRICT twW,
+template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+__global__ __launch_bounds__(NT) void k_rinv_rows_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                         const real2* LPC_RESTRICT S, RealDst dst) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
@@ -431,8 +431,9 @@ struct ColPass {
 };
 
 // plain pass over ONE spectrum array, in place (global -> registers -> [LDS] -> registers -> global)
-template <int NT, int EMAX, bool INV>
-__global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, Fft1dPlan plan, ColPass cp,
+// PL / SBT: run-time plan (SBT unused), or a compile-time plan with SBT == cp.T columns per tile (lpc_sfft.h)
+template <int NT, int EMAX, bool INV, class PL = Fft1dPlan, int SBT = 0>
+__global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
                                               real2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
@@ -462,8 +463,13 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, Fft1dPlan plan, ColPas
       base[i * rstep + c] = x;
     }
   };
-  if (INV) fft_tile<NT, EMAX, INV, false, false, true, LPC_COLS_FUSEL>(s, plan, cp.T, cp.tdiv, tid, in, out, untwiddle);
-  else fft_tile<NT, EMAX, INV, false, false, false, LPC_COLS_FUSEL>(s, plan, cp.T, cp.tdiv, tid, in, out);
+  if constexpr (is_static_plan<PL>::value) {
+    if (INV) fft_tile<NT, EMAX, INV, false, false, true, LPC_COLS_FUSEL, SBT>(s, plan, cp.T, cp.tdiv, tid, in, out, untwiddle);
+    else fft_tile<NT, EMAX, INV, false, false, false, LPC_COLS_FUSEL, SBT>(s, plan, cp.T, cp.tdiv, tid, in, out);
+  } else {
+    if (INV) fft_tile<NT, EMAX, INV, false, false, true, LPC_COLS_FUSEL>(s, plan, cp.T, cp.tdiv, tid, in, out, untwiddle);
+    else fft_tile<NT, EMAX, INV, false, false, false, LPC_COLS_FUSEL>(s, plan, cp.T, cp.tdiv, tid, in, out);
+  }
 }
 
 // fused middle of a convolution: forward pass B -> multiply by the PSF spectrum (or its
@@ -689,8 +695,9 @@ __global__ __launch_bounds__(64) void k_cols_mid_admm_reg(PlaneGeom g, Fft1dPlan
 //   HVh = s * H * Vh                             (s = spectral phase of ifftshift)
 // then inverse pass B; SA <- Vh path, SB <- HVh path.
 // Tile: [N][2T] -- columns 0..T-1 belong to SA, T..2T-1 to SB.
-template <int NT, int EMAX>
-__global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan plan, ColPass cp,
+// PL / SBT2: run-time plan, or a compile-time plan with SBT2 == 2 * cp.T tile columns (both arrays)
+template <int NT, int EMAX, class PL = Fft1dPlan, int SBT2 = 0>
+__global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColPass cp,
                                                        real2* LPC_RESTRICT SA,
                                                        real2* LPC_RESTRICT SB,
                                                        const real2* LPC_RESTRICT Hs,
@@ -731,7 +738,10 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
     const int j = c < T ? c : c - T;
     return (c0 + j < g.Wc) ? (c < T ? ba : bb)[i * rstep + j] : make_real2((real)0., (real)0.);
   };
-  fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1>(s, plan, T2, t2div, tid, in, LdsNatural{});
+  if constexpr (is_static_plan<PL>::value)
+    fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1, false, SBT2>(s, plan, T2, t2div, tid, in, LdsNatural{});
+  else
+    fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1>(s, plan, T2, t2div, tid, in, LdsNatural{});
 #pragma unroll
   for (int k = 0; k < EP; ++k) {
     const int e = tid + k * NT;
@@ -759,7 +769,10 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, Fft1dPlan pla
     const int j = c < T ? c : c - T;
     if (c0 + j < g.Wc) (c < T ? ba : bb)[i * rstep + j] = x;
   };
-  fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL>(s, plan, T2, t2div, tid, LdsNatural{}, out);
+  if constexpr (is_static_plan<PL>::value)
+    fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL, SBT2>(s, plan, T2, t2div, tid, LdsNatural{}, out);
+  else
+    fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL>(s, plan, T2, t2div, tid, LdsNatural{}, out);
 }
 
 // ============================================================ ADMM spatial kernel ==
@@ -1097,8 +1110,8 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
 // k_admm_spatial_v4.  The rows above / below are re-read from L2: blocks are handed out
 // in an XCD-aware order (block b runs on XCD b % 8: each XCD gets a contiguous band of rows), so rows r and r+1 are
 // in flight together on ONE L2.  grid = (2 * Hp, planes); `plan` has length Wp/2, `twW` is the length-Wp table.
-template <int NT, int EMAX, bool SK, int UNR = 1>
-__global__ __launch_bounds__(NT) void k_admm_rows_fused(PlaneGeom g, AdmmScalars p, Fft1dPlan plan,
+template <int NT, int EMAX, bool SK, int UNR = 1, int MINW = 1, class PL = Fft1dPlan>
+__global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmScalars p, PL plan,
                                                          const real2* LPC_RESTRICT twW,
                                                          const float* LPC_RESTRICT V, const float* LPC_RESTRICT Vold,
                                                          const float* LPC_RESTRICT HV, const float* LPC_RESTRICT HVold,

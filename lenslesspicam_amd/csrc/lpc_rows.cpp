@@ -5,6 +5,12 @@
 // forward rows of ONE real source (pairs of rows) into spectrum S (planes = nplanes)
 int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
+  if (e->rows_half && e->static_rows == 4096)
+    return with_sk(e->static_sk, [&](auto SKc) {
+      constexpr bool sk = decltype(SKc)::value;
+      return launch_k(e, kid, k_rfwd_rows_half<256, 16, sk, RowArg4096>, dim3(src.nrows, nplanes), 256,
+                      LPC_ROW_SMEM_BYTES(4096, sk), g, splan_arg<RowPlan4096>(e->planWh), e->planW.tw, src, S);
+    });
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NT, auto EM, auto SK, auto) {
       constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
@@ -23,6 +29,12 @@ int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int ki
 
 int rows_inv_single(Engine* e, const real2* S, const RealDst& dst, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
+  if (e->rows_half && e->static_rows == 4096)
+    return with_sk(e->static_sk, [&](auto SKc) {
+      constexpr bool sk = decltype(SKc)::value;
+      return launch_k(e, kid, k_rinv_rows_half<256, 16, sk, RowArg4096>, dim3(dst.nrows, nplanes), 256,
+                      LPC_ROW_SMEM_BYTES(4096, sk), g, splan_arg<RowPlan4096>(e->planWh), e->planW.tw, S, dst);
+    });
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NT, auto EM, auto SK, auto) {
       constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
@@ -45,6 +57,13 @@ int admm_rows_fwd(Engine* e) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
+  if (e->rows_half && e->static_rows == 4096)
+    return with_sk(e->static_sk, [&](auto SKc) {
+      constexpr bool sk = decltype(SKc)::value;
+      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_half<256, 16, sk, RowArg4096>, dim3(2 * g.Hp, e->P), 256,
+                      LPC_ROW_SMEM_BYTES(4096, sk), g, splan_arg<RowPlan4096>(e->planWh), e->planW.tw,
+                    (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
+    });
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
@@ -72,6 +91,25 @@ int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real
   real2* SB = e->S + (size_t)e->P * g.cplane;
   static int unr = -1;     // tuning knob: chunks of a row in flight per thread (12-MP shape only)
   if (unr < 0) unr = std::getenv("LPC_FUSED_UNROLL") ? atoi(std::getenv("LPC_FUSED_UNROLL")) : 1;
+  if (e->static_rows == 4096 && !std::getenv("LPC_FUSED_OCC5") && !std::getenv("LPC_FUSED_UNROLL"))
+    return with_sk(e->static_sk, [&](auto SKc) {
+      constexpr bool sk = decltype(SKc)::value;
+      return launch_k(e, LPC_K_SPATIAL, k_admm_rows_fused<256, 16, sk, 1, 1, RowArg4096>, dim3(2 * g.Hp, e->P), 256,
+                      LPC_ROW_SMEM_BYTES(4096, sk), g, sc, splan_arg<RowPlan4096>(e->planWh), (const real2*)e->planW.tw,
+                    Vc, Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi,
+                    (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
+                    e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB,
+                    (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr));
+    });
+  static int occ5 = -1;    // tuning knob: un-skewed 32 KiB tile + 96-VGPR budget = 5 workgroups per CU (12-MP shape only)
+  if (occ5 < 0) occ5 = std::getenv("LPC_FUSED_OCC5") ? 1 : 0;
+  if (occ5 && g.Wp == 8192)
+    return launch_k(e, LPC_K_SPATIAL, k_admm_rows_fused<256, 16, false, 1, 5>, dim3(2 * g.Hp, e->P), 256,
+                    LPC_ROW_SMEM_BYTES(g.Wp / 2, false), g, sc, e->planWh, (const real2*)e->planW.tw, Vc, Vo,
+                    (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi,
+                    (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
+                    e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB,
+                    (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr));
   return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
     constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
     constexpr bool sk = decltype(SK)::value;
@@ -98,6 +136,13 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout) {
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
+  if (e->rows_half && e->static_rows == 4096)
+    return with_sk(e->static_sk, [&](auto SKc) {
+      constexpr bool sk = decltype(SKc)::value;
+      return launch_k(e, LPC_K_ROW_INV, k_rinv_half<256, 16, sk, RowArg4096>, dim3(2 * g.Hp, e->P), 256,
+                      LPC_ROW_SMEM_BYTES(4096, sk), g, splan_arg<RowPlan4096>(e->planWh), e->planW.tw,
+                    (const real2*)SA, (const real2*)SB, Vout, HVout);
+    });
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;

@@ -1,0 +1,233 @@
+// lpc_sfft.h -- the workgroup FFT of lpc_fft.h with the PLAN AS A TYPE.
+//
+// lpc_fft.h runs any 5-smooth length from a plan passed by value at launch time: radix per stage from a `switch`,
+// index arithmetic through run-time strides and reciprocal multiplications, tail guards on every loop, and a plan
+// structure that alone takes ~60 SGPRs.  The shapes that carry BASELINE.json's configurations are few and known
+// (4096-point half rows of a 12-MP frame, its 128 x 48 column split, 1920 / 90 x 24 for the 1080p depth stack, ...);
+// for those the host picks a kernel instantiated on `SPlanArg<SPlan<radices...>>` instead of `Fft1dPlan`, and
+// fft_tile() -- same name, same contract, overloaded on the plan type -- expands into straight-line stages:
+//   * length, radix, stride, twiddle step, tile width and thread count are constants: butterfly / element indices are
+//     shifts and masks, LDS offsets are immediates, no tail guards when the work divides by the workgroup;
+//   * the stage loop is unrolled at compile time (no radix switch, so registers are allocated for the radices that
+//     are really used);
+//   * the kernel argument shrinks to the twiddle-table pointer.
+// Kernels stay single-source: they are templates on the plan argument type and call fft_tile(s, plan, ...) either way.
+#pragma once
+#include "lpc_fft.h"
+#include <utility>
+
+template <int... RS>
+struct SPlan {
+  static constexpr int nst = (int)sizeof...(RS);
+  static constexpr int n = (1 * ... * RS);
+  static __host__ __device__ constexpr int radix(int st) {
+    const int r[] = {RS...};
+    return r[st];
+  }
+  static __host__ __device__ constexpr int ns(int st) {   // product of the radices of the stages before st
+    int v = 1;
+    for (int i = 0; i < st; ++i) v *= radix(i);
+    return v;
+  }
+  // same rule as plan_from_radices() in lpc_engine.cpp: the i + i/8 skew stays affine in every stage
+  static __host__ __device__ constexpr bool skew_ok() {
+    for (int st = 0; st < nst; ++st) {
+      if ((n / radix(st)) % 8 != 0) return false;
+      if (!(ns(st) % 8 == 0 || (ns(st) == 1 && radix(st) % 8 == 0))) return false;
+    }
+    return true;
+  }
+  static bool matches(const Fft1dPlan& p) {             // host: is this the plan build_plan() made?
+    if (p.n != n || p.nst != nst) return false;
+    for (int st = 0; st < nst; ++st)
+      if (p.radix[st] != radix(st)) return false;
+    return true;
+  }
+};
+
+// what a kernel receives instead of an Fft1dPlan: only the twiddle table travels at run time
+template <class P>
+struct SPlanArg {
+  using plan = P;
+  static constexpr int n = P::n;
+  const real2* tw;   // exp(-2 pi i q / n), n entries (the table of the Fft1dPlan this replaces)
+};
+template <class P>
+static inline SPlanArg<P> splan_arg(const Fft1dPlan& p) {
+  SPlanArg<P> a;
+  a.tw = p.tw;
+  return a;
+}
+
+template <class T> struct is_static_plan : std::false_type {};
+template <class P> struct is_static_plan<SPlanArg<P>> : std::true_type {};
+
+// ---- one stage, everything but tid and the pointers known at compile time ------------------------------------
+template <class P, int ST, int NT, int BT, bool INV, bool SKEW>
+static __device__ __forceinline__ void sfft_stage(real2* s, const real2* LPC_RESTRICT tw, int tid) {
+  constexpr int R = P::radix(ST), N = P::n, NS = P::ns(ST);
+  constexpr int NB = N / R, NWORK = NB * BT, MAXB = (NWORK + NT - 1) / NT;
+  constexpr bool GUARD = (NWORK % NT) != 0;
+  constexpr int IST = NB * BT, OST = NS * BT;
+  constexpr int RS = SKEW ? IST + (IST >> 3) : IST, WS = SKEW ? OST + (OST >> 3) : OST;
+  constexpr int TWSTEP = N / (NS * R);
+  real2 v[MAXB][R];
+  int obase[MAXB];
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int w = tid + b * NT;
+    obase[b] = -1;
+    if (!GUARD || w < NWORK) {
+      const int j = w / BT, c = w % BT;
+      const int jq = j / NS, k = j % NS;
+      const int rb = lds_slot<SKEW>(w);
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[b][m] = s[rb + m * RS];
+      if (NS > 1) twiddle_mul<R, INV>(v[b], tw, k * TWSTEP);
+      Dft<R, INV>::run(v[b]);
+      obase[b] = lds_slot<SKEW>((jq * NS * R + k) * BT + c);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    if (!GUARD || obase[b] >= 0) {
+      if (SKEW && NS == 1) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) s[obase[b] + m + (m >> 3)] = v[b][m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < R; ++m) s[obase[b] + m * WS] = v[b][m];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+template <class P, int NT, int BT, bool INV, bool SKEW, int FIRST, int... I>
+static __device__ __forceinline__ void sfft_stages(real2* s, const real2* LPC_RESTRICT tw, int tid,
+                                                    std::integer_sequence<int, I...>) {
+  (sfft_stage<P, FIRST + I, NT, BT, INV, SKEW>(s, tw, tid), ...);
+}
+
+// first stage fused into the tile fill (see fft_first_stage_fused)
+template <class P, int NT, int BT, bool INV, bool SKEW, bool SRC_LDS, class Src, class Fix>
+static __device__ __forceinline__ void sfft_first_fused(real2* s, int tid, Src& src, Fix& fix) {
+  constexpr int R = P::radix(0), N = P::n;
+  constexpr int NB = N / R, NWORK = NB * BT, MAXB = (NWORK + NT - 1) / NT;
+  constexpr bool GUARD = (NWORK % NT) != 0;
+  real2 v[MAXB][R];
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int w = tid + b * NT;
+    if (!GUARD || w < NWORK) {
+      const int j = w / BT, c = w % BT;
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[b][m] = src(j + m * NB, c);
+    }
+  }
+  if (SRC_LDS) __syncthreads();
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int w = tid + b * NT;
+    if (!GUARD || w < NWORK) {
+      const int j = w / BT, c = w % BT;
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[b][m] = fix(j + m * NB, c, v[b][m]);
+      Dft<R, INV>::run(v[b]);
+      const int ob = lds_slot<SKEW>(j * R * BT + c);
+      if (SKEW) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) s[ob + m + (m >> 3)] = v[b][m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < R; ++m) s[ob + m * BT] = v[b][m];
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// last stage fused into the drain (see fft_last_stage_fused)
+template <class P, int NT, int BT, bool INV, bool SKEW, class Dst>
+static __device__ __forceinline__ void sfft_last_fused(real2* s, const real2* LPC_RESTRICT tw, int tid, Dst& dst) {
+  constexpr int ST = P::nst - 1;
+  constexpr int R = P::radix(ST), N = P::n, NS = P::ns(ST);
+  constexpr int NB = N / R, NWORK = NB * BT, MAXB = (NWORK + NT - 1) / NT;
+  constexpr bool GUARD = (NWORK % NT) != 0;
+  constexpr int IST = NB * BT, RS = SKEW ? IST + (IST >> 3) : IST;
+  constexpr int TWSTEP = N / (NS * R);
+  real2 v[MAXB][R];
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int w = tid + b * NT;
+    if (!GUARD || w < NWORK) {
+      const int rb = lds_slot<SKEW>(w);
+#pragma unroll
+      for (int m = 0; m < R; ++m) v[b][m] = s[rb + m * RS];
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b) {
+    const int w = tid + b * NT;
+    if (!GUARD || w < NWORK) {
+      const int j = w / BT, c = w % BT;
+      const int jq = j / NS, k = j % NS;
+      if (NS > 1) twiddle_mul<R, INV>(v[b], tw, k * TWSTEP);
+      Dft<R, INV>::run(v[b]);
+      const int oi = jq * NS * R + k;
+#pragma unroll
+      for (int m = 0; m < R; ++m) dst(oi + m * NS, c, v[b][m]);
+    }
+  }
+}
+
+// ---- fft_tile, static-plan overload: same template parameters and call shape as the run-time one ----------------
+// EMAX must be n * BT / NT rounded up (the kernels' launch tables guarantee it); BT is passed as a run-time value for
+// source compatibility but MUST equal the compile-time SBT the kernel was instantiated for.
+template <int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, bool FUSE1 = false, bool FUSEL = false, int SBT = 1,
+          class P, class Src, class Dst, class Fix = NoFix>
+static __device__ __forceinline__ void fft_tile(real2* s, const SPlanArg<P>& pa, int /*BT*/, FastDiv /*btdiv*/, int tid,
+                                                 Src src, Dst dst, Fix fix = Fix()) {
+  constexpr int BT = SBT;
+  constexpr int NELEM = P::n * BT;
+  constexpr int EM = (NELEM + NT - 1) / NT;
+  constexpr bool GUARD = (NELEM % NT) != 0;
+  static_assert(EM <= EMAX, "static plan: the tile does not fit the workgroup shape");
+  constexpr bool src_lds = std::is_same<Src, LdsNatural>::value, dst_lds = std::is_same<Dst, LdsNatural>::value;
+  constexpr bool fuse1 = FUSE1 && !src_lds && P::nst >= 1;
+  constexpr bool fusel = FUSEL && !dst_lds && (P::nst - (fuse1 ? 1 : 0)) >= 1;
+  const real2* tw = pa.tw;
+  if constexpr (fuse1) {
+    sfft_first_fused<P, NT, BT, INV, SKEW, SRC_LDS>(s, tid, src, fix);
+  } else if constexpr (!src_lds) {
+    real2 v[EM];
+#pragma unroll
+    for (int k = 0; k < EM; ++k) {
+      const int e = tid + k * NT;
+      if (!GUARD || e < NELEM) v[k] = src(e / BT, e % BT);
+    }
+    if (SRC_LDS) __syncthreads();
+#pragma unroll
+    for (int k = 0; k < EM; ++k) {
+      const int e = tid + k * NT;
+      if (!GUARD || e < NELEM) {
+        if constexpr (std::is_same<Fix, NoFix>::value) s[lds_slot<SKEW>(e)] = v[k];
+        else s[lds_slot<SKEW>(e)] = fix(e / BT, e % BT, v[k]);
+      }
+    }
+    __syncthreads();
+  }
+  constexpr int FIRST = fuse1 ? 1 : 0;
+  constexpr int NMID = P::nst - FIRST - (fusel ? 1 : 0);
+  sfft_stages<P, NT, BT, INV, SKEW, FIRST>(s, tw, tid, std::make_integer_sequence<int, (NMID > 0 ? NMID : 0)>{});
+  if constexpr (fusel) {
+    sfft_last_fused<P, NT, BT, INV, SKEW>(s, tw, tid, dst);
+  } else if constexpr (!dst_lds) {
+#pragma unroll
+    for (int k = 0; k < EM; ++k) {
+      const int e = tid + k * NT;
+      if (!GUARD || e < NELEM) dst(e / BT, e % BT, s[lds_slot<SKEW>(e)]);
+    }
+  }
+}

@@ -339,3 +339,57 @@ def test_convolver_half_length_row_kernels(backend, monkeypatch):
     for tag in ("a", "b", "c"):
         test_convolver_golden(backend, tag)
     test_convolver_slice_commutes(backend)
+
+
+@pytest.mark.parametrize("static", [True, False], ids=["static_plan", "runtime_plan"])
+def test_8192_column_rows_static_plan(backend, monkeypatch, static):
+    """12 MP's ROW shape on a frame with only a few rows: 4096 columns pad to 8192, the half-row transform has 4096
+    points = 8.8.8.8, which is served by kernels instantiated on a compile-time plan (lpc_sfft.h) -- ADMM through the
+    fused image-domain + row kernel, the gradient-descent family's residual / update kernels, and the convolver's
+    pad-on-load / crop-on-store rows.  LPC_NO_STATIC runs the same frame through the run-time plan."""
+    if not static:
+        monkeypatch.setenv("LPC_NO_STATIC", "1")
+    H, W, C = 3, 4096, 1
+    rng = np.random.default_rng(11)
+    psf = orc.synthetic_psf(1, H, W, C, seed=4)
+    y = rng.random((H, W, C), dtype=np.float32)
+    rec = lpa.ADMM(torch.from_numpy(psf), tau=2e-6, mu2=1e-4)
+    assert rec._padded_shape == [1, 5, 8192, 1]
+    rec.set_data(torch.from_numpy(y))
+    o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
+    o.set_data(y)
+    assert rel(rec.apply(n_iter=4, disp_iter=None), o.apply(4)) <= 5e-6
+    fis = lpa.FISTA(torch.from_numpy(psf))
+    fis.set_data(torch.from_numpy(y))
+    of = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
+    of.set_data(y)
+    assert rel(fis.apply(n_iter=4, disp_iter=None), of.apply(4)) <= 5e-6
+    cv = lpa.RealFFTConvolve2D(torch.from_numpy(psf), pad=True)
+    oc = orc.ConvolverOracle(psf, pad=True)
+    x = torch.from_numpy(rng.standard_normal((1, 1, H, W, C)).astype(np.float32))
+    assert rel(cv.convolve(x), oc.convolve(x)) <= 2e-6
+    assert rel(cv.deconvolve(x), oc.deconvolve(x)) <= 2e-6
+
+
+@pytest.mark.parametrize("static", [True, False], ids=["static_plan", "runtime_plan"])
+def test_6144_row_columns_static_plan(backend, monkeypatch, static):
+    """12 MP's COLUMN shape on a frame only 9 columns wide: 3072 rows pad to 6144 = 128 x 48, 16-column tiles -- pass A
+    (128 points = 8.8.2, forward and inverse) and ADMM's fused middle (48 points = 8.6 over both spectra) run on
+    compile-time plans; LPC_NO_STATIC is the same frame on the run-time plans."""
+    if not static:
+        monkeypatch.setenv("LPC_NO_STATIC", "1")
+    H, W, C = 3072, 9, 1
+    rng = np.random.default_rng(12)
+    psf = orc.synthetic_psf(1, H, W, C, seed=5)
+    y = rng.random((H, W, C), dtype=np.float32)
+    rec = lpa.ADMM(torch.from_numpy(psf), tau=2e-6, mu2=1e-4)
+    assert rec._padded_shape == [1, 6144, 18, 1]
+    rec.set_data(torch.from_numpy(y))
+    o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
+    o.set_data(y)
+    assert rel(rec.apply(n_iter=3, disp_iter=None), o.apply(3)) <= 5e-6
+    fis = lpa.FISTA(torch.from_numpy(psf))
+    fis.set_data(torch.from_numpy(y))
+    of = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
+    of.set_data(y)
+    assert rel(fis.apply(n_iter=3, disp_iter=None), of.apply(3)) <= 5e-6

@@ -3,7 +3,7 @@
 # environment knobs, one summary line each
 out=gpurun_out/$1; shift; mkdir -p $out
 export MPLBACKEND=Agg
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs"
+B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs $BENCH_ARGS"
 for spec in "$@"; do
   label=${spec%%:*}; envs=${spec#*:}
   echo -n "== $label [$envs] : "
