@@ -37,7 +37,8 @@ def build_hip(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     base = [hipcc, "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-x", "hip",
             "-I", os.path.join(ROOT, "include"), "-I", CSRC]
-    flavours = (("f32", OUT, []), ("f64", OUT_F64, ["-DLPC_DOUBLE"]))
+    extra_defs = os.environ.get("LPC_EXTRA_DEFS", "").split()    # e.g. -DLPC_DEBUG_KNOBS for timing experiments
+    flavours = (("f32", OUT, extra_defs), ("f64", OUT_F64, ["-DLPC_DOUBLE"] + extra_defs))
     jobs = []
     for tag, _, extra in flavours:
         for src in units():

@@ -14,12 +14,15 @@ int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1,
     cp.needn = g.H;
   }
   const dim3 grid(cp.G * cp.ntile_c, nplanes);
-  if (e->static_cols) {   // 128-point pass A, 16 columns per tile: 2048 points = 256 threads x 8
-    const size_t smem = (size_t)128 * 16 * sizeof(real2);
-    const SPlanArg<ColPlan128> pa = splan_arg<ColPlan128>(e->planA);
-    if (inverse) return launch_k(e, kid, k_cols<256, 8, true, SPlanArg<ColPlan128>, 16>, grid, 256, smem, g, pa, cp, S);
-    return launch_k(e, kid, k_cols<256, 8, false, SPlanArg<ColPlan128>, 16>, grid, 256, smem, g, pa, cp, S);
-  }
+  auto static_passA = [&](auto plan_tag) {     // 16 columns per tile; 128 x 16 = 256 x 8 points, 90 x 16 = 1440 <= 256 x 8
+    using P = decltype(plan_tag);
+    const size_t smem = (size_t)P::n * 16 * sizeof(real2);
+    const SPlanArg<P> pa = splan_arg<P>(e->planA);
+    if (inverse) return launch_k(e, kid, k_cols<256, 8, true, SPlanArg<P>, 16>, grid, 256, smem, g, pa, cp, S);
+    return launch_k(e, kid, k_cols<256, 8, false, SPlanArg<P>, 16>, grid, 256, smem, g, pa, cp, S);
+  };
+  if (e->static_passA == 128) return static_passA(ColPlan128{});
+  if (e->static_passA == 90) return static_passA(ColPlan90{});
   return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
     const size_t smem = (size_t)cp.N * cp.T * sizeof(real2);
@@ -98,7 +101,13 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
     // (profiles/r01b_notes.md): 24 points 0.89 ms and 32 points 0.83 ms beat the LDS middle (0.99 / 0.92 ms) but
     // need a 256- / 192-point pass A that costs more than it saves; 48 points is 1.62 ms (AGPR traffic).
     if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_admm_reg<8, 3>)); }
-    else if (e->static_cols) {   // 48-point middle, 2 x 16 tile columns: 1536 points = 256 threads x 6
+    else if (e->static_mid == 540) {   // C1 / C4: 540 points x 2 x 8 tile columns = 8640 points = 512 threads x 17
+      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<512, 18, SPlanArg<ColPlan540>, 16>, grid, 512,
+                      (size_t)540 * 16 * sizeof(real2), g, splan_arg<ColPlan540>(e->planB), cp, SA, SB,
+                      (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2,
+                      sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
+    }
+    else if (e->static_mid == 48) {   // 48-point middle, 2 x 16 tile columns: 1536 points = 256 threads x 6
       LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<256, 8, SPlanArg<ColPlan48>, 32>, grid, 256,
                       (size_t)48 * 32 * sizeof(real2), g, splan_arg<ColPlan48>(e->planB), cp, SA, SB,
                       (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2,

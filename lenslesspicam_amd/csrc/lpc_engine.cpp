@@ -199,8 +199,10 @@ static int setup_geometry(Engine* e) {
   e->rows_half = half_ok && wide && !std::getenv("LPC_ROWS_PAIRED");
   if (half_ok && std::getenv("LPC_ROWS_HALF")) e->rows_half = true;   // test knob: small frames too
   if (e->rows_half) LPC_OK(build_plan(e, e->planWh, g.Wp / 2));
-  if (e->rows_half && RowPlan4096::matches(e->planWh) && e->planWh.skew_ok && !std::getenv("LPC_NO_STATIC"))
-    e->static_rows = 4096;
+  if (e->rows_half && e->planWh.skew_ok && !std::getenv("LPC_NO_STATIC")) {
+    if (RowPlan4096::matches(e->planWh)) e->static_rows = 4096;
+    if (RowPlan1920::matches(e->planWh)) e->static_rows = 1920;
+  }
 
   // float4 lanes and half-length rows: r_sp and a are computed by the row workgroups themselves (float32 build)
   e->fuse_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && e->rows_half && g.Wp % 4 == 0 &&
@@ -208,8 +210,16 @@ static int setup_geometry(Engine* e) {
   LPC_OK(build_plan(e, e->planB, e->N2));
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
   e->static_sk = !std::getenv("LPC_ROWS_NOSKEW");
-  e->static_cols = e->N1 == 128 && e->N2 == 48 && e->T == 16 && ColPlan128::matches(e->planA) &&
-                   ColPlan48::matches(e->planB) && !std::getenv("LPC_NO_STATIC") && !std::getenv("LPC_NO_STATIC_COLS");
+  // 4096-point rows as 16.16.16: one radix-16 butterfly per thread and stage, one LDS round trip fewer than 8.8.8.8
+  // (same-box A/B, profiles/r02_notes.md: inverse rows 0.518 -> 0.487 ms, FISTA 412 -> 417 it/s); LPC_ROWS_R8 = the old plan
+  e->rows_r16 = std::getenv("LPC_ROWS_R8") == nullptr;
+  if (!std::getenv("LPC_NO_STATIC") && !std::getenv("LPC_NO_STATIC_COLS")) {
+    if (e->N1 > 1 && e->T == 16 && ColPlan128::matches(e->planA)) e->static_passA = 128;
+    if (e->N1 > 1 && e->T == 16 && ColPlan90::matches(e->planA)) e->static_passA = 90;
+    if (e->N1 > 1 && e->T == 16 && ColPlan48::matches(e->planB)) e->static_mid = 48;
+    if (e->N1 == 1 && e->T == 8 && ColPlan540::matches(e->planB)) e->static_mid = 540;
+    if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan960::matches(e->planW)) e->static_prow = 960;
+  }
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
   const int ntc = (g.Wc + e->T - 1) / e->T;
   ColPass& A = e->passA;

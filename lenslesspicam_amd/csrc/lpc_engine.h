@@ -80,7 +80,10 @@ struct lpc_engine {
   Fft1dPlan planWh{};   // length Wp/2: ADMM rows, one real row per half-length transform (rows_half)
   bool rows_half = false;
   bool static_sk = true;   // static-plan row kernels: LDS skew on (tuning knob LPC_ROWS_NOSKEW: 32 KiB tiles, 5 per CU)
-  bool static_cols = false;  // 128 x 48 split with T = 16 served by compile-time plans
+  int static_passA = 0;    // pass-A length served by a compile-time plan (128 | 90, 16-column tiles), else 0
+  int static_mid = 0;      // ADMM LDS-middle length served by a compile-time plan (48 with T = 16 | 540 with T = 8)
+  int static_prow = 0;     // ADMM PAIRED-row length served by a compile-time plan (960), else 0
+  bool rows_r16 = false;   // 4096-point rows as 16.16.16 instead of 8.8.8.8
   int static_rows = 0;     // length of the half-row transform when a compile-time plan serves it (lpc_sfft.h), else 0
   bool fuse_rows = false;  // ADMM: the image-domain kernel is fused into the forward row pass (k_admm_rows_fused)
   bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (LPC_MID_LDS=1: off)
@@ -225,12 +228,33 @@ static inline RealDst dst_cropped(const Engine* e, real* base) {
 // static-plan shapes (lpc_sfft.h).  4096 = 8.8.8.8: the half-row transform of 8192-column padded frames (12 MP)
 typedef SPlan<8, 8, 8, 8> RowPlan4096;
 typedef SPlanArg<RowPlan4096> RowArg4096;
+typedef SPlan<16, 16, 16> RowPlan4096r16;   // the same length in three radix-16 stages (one butterfly per thread and stage)
 // 12 MP's column split 6144 = 128 x 48 with 16-column tiles: pass A 128 = 8.8.2, fused middle 48 = 8.6
 typedef SPlan<8, 8, 2> ColPlan128;
 typedef SPlan<8, 6> ColPlan48;
+// 1080 x 1920 frames: 2160 = 90 x 24, pass A 90 = 6.5.3 (the 24-point middle lives in registers)
+typedef SPlan<6, 5, 3> ColPlan90;
+// DiffuserCam-sized frames (270 x 480 -> 540 x 960): single-pass 540-point columns = 6.6.5.3 over 2 x 8 tile columns,
+// paired rows of 960 = 8.8.5.3
+typedef SPlan<6, 6, 5, 3> ColPlan540;
+typedef SPlan<8, 8, 5, 3> RowPlan960;
+typedef SPlan<8, 8, 6, 5> RowPlan1920;      // half rows of 3840-column padded frames (1080 x 1920)
+// workgroup shape per static row plan: NT threads x EM points (the same table as dispatch_cfg)
+template <class P, int NT_, int EM_>
+struct RowShape { using plan = P; static constexpr int nt = NT_, em = EM_; };
+template <class F>
+static inline int with_row_shape(const lpc_engine* e, F&& f);
 template <class F>
 static inline int with_sk(bool sk, F&& f) {
   return sk ? f(std::integral_constant<bool, true>{}) : f(std::integral_constant<bool, false>{});
+}
+
+template <class F>
+static inline int with_row_shape(const lpc_engine* e, F&& f) {
+  if (e->static_rows == 4096 && e->rows_r16) return f(RowShape<RowPlan4096r16, 256, 16>{});
+  if (e->static_rows == 4096) return f(RowShape<RowPlan4096, 256, 16>{});
+  if (e->static_rows == 1920) return f(RowShape<RowPlan1920, 256, 8>{});
+  return fail("internal: no static row plan for this length");
 }
 
 // ---- host functions that cross translation units ------------------------------------------------------------

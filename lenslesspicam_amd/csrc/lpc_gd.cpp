@@ -6,12 +6,15 @@
 int gd_rows_mid(Engine* e) {
   const PlaneGeom& g = e->g;
   const int nblk = (g.H + 1) / 2;
-  if (e->rows_half && e->static_rows == 4096)
-    return with_sk(e->static_sk, [&](auto SKc) {
+  if (e->rows_half && e->static_rows)
+    return with_row_shape(e, [&](auto SHc) {
+      using SH = decltype(SHc);
+      return with_sk(e->static_sk, [&](auto SKc) {
       constexpr bool sk = decltype(SKc)::value;
-      return launch_k(e, LPC_K_ROW_INV, k_rinv_gd_mid_half<256, 16, sk, RowArg4096>, dim3(g.H, e->P), 256,
-                      LPC_ROW_SMEM_BYTES(4096, sk), g, splan_arg<RowPlan4096>(e->planWh), e->planW.tw,
-                    (const real2*)e->S, e->S2, (const real*)e->Y);
+        return launch_k(e, LPC_K_ROW_INV, k_rinv_gd_mid_half<SH::nt, SH::em, sk, SPlanArg<typename SH::plan>>, dim3(g.H, e->P), SH::nt,
+                        LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, splan_arg<typename SH::plan>(e->planWh), e->planW.tw,
+                      (const real2*)e->S, e->S2, (const real*)e->Y);
+      });
     });
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
@@ -35,12 +38,15 @@ int gd_rows_update(Engine* e, const GdScalars& sc, const real* alpha) {
   const PlaneGeom& g = e->g;
   const int nblk = (g.H + 1) / 2;
   const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
-  if (e->rows_half && e->static_rows == 4096)
-    return with_sk(e->static_sk, [&](auto SKc) {
+  if (e->rows_half && e->static_rows)
+    return with_row_shape(e, [&](auto SHc) {
+      using SH = decltype(SHc);
+      return with_sk(e->static_sk, [&](auto SKc) {
       constexpr bool sk = decltype(SKc)::value;
-      return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update_half<256, 16, sk, RowArg4096>, dim3(g.H, e->P), 256,
-                      LPC_ROW_SMEM_BYTES(4096, sk), g, splan_arg<RowPlan4096>(e->planWh), e->planW.tw,
-                    (const real2*)e->S2, e->gx, e->gaux, alpha, sc);
+        return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update_half<SH::nt, SH::em, sk, SPlanArg<typename SH::plan>>, dim3(g.H, e->P), SH::nt,
+                        LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, splan_arg<typename SH::plan>(e->planWh), e->planW.tw,
+                      (const real2*)e->S2, e->gx, e->gaux, alpha, sc);
+      });
     });
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {

@@ -154,8 +154,8 @@ static __device__ __forceinline__ void tangle_r2_load(real2* s, int Wp, const re
 }
 
 // ---- forward, ADMM: row r of array A and row r of array B -> spectra SA, SB ------------
-template <int NT, int EMAX, bool SK, bool R2>
-__global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
+template <int NT, int EMAX, bool SK, bool R2, class PL = Fft1dPlan>
+__global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, PL plan,
                                                      const real* LPC_RESTRICT A,
                                                      const real* LPC_RESTRICT B,
                                                      real2* LPC_RESTRICT SA,
@@ -167,8 +167,11 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, Fft1dPlan plan,
   const real* a = A + pl * g.rplane + (long)row * g.rpitch;
   const real* b = B + pl * g.rplane + (long)row * g.rpitch;
   auto src = [&](int i, int) { return make_real2(a[i], b[i]); };
-  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{}, NoFix{}, 0,
-                                             R2 ? 1 : 0);
+  if constexpr (is_static_plan<PL>::value)     // compile-time plans: no radix-2 folding (R2 == false)
+    fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
+  else
+    fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{}, NoFix{}, 0,
+                                               R2 ? 1 : 0);
   real2* oa = SA + pl * g.cplane + (long)row * g.cpitch;
   real2* ob = SB + pl * g.cplane + (long)row * g.cpitch;
   if (R2) untangle_r2_store<NT, SK>(s, g.Wp, plan.tw, oa, ob, true, tid);
@@ -312,8 +315,8 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows_half(PlaneGeom g, PL plan, con
 // ---- inverse, ADMM: spectra SA, SB -> real arrays A, B (no shift, padded) ---------------
 // R2: `plan` is the inverse-row plan whose FIRST stage is the radix-2 one (fused into the tangling); SK is
 // false in that case (the skew is not affine for ns = 2).
-template <int NT, int EMAX, bool SK, bool R2>
-__global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, Fft1dPlan plan,
+template <int NT, int EMAX, bool SK, bool R2, class PL = Fft1dPlan>
+__global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, PL plan,
                                                      const real2* LPC_RESTRICT SA,
                                                      const real2* LPC_RESTRICT SB,
                                                      real* LPC_RESTRICT A, real* LPC_RESTRICT B) {
@@ -329,8 +332,11 @@ __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, Fft1dPlan plan,
   real* a = A + pl * g.rplane + (long)row * g.rpitch;
   real* b = B + pl * g.rplane + (long)row * g.rpitch;
   auto out = [&](int i, int, real2 v) { a[i] = v.x; b[i] = v.y; };
-  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out, NoFix{},
-                                                  R2 ? 1 : 0, 0);
+  if constexpr (is_static_plan<PL>::value)
+    fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
+  else
+    fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out, NoFix{},
+                                                    R2 ? 1 : 0, 0);
 }
 
 // ---- inverse, generic: spectrum rows -> ONE real sink with ifftshift (+ crop) -----------
@@ -970,6 +976,33 @@ static __device__ __forceinline__ void tv_component(const AdmmScalars& p, float 
   q = p.mu2 * un - eta;
 }
 
+// ---- the same arithmetic, two pixels per operand (packed FP32 on gfx950, see v2f in lpc_rt.h) ----
+static __device__ __forceinline__ v2f div_by2(v2f x, float d, float r) {      // div_by, two quotients
+#if defined(LPC_SIMT_EMU)
+  (void)r;
+  return mk2(x.x / d, x.y / d);
+#else
+  const v2f rr = mk2(r, r);
+  const v2f q = x * rr;
+  const v2f e = fma2(mk2(-d, -d), q, x);
+  return fma2(e, rr, q);
+#endif
+}
+static __device__ __forceinline__ v2f soft_thresh2(v2f a, float thr) {
+  return mk2(soft_thresh_dev(a.x, thr), soft_thresh_dev(a.y, thr));
+}
+static __device__ __forceinline__ void tv_component2(const AdmmScalars& p, v2f vc, v2f vn, v2f oc, v2f on, v2f eta,
+                                                      v2f& eta_new, v2f& q) {
+  const v2f psi = vn - vc;
+  if (!p.first) {
+    const v2f uo = soft_thresh2((on - oc) + div_by2(eta, p.mu2p, p.r_mu2p), p.thrp);
+    eta = eta + p.mu2p * (psi - uo);
+  }
+  const v2f un = soft_thresh2(psi + div_by2(eta, p.mu2, p.r_mu2), p.thr);
+  eta_new = eta;
+  q = p.mu2 * un - eta;
+}
+
 template <int TH, int NT>
 __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars p,
                                                          const float* LPC_RESTRICT V,
@@ -1132,93 +1165,147 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
   const long poff = pl * g.rplane;
   const long o_row = poff + (long)gr * g.rpitch;
   const int n4 = g.Wp >> 2;
+#ifdef LPC_DEBUG_KNOBS   // timing experiments only: MINW == 3 skips the image-domain half (the tile is filled with junk)
+  if (MINW == 3) {
+    for (int q = tid; q < n4; q += NT) {
+      s[lds_slot<SK>(2 * q)] = make_real2((real)q, (real)tid);
+      s[lds_slot<SK>(2 * q + 1)] = make_real2((real)gr, (real)arr);
+    }
+  } else
+#endif
   if (arr == 0) {
     const long o_up = poff + (long)(gr == 0 ? g.Hp - 1 : gr - 1) * g.rpitch;
     const long o_dn = poff + (long)(gr + 1 == g.Hp ? 0 : gr + 1) * g.rpitch;
-#pragma unroll UNR
-    for (int q = tid; q < n4; q += NT) {
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // everything one float4 of the row needs from HBM / L2; PF > 1: the NEXT quad's loads are issued before this
+    // quad's arithmetic (the static-plan build of this kernel needs 70 VGPRs of a 128-VGPR budget: the spare registers
+    // buy a second set of loads in flight per wave)
+    struct Quad { float4 vm, vc, vp, om, oc, op, e0, e0d, e1, rho; float vl, vr, ol, orr, e1r; };
+    auto load_quad = [&](int q) {
+      Quad c;
       const int gc = 4 * q;
       const int cl = gc == 0 ? g.Wp - 1 : gc - 1, cr = gc + 4 == g.Wp ? 0 : gc + 4;
-      const float4 vm4 = ld4(V + o_up + gc), vc4 = ld4(V + o_row + gc), vp4 = ld4(V + o_dn + gc);
-      const float vl = V[o_row + cl], vr = V[o_row + cr];
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      float4 om4 = z4, oc4 = z4, op4 = z4;
-      float ol = 0.f, orr = 0.f;
+      c.vm = ld4(V + o_up + gc); c.vc = ld4(V + o_row + gc); c.vp = ld4(V + o_dn + gc);
+      c.vl = V[o_row + cl]; c.vr = V[o_row + cr];
+      c.om = z4; c.oc = z4; c.op = z4; c.ol = 0.f; c.orr = 0.f;
       if (!p.first) {
-        om4 = ld4(Vold + o_up + gc); oc4 = ld4(Vold + o_row + gc); op4 = ld4(Vold + o_dn + gc);
-        ol = Vold[o_row + cl]; orr = Vold[o_row + cr];
+        c.om = ld4(Vold + o_up + gc); c.oc = ld4(Vold + o_row + gc); c.op = ld4(Vold + o_dn + gc);
+        c.ol = Vold[o_row + cl]; c.orr = Vold[o_row + cr];
       }
-      const float4 e04 = ld4(eta0 + o_row + gc), e0d4 = ld4(eta0 + o_dn + gc), e14 = ld4(eta1 + o_row + gc);
-      const float e1r = eta1[o_row + cr];
-      const float4 rho4 = ld4(rho + o_row + gc);
-      float4 vwc4 = z4, vwo4 = z4;
-      if (VWc) vwc4 = ld4(VWc + o_row + gc);
-      if (VWo) vwo4 = ld4(VWo + o_row + gc);
+      c.e0 = ld4(eta0 + o_row + gc); c.e0d = ld4(eta0 + o_dn + gc); c.e1 = ld4(eta1 + o_row + gc);
+      c.e1r = eta1[o_row + cr];
+      c.rho = ld4(rho + o_row + gc);
+      return c;
+    };
+    auto do_quad = [&](const Quad& c, int q, auto vw_tag) {
+      constexpr bool VW = decltype(vw_tag)::value;
+      const int gc = 4 * q;
+      float4 vwc4 = z4, vwo4 = z4;      // only for the two iterations after a read-out clamped the estimate
+      if (VW && VWc) vwc4 = ld4(VWc + o_row + gc);
+      if (VW && VWo) vwo4 = ld4(VWo + o_row + gc);
       const float vwcs[4] = {vwc4.x, vwc4.y, vwc4.z, vwc4.w}, vwos[4] = {vwo4.x, vwo4.y, vwo4.z, vwo4.w};
-      const float vcs[6] = {vl, vc4.x, vc4.y, vc4.z, vc4.w, vr};       // cols gc-1 .. gc+4 of row gr
-      const float ocs[6] = {ol, oc4.x, oc4.y, oc4.z, oc4.w, orr};
-      const float vms[4] = {vm4.x, vm4.y, vm4.z, vm4.w}, vps[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
-      const float oms[4] = {om4.x, om4.y, om4.z, om4.w}, ops[4] = {op4.x, op4.y, op4.z, op4.w};
-      const float rhs[4] = {rho4.x, rho4.y, rho4.z, rho4.w};
-      const float e0s[4] = {e04.x, e04.y, e04.z, e04.w}, e0ds[4] = {e0d4.x, e0d4.y, e0d4.z, e0d4.w};
-      const float e1s[5] = {e14.x, e14.y, e14.z, e14.w, e1r};
-      float q1[5], e1n[5];
+      const float vcs[6] = {c.vl, c.vc.x, c.vc.y, c.vc.z, c.vc.w, c.vr};       // cols gc-1 .. gc+4 of row gr
+      const float ocs[6] = {c.ol, c.oc.x, c.oc.y, c.oc.z, c.oc.w, c.orr};
+      const float vms[4] = {c.vm.x, c.vm.y, c.vm.z, c.vm.w}, vps[4] = {c.vp.x, c.vp.y, c.vp.z, c.vp.w};
+      const float oms[4] = {c.om.x, c.om.y, c.om.z, c.om.w}, ops[4] = {c.op.x, c.op.y, c.op.z, c.op.w};
+      const float rhs[4] = {c.rho.x, c.rho.y, c.rho.z, c.rho.w};
+      const float e0s[4] = {c.e0.x, c.e0.y, c.e0.z, c.e0.w}, e0ds[4] = {c.e0d.x, c.e0d.y, c.e0d.z, c.e0d.w};
+      const float e1s[5] = {c.e1.x, c.e1.y, c.e1.z, c.e1.w, c.e1r};
+      // two pixels per operand: pairs (0,1) and (2,3) of the quad; the 5th column difference (needed only for q) alone
+      float q1[5], e1n[5], e0n[4], rhn[4], rs[4];
 #pragma unroll
-      for (int i = 0; i < 5; ++i)   // column-difference component at cols gc .. gc+4 (the 5th only for q)
-        tv_component(p, vcs[i + 1], vcs[i], ocs[i + 1], ocs[i], e1s[i], e1n[i], q1[i]);
-      float e0n[4], rhn[4], rs[4];
+      for (int h = 0; h < 2; ++h) {
+        const int i = 2 * h;
+        v2f en, qq;
+        tv_component2(p, mk2(vcs[i + 1], vcs[i + 2]), mk2(vcs[i], vcs[i + 1]), mk2(ocs[i + 1], ocs[i + 2]),
+                      mk2(ocs[i], ocs[i + 1]), mk2(e1s[i], e1s[i + 1]), en, qq);               // column differences
+        e1n[i] = en.x; e1n[i + 1] = en.y; q1[i] = qq.x; q1[i + 1] = qq.y;
+      }
+      tv_component(p, vcs[5], vcs[4], ocs[5], ocs[4], e1s[4], e1n[4], q1[4]);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        float q0c, q0d, dummy;
-        tv_component(p, vcs[i + 1], vms[i], ocs[i + 1], oms[i], e0s[i], e0n[i], q0c);   // this pixel
-        tv_component(p, vps[i], vcs[i + 1], ops[i], ocs[i + 1], e0ds[i], dummy, q0d);   // the pixel below
-        const float vc = vcs[i + 1];
-        float rhov = rhs[i];
+      for (int h = 0; h < 2; ++h) {
+        const int i = 2 * h;
+        const v2f vc2 = mk2(vcs[i + 1], vcs[i + 2]), oc2 = mk2(ocs[i + 1], ocs[i + 2]);
+        v2f en, q0c, q0d, dummy;
+        tv_component2(p, vc2, mk2(vms[i], vms[i + 1]), oc2, mk2(oms[i], oms[i + 1]), mk2(e0s[i], e0s[i + 1]), en,
+                      q0c);                                                                        // these pixels
+        tv_component2(p, mk2(vps[i], vps[i + 1]), vc2, mk2(ops[i], ops[i + 1]), oc2, mk2(e0ds[i], e0ds[i + 1]),
+                      dummy, q0d);                                                                 // the pixels below
+        e0n[i] = en.x; e0n[i + 1] = en.y;
+        v2f rhov = mk2(rhs[i], rhs[i + 1]);
         if (!p.first) {
-          const float wo = fmaxf(div_by(rhov, p.mu3p, p.r_mu3p) + (VWo ? vwos[i] : ocs[i + 1]), 0.f);
-          rhov = rhov + p.mu3p * (vc - wo);
+          const v2f vo2 = (VW && VWo) ? mk2(vwos[i], vwos[i + 1]) : oc2;
+          const v2f t = div_by2(rhov, p.mu3p, p.r_mu3p) + vo2;
+          const v2f wo = mk2(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f));
+          rhov = rhov + p.mu3p * (vc2 - wo);
         }
-        const float wn = fmaxf(div_by(rhov, p.mu3, p.r_mu3) + (VWc ? vwcs[i] : vc), 0.f);
-        const float d1 = q0d - q0c;
-        const float d2 = q1[i + 1] - q1[i];
-        rhn[i] = rhov;
-        rs[i] = (p.mu3 * wn - rhov) + (d1 + d2);
+        const v2f vw2 = (VW && VWc) ? mk2(vwcs[i], vwcs[i + 1]) : vc2;
+        const v2f t = div_by2(rhov, p.mu3, p.r_mu3) + vw2;
+        const v2f wn = mk2(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f));
+        const v2f d1 = q0d - q0c;
+        const v2f d2 = mk2(q1[i + 1], q1[i + 2]) - mk2(q1[i], q1[i + 1]);
+        const v2f r2 = (p.mu3 * wn - rhov) + (d1 + d2);
+        rhn[i] = rhov.x; rhn[i + 1] = rhov.y;
+        rs[i] = r2.x; rs[i + 1] = r2.y;
       }
       st4(rho + o_row + gc, make_float4(rhn[0], rhn[1], rhn[2], rhn[3]));
       st4(eta0_out + o_row + gc, make_float4(e0n[0], e0n[1], e0n[2], e0n[3]));
       st4(eta1_out + o_row + gc, make_float4(e1n[0], e1n[1], e1n[2], e1n[3]));
       s[lds_slot<SK>(2 * q)] = make_real2(rs[0], rs[1]);          // z[j] = (x[2j], x[2j+1])
       s[lds_slot<SK>(2 * q + 1)] = make_real2(rs[2], rs[3]);
+    };
+    // Measured on MI355X (profiles/r02_notes.md): issuing the next quad's loads ahead of this quad's arithmetic (whole
+    // quad: 176 VGPRs, 2 workgroups per CU; first-touch rows only: 142 VGPRs) is SLOWER than this plain loop at 70
+    // VGPRs and 4 workgroups per CU (1.84 vs 2.21 / 1.98 ms): the kernel is bound by instruction issue (VALU 38 %,
+    // all instructions 55 % of every SIMD cycle, PMC), not by exposed latency.
+    if (!VWc && !VWo) {
+#pragma unroll 1
+      for (int q = tid; q < n4; q += NT) do_quad(load_quad(q), q, std::false_type{});
+    } else {
+#pragma unroll 1
+      for (int q = tid; q < n4; q += NT) do_quad(load_quad(q), q, std::true_type{});
     }
   } else {
     const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
     const bool row_in = (gr >= g.sh) && (gr < g.sh + g.H);
     const float* y = Y + (long)dpl * g.uplane + (long)(gr - g.sh) * g.W;     // dereferenced only when row_in
     const bool y4 = ((g.sw | g.W) & 3) == 0;                                 // window and pitch allow float4 loads of y
-#pragma unroll UNR
-    for (int q = tid; q < n4; q += NT) {
+    struct QuadX { float4 hv, xi, ho; float ys[4]; bool ins[4]; };
+    auto load_quadx = [&](int q) {
+      QuadX c;
       const int gc = 4 * q;
-      const float4 hv4 = ld4(HV + o_row + gc), xi4 = ld4(xi + o_row + gc);
-      float4 ho4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!p.first) ho4 = ld4(HVold + o_row + gc);
-      float ys[4] = {0.f, 0.f, 0.f, 0.f};
-      bool ins[4] = {false, false, false, false};
+      c.hv = ld4(HV + o_row + gc); c.xi = ld4(xi + o_row + gc);
+      c.ho = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!p.first) c.ho = ld4(HVold + o_row + gc);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { c.ys[i] = 0.f; c.ins[i] = false; }
       if (row_in) {
         if (y4) {
           if (gc >= g.sw && gc < g.sw + g.W) {
             const float4 yv = ld4(y + (gc - g.sw));
-            ys[0] = yv.x; ys[1] = yv.y; ys[2] = yv.z; ys[3] = yv.w;
-            ins[0] = ins[1] = ins[2] = ins[3] = true;
+            c.ys[0] = yv.x; c.ys[1] = yv.y; c.ys[2] = yv.z; c.ys[3] = yv.w;
+            c.ins[0] = c.ins[1] = c.ins[2] = c.ins[3] = true;
           }
         } else {
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
             const int cc = gc + i;
-            ins[i] = (cc >= g.sw) && (cc < g.sw + g.W);
-            if (ins[i]) ys[i] = y[cc - g.sw];
+            c.ins[i] = (cc >= g.sw) && (cc < g.sw + g.W);
+            if (c.ins[i]) c.ys[i] = y[cc - g.sw];
           }
         }
       }
+      return c;
+    };
+    QuadX nxt = load_quadx(tid < n4 ? tid : 0);
+#pragma unroll 1
+    for (int q = tid; q < n4; q += NT) {
+      const int gc = 4 * q;
+      const QuadX c = nxt;
+      if (q + NT < n4) nxt = load_quadx(q + NT);
+      const float4 hv4 = c.hv, xi4 = c.xi, ho4 = c.ho;
+      const float* ys = c.ys;
+      const bool* ins = c.ins;
       const float hvs[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, xis[4] = {xi4.x, xi4.y, xi4.z, xi4.w};
       const float hos[4] = {ho4.x, ho4.y, ho4.z, ho4.w};
       float xin[4], as[4];
@@ -1240,6 +1327,9 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
     }
   }
   __syncthreads();
+#ifdef LPC_DEBUG_KNOBS   // timing experiments only (results are garbage): MINW == 2 skips the butterflies
+  if (MINW != 2)
+#endif
   fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
   untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, (arr ? SB : SA) + pl * g.cplane + (long)gr * g.cpitch, tid);
 }

@@ -5,11 +5,14 @@
 // forward rows of ONE real source (pairs of rows) into spectrum S (planes = nplanes)
 int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
-  if (e->rows_half && e->static_rows == 4096)
-    return with_sk(e->static_sk, [&](auto SKc) {
+  if (e->rows_half && e->static_rows)
+    return with_row_shape(e, [&](auto SHc) {
+      using SH = decltype(SHc);
+      return with_sk(e->static_sk, [&](auto SKc) {
       constexpr bool sk = decltype(SKc)::value;
-      return launch_k(e, kid, k_rfwd_rows_half<256, 16, sk, RowArg4096>, dim3(src.nrows, nplanes), 256,
-                      LPC_ROW_SMEM_BYTES(4096, sk), g, splan_arg<RowPlan4096>(e->planWh), e->planW.tw, src, S);
+        return launch_k(e, kid, k_rfwd_rows_half<SH::nt, SH::em, sk, SPlanArg<typename SH::plan>>, dim3(src.nrows, nplanes), SH::nt,
+                        LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, splan_arg<typename SH::plan>(e->planWh), e->planW.tw, src, S);
+      });
     });
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NT, auto EM, auto SK, auto) {
@@ -29,11 +32,14 @@ int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int ki
 
 int rows_inv_single(Engine* e, const real2* S, const RealDst& dst, int nplanes, int kid) {
   const PlaneGeom& g = e->g;
-  if (e->rows_half && e->static_rows == 4096)
-    return with_sk(e->static_sk, [&](auto SKc) {
+  if (e->rows_half && e->static_rows)
+    return with_row_shape(e, [&](auto SHc) {
+      using SH = decltype(SHc);
+      return with_sk(e->static_sk, [&](auto SKc) {
       constexpr bool sk = decltype(SKc)::value;
-      return launch_k(e, kid, k_rinv_rows_half<256, 16, sk, RowArg4096>, dim3(dst.nrows, nplanes), 256,
-                      LPC_ROW_SMEM_BYTES(4096, sk), g, splan_arg<RowPlan4096>(e->planWh), e->planW.tw, S, dst);
+        return launch_k(e, kid, k_rinv_rows_half<SH::nt, SH::em, sk, SPlanArg<typename SH::plan>>, dim3(dst.nrows, nplanes), SH::nt,
+                        LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, splan_arg<typename SH::plan>(e->planWh), e->planW.tw, S, dst);
+      });
     });
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NT, auto EM, auto SK, auto) {
@@ -57,12 +63,15 @@ int admm_rows_fwd(Engine* e) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
-  if (e->rows_half && e->static_rows == 4096)
-    return with_sk(e->static_sk, [&](auto SKc) {
+  if (e->rows_half && e->static_rows)
+    return with_row_shape(e, [&](auto SHc) {
+      using SH = decltype(SHc);
+      return with_sk(e->static_sk, [&](auto SKc) {
       constexpr bool sk = decltype(SKc)::value;
-      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_half<256, 16, sk, RowArg4096>, dim3(2 * g.Hp, e->P), 256,
-                      LPC_ROW_SMEM_BYTES(4096, sk), g, splan_arg<RowPlan4096>(e->planWh), e->planW.tw,
-                    (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
+        return launch_k(e, LPC_K_ROW_FWD, k_rfwd_half<SH::nt, SH::em, sk, SPlanArg<typename SH::plan>>, dim3(2 * g.Hp, e->P), SH::nt,
+                        LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, splan_arg<typename SH::plan>(e->planWh), e->planW.tw,
+                      (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
+      });
     });
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
@@ -72,6 +81,10 @@ int admm_rows_fwd(Engine* e) {
                       LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real*)e->Rsp,
                       (const real*)e->Aarr, SA, SB);
     });
+  if (e->static_prow == 960)     // C1 / C4: paired rows of 960 points = 256 threads x 4 (3.75)
+    return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<256, 4, true, false, SPlanArg<RowPlan960>>, dim3(g.Hp, e->P), 256,
+                    LPC_ROW_SMEM_BYTES(960, true), g, splan_arg<RowPlan960>(e->planW), (const real*)e->Rsp,
+                    (const real*)e->Aarr, SA, SB);
   return dispatch_row(g.Wp, e->planW.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
     constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
     constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
@@ -91,16 +104,28 @@ int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real
   real2* SB = e->S + (size_t)e->P * g.cplane;
   static int unr = -1;     // tuning knob: chunks of a row in flight per thread (12-MP shape only)
   if (unr < 0) unr = std::getenv("LPC_FUSED_UNROLL") ? atoi(std::getenv("LPC_FUSED_UNROLL")) : 1;
-  if (e->static_rows == 4096 && !std::getenv("LPC_FUSED_OCC5") && !std::getenv("LPC_FUSED_UNROLL"))
-    return with_sk(e->static_sk, [&](auto SKc) {
-      constexpr bool sk = decltype(SKc)::value;
-      return launch_k(e, LPC_K_SPATIAL, k_admm_rows_fused<256, 16, sk, 1, 1, RowArg4096>, dim3(2 * g.Hp, e->P), 256,
-                      LPC_ROW_SMEM_BYTES(4096, sk), g, sc, splan_arg<RowPlan4096>(e->planWh), (const real2*)e->planW.tw,
-                    Vc, Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi,
-                    (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
-                    e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB,
-                    (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr));
+  if (e->static_rows && !std::getenv("LPC_FUSED_OCC5") && !std::getenv("LPC_FUSED_UNROLL")) {
+    return with_row_shape(e, [&](auto SHc) {
+      using SH = decltype(SHc);
+      using PA = SPlanArg<typename SH::plan>;
+      return with_sk(e->static_sk, [&](auto SKc) {
+        constexpr bool sk = decltype(SKc)::value;
+        auto go = [&](auto kernel) {
+          return launch_k(e, LPC_K_SPATIAL, kernel, dim3(2 * g.Hp, e->P), SH::nt, LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g,
+                          sc, splan_arg<typename SH::plan>(e->planWh), (const real2*)e->planW.tw, Vc, Vo,
+                          (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi,
+                          (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
+                          e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB,
+                          (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr));
+        };
+#ifdef LPC_DEBUG_KNOBS
+        if (std::getenv("LPC_DEBUG_FUSED_NOFFT")) return go(k_admm_rows_fused<SH::nt, SH::em, sk, 1, 2, PA>);
+        if (std::getenv("LPC_DEBUG_FUSED_NOSPATIAL")) return go(k_admm_rows_fused<SH::nt, SH::em, sk, 1, 3, PA>);
+#endif
+        return go(k_admm_rows_fused<SH::nt, SH::em, sk, 1, 1, PA>);
+      });
     });
+  }
   static int occ5 = -1;    // tuning knob: un-skewed 32 KiB tile + 96-VGPR budget = 5 workgroups per CU (12-MP shape only)
   if (occ5 < 0) occ5 = std::getenv("LPC_FUSED_OCC5") ? 1 : 0;
   if (occ5 && g.Wp == 8192)
@@ -136,12 +161,15 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout) {
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
-  if (e->rows_half && e->static_rows == 4096)
-    return with_sk(e->static_sk, [&](auto SKc) {
+  if (e->rows_half && e->static_rows)
+    return with_row_shape(e, [&](auto SHc) {
+      using SH = decltype(SHc);
+      return with_sk(e->static_sk, [&](auto SKc) {
       constexpr bool sk = decltype(SKc)::value;
-      return launch_k(e, LPC_K_ROW_INV, k_rinv_half<256, 16, sk, RowArg4096>, dim3(2 * g.Hp, e->P), 256,
-                      LPC_ROW_SMEM_BYTES(4096, sk), g, splan_arg<RowPlan4096>(e->planWh), e->planW.tw,
-                    (const real2*)SA, (const real2*)SB, Vout, HVout);
+        return launch_k(e, LPC_K_ROW_INV, k_rinv_half<SH::nt, SH::em, sk, SPlanArg<typename SH::plan>>, dim3(2 * g.Hp, e->P), SH::nt,
+                        LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, splan_arg<typename SH::plan>(e->planWh), e->planW.tw,
+                      (const real2*)SA, (const real2*)SB, Vout, HVout);
+      });
     });
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
@@ -151,6 +179,10 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout) {
                       LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real2*)SA,
                       (const real2*)SB, Vout, HVout);
     });
+  if (e->static_prow == 960)
+    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<256, 4, true, false, SPlanArg<RowPlan960>>, dim3(g.Hp, e->P), 256,
+                    LPC_ROW_SMEM_BYTES(960, true), g, splan_arg<RowPlan960>(e->planW), (const real2*)SA, (const real2*)SB,
+                    Vout, HVout);
   return dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
     constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
     constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;

@@ -145,6 +145,25 @@ static __host__ __device__ __forceinline__ real rabs(real a) { return fabsf(a); 
 static __host__ __device__ __forceinline__ real rsqrt_of(real a) { return sqrtf(a); }
 #endif
 
+// ------------------------------------------------------------ two-wide float math --
+// v2f: two independent float values per operand.  On gfx950 `+ - *` and fma2() on this type become v_pk_add_f32 /
+// v_pk_mul_f32 / v_pk_fma_f32 -- two results per VALU issue slot, which matters where a kernel is bound by instruction
+// issue (the image-domain half of the fused ADMM row kernel: 4 independent pixels per lane).  The emulator build
+// uses a plain struct.
+#if defined(LPC_SIMT_EMU)
+struct v2f { float x, y; };
+static inline v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+static inline v2f operator+(v2f a, v2f b) { return mk2(a.x + b.x, a.y + b.y); }
+static inline v2f operator-(v2f a, v2f b) { return mk2(a.x - b.x, a.y - b.y); }
+static inline v2f operator*(v2f a, v2f b) { return mk2(a.x * b.x, a.y * b.y); }
+static inline v2f operator*(float a, v2f b) { return mk2(a * b.x, a * b.y); }
+static inline v2f fma2(v2f a, v2f b, v2f c) { return mk2(std::fma(a.x, b.x, c.x), std::fma(a.y, b.y, c.y)); }
+#else
+typedef float v2f __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.y = b; return r; }
+static __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+#endif
+
 // ------------------------------------------------------------ small helpers --
 static __host__ __device__ __forceinline__ real2 cmul(real2 a, real2 b) {
   return make_real2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);

@@ -393,3 +393,34 @@ def test_6144_row_columns_static_plan(backend, monkeypatch, static):
     of = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
     of.set_data(y)
     assert rel(fis.apply(n_iter=3, disp_iter=None), of.apply(3)) <= 5e-6
+
+
+def _admm_fista_vs_oracle(H, W, C, padded, n_admm=3, n_fista=3, seed=13, tol=5e-6):
+    rng = np.random.default_rng(seed)
+    psf = orc.synthetic_psf(1, H, W, C, seed=seed)
+    y = rng.random((H, W, C), dtype=np.float32)
+    rec = lpa.ADMM(torch.from_numpy(psf), tau=2e-6, mu2=1e-4)
+    assert rec._padded_shape[1:3] == list(padded)
+    rec.set_data(torch.from_numpy(y))
+    o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
+    o.set_data(y)
+    assert rel(rec.apply(n_iter=n_admm, disp_iter=None), o.apply(n_admm)) <= tol
+    fis = lpa.FISTA(torch.from_numpy(psf))
+    fis.set_data(torch.from_numpy(y))
+    of = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
+    of.set_data(y)
+    assert rel(fis.apply(n_iter=n_fista, disp_iter=None), of.apply(n_fista)) <= tol
+
+
+@pytest.mark.parametrize("static", [True, False], ids=["static_plan", "runtime_plan"])
+@pytest.mark.parametrize("shape,padded", [((3, 1920, 1), (5, 3840)), ((1080, 9, 1), (2160, 18)),
+                                          ((270, 480, 1), (540, 960))],
+                         ids=["rows1920", "cols90x24", "c1_540x960"])
+def test_other_baseline_shapes_static_plans(backend, monkeypatch, static, shape, padded):
+    """The remaining BASELINE shapes with compile-time plans, each on a frame that keeps the emulator fast:
+    1080p's half rows (1920 = 8.8.6.5; ADMM through the fused image-domain + row kernel), its column split
+    2160 = 90 x 24 (pass A 90 = 6.5.3 + the register-resident 24-point middle), and the DiffuserCam-sized frame of
+    C1 / C4 in full (single-pass 540-point ADMM middle = 6.6.5.3 over 2 x 8 tile columns, paired 960-point rows)."""
+    if not static:
+        monkeypatch.setenv("LPC_NO_STATIC", "1")
+    _admm_fista_vs_oracle(*shape, padded, n_admm=2 if shape[0] == 270 else 3, n_fista=2 if shape[0] == 270 else 3)

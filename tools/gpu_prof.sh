@@ -6,10 +6,10 @@ out=$PWD/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 B="python $PWD/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-other-configs --n-iter 4 $@"
 cd /tmp
-rocprofv3 --kernel-trace --stats -d $out/prof_stats -o stats -- $B > $out/prof_stats.log 2>&1
-rocprofv3 --pmc FETCH_SIZE -d $out/prof_fetch -o c -- $B > $out/prof_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE -d $out/prof_write -o c -- $B > $out/prof_write.log 2>&1
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -d $out/prof_sq -o c -- $B > $out/prof_sq.log 2>&1
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum -d $out/prof_l2 -o c -- $B > $out/prof_l2.log 2>&1
+rocprofv3 --kernel-trace --stats -f csv -d $out/prof_stats -o stats -- $B > $out/prof_stats.log 2>&1
+rocprofv3 -f csv --pmc FETCH_SIZE -d $out/prof_fetch -o c -- $B > $out/prof_fetch.log 2>&1
+rocprofv3 -f csv --pmc WRITE_SIZE -d $out/prof_write -o c -- $B > $out/prof_write.log 2>&1
+rocprofv3 -f csv --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT -d $out/prof_sq -o c -- $B > $out/prof_sq.log 2>&1
+rocprofv3 -f csv --pmc TCC_HIT_sum TCC_MISS_sum -d $out/prof_l2 -o c -- $B > $out/prof_l2.log 2>&1
 cd - > /dev/null
 ls $out

@@ -26,14 +26,15 @@ def short(name):
     return n.split("(")[0]
 
 
-stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv"))
+stats = glob.glob(os.path.join(src, "prof_stats", "*", "*_kernel_stats.csv")) + \
+    glob.glob(os.path.join(src, "prof_stats", "*_kernel_stats.csv"))
 if stats:
     shutil.copy(stats[0], os.path.join(out, f"{tag}_kernel_stats.csv"))
 
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 meta = {}
 for d in sorted(glob.glob(os.path.join(src, "prof_*"))):
-    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")):
+    for f in glob.glob(os.path.join(d, "*", "*_counter_collection.csv")) + glob.glob(os.path.join(d, "*_counter_collection.csv")):
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
