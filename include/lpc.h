@@ -193,6 +193,14 @@ int lpc_preprocess_frames(const lpc_prep_config* cfg, const void* dev_raw, int n
 int lpc_preprocess_psf(const lpc_prep_config* cfg, const void* dev_raw, int depth, lpc_real* dev_psf_out,
                        lpc_real* dev_bg_out, void* stream);
 
+/* resize (lensless/utils/image.py:28-80, the torch branch): anti-aliased bilinear resampling of n channels-last images
+ * (n,H,W,C) -> (n,Hout,Wout,C), last axis first, result clipped to the input's [min, max].  This is what
+ * load_psf(downsample=...) / load_data's "resize the frame to the PSF" do through torchvision's
+ * Resize(size, antialias=True) = torch.nn.functional.interpolate(mode="bilinear", antialias=True).  Handle-free,
+ * asynchronous on `stream`. */
+int lpc_resize_aa(const lpc_real* dev_in, int n, int H, int W, int C, int Hout, int Wout, lpc_real* dev_out,
+                  void* stream);
+
 /* ---- measurement support (bench.py roofline leg) ----------------------------------- */
 enum lpc_kernel_id {
   LPC_K_SPATIAL = 0,   /* fused prox/update kernel (ADMM) / fused update (GD family)  */

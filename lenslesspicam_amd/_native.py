@@ -98,6 +98,7 @@ class Lib:
             "lpc_image_metrics": [fp, fp, C.c_long, C.c_int, C.c_int, fp, vp],
             "lpc_preprocess_frames": [C.POINTER(PrepConfig), vp, C.c_int, fp, fp, vp],
             "lpc_preprocess_psf": [C.POINTER(PrepConfig), vp, C.c_int, fp, fp, vp],
+            "lpc_resize_aa": [fp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, fp, vp],
         }
         for name, args in sig.items():
             fn = getattr(d, name)
@@ -126,6 +127,9 @@ class Lib:
 
     def preprocess_psf(self, cfg: PrepConfig, raw_ptr, depth, psf_ptr, bg_ptr, stream=0):
         self.check(self.dll.lpc_preprocess_psf(C.byref(cfg), raw_ptr, int(depth), psf_ptr, bg_ptr, stream))
+
+    def resize_aa(self, in_ptr, n, H, W, Cn, Hout, Wout, out_ptr, stream=0):
+        self.check(self.dll.lpc_resize_aa(in_ptr, int(n), int(H), int(W), int(Cn), int(Hout), int(Wout), out_ptr, stream))
 
     def create(self, **kw) -> "Handle":
         cfg = Config()

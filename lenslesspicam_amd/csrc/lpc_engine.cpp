@@ -976,6 +976,31 @@ int lpc_preprocess_psf(const lpc_prep_config* cfg, const void* dev_raw, int dept
   return rc;
 }
 
+int lpc_resize_aa(const real* dev_in, int n, int H, int W, int C, int Hout, int Wout, real* dev_out, void* stream) {
+  if (!dev_in || !dev_out) return fail("lpc_resize_aa: null argument");
+  if (n < 1 || H < 1 || W < 1 || C < 1 || Hout < 1 || Wout < 1) return fail("lpc_resize_aa: bad size");
+  Engine tmp;
+  tmp.stream = (lpcStream_t)stream;
+  Engine* e = &tmp;
+  const long nin = (long)n * H * W * C;
+  const int nblk = (int)std::max<long>(1, std::min<long>(1024, nin / 4096));
+  void* scratch = nullptr;        // [n][H][Wout][C] intermediate, then 2 * nblk partials and the (max, min) pair
+  const size_t mid = (size_t)n * H * Wout * C;
+  LPC_RT(rt::dev_malloc_async(&scratch, (mid + 2 * (size_t)nblk + 2) * sizeof(real), e->stream));
+  real* tmpbuf = (real*)scratch;
+  real* part = tmpbuf + mid;
+  real* rng = part + 2 * (size_t)nblk;
+  int rc = launch_k(e, -1, k_flat_minmax<256>, dim3(nblk, 1), 256, 2 * 256 * sizeof(real), dev_in, nin, part);
+  if (!rc) rc = launch_k(e, -1, k_flat_range, dim3(1), 64, 0, (const real*)part, nblk, 1, rng);
+  // image.py:59-64: the last spatial axis first (aten's separable kernel), then the rows
+  if (!rc) rc = launch_k(e, -1, k_resize_aa_axis<256>, grid1d((long)mid, 256), 256, 0, dev_in, tmpbuf, (long)n * H, W, Wout,
+                         (long)C, (const real*)nullptr);
+  if (!rc) rc = launch_k(e, -1, k_resize_aa_axis<256>, grid1d((long)n * Hout * Wout * C, 256), 256, 0, (const real*)tmpbuf,
+                         dev_out, (long)n, H, Hout, (long)Wout * C, (const real*)rng);
+  (void)rt::dev_free_async(scratch, e->stream);
+  return rc;
+}
+
 int lpc_profile_enable(lpc_handle e, int on) {
   if (!e) return fail("null handle");
 #if !defined(LPC_SIMT_EMU)

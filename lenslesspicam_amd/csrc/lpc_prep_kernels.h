@@ -228,3 +228,40 @@ __global__ __launch_bounds__(NT) void k_prep_psf(PrepGeom g, const void* LPC_RES
     }
   }
 }
+
+// ---- resize: lensless/utils/image.py:28-80 (torch branch) ----------------------------------------------------
+// Anti-aliased bilinear resampling, separable, last spatial axis first -- what torchvision's
+// Resize(size, antialias=True) computes through torch.nn.functional.interpolate (aten UpSampleKernel.cpp; restated
+// and pinned in oracle/preprocess_oracle.py).  One axis per launch: the array is viewed as (outer, L_in, inner) and
+// written as (outer, L_out, inner); each thread owns one output value and forms its <= 2*ceil(support)+1 normalised
+// triangle weights on the fly (downsample 4: 9 taps).  `rng` (max, min of the INPUT) != NULL: clip on the way out
+// (image.py:80).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_resize_aa_axis(const real* LPC_RESTRICT src, real* LPC_RESTRICT dst, long outer,
+                                                        int Lin, int Lout, long inner, const real* LPC_RESTRICT rng) {
+  const long total = outer * Lout * inner;
+  const real scale = (real)Lin / (real)Lout;
+  const real support = scale >= (real)1. ? scale : (real)1.;
+  const real inv = scale >= (real)1. ? (real)1. / scale : (real)1.;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < total; e += (long)gridDim.x * NT) {
+    const long in_ = e % inner;
+    const long t = e / inner;
+    const int i = (int)(t % Lout);
+    const long o = t / Lout;
+    const real center = scale * ((real)i + (real)0.5);
+    int xmin = (int)(center - support + (real)0.5);
+    xmin = xmin < 0 ? 0 : xmin;
+    int xmax = (int)(center + support + (real)0.5);
+    xmax = xmax > Lin ? Lin : xmax;
+    real tot = (real)0.;
+    for (int j = xmin; j < xmax; ++j) tot += rmax((real)0., (real)1. - rabs(((real)j - center + (real)0.5) * inv));
+    const real* sp = src + (o * Lin) * inner + in_;
+    real acc = (real)0.;
+    for (int j = xmin; j < xmax; ++j) {
+      const real w = rmax((real)0., (real)1. - rabs(((real)j - center + (real)0.5) * inv)) / tot;
+      acc = j == xmin ? sp[(long)j * inner] * w : acc + sp[(long)j * inner] * w;
+    }
+    if (rng) acc = rmin(rmax(acc, rng[1]), rng[0]);
+    dst[e] = acc;
+  }
+}

@@ -129,6 +129,30 @@ def preprocess_data(raw_psf, raw_data, bg_pix=(5, 25), flip=False, flip_ud=False
     return (psf, data, bg) if return_bg else (psf, data)
 
 
+def resize(img, factor=None, shape=None, dtype=None):
+    """``lensless.utils.image.resize`` (image.py:28-80), the branch the reference takes when torch is installed:
+    anti-aliased bilinear resampling (torchvision ``Resize(size, antialias=True)``), then a clip to the input's range.
+    ``img``: channels-last (..., H, W, C) array or tensor; returns a device tensor of the same rank.  Runs on the
+    device (``lpc_resize_aa``).  Parity: pinned against ``torch.nn.functional.interpolate(antialias=True)`` -- the
+    function torchvision calls -- because torchvision / cv2 are absent here."""
+    assert not (factor is None and shape is None), "Must specify either factor or shape"
+    t = img if isinstance(img, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(img))
+    if dtype is None:
+        dtype = "float64" if t.dtype == torch.float64 else "float32"
+    lib, dev = _recon.runtime(dtype)
+    tdt = torch.float64 if dtype == "float64" else torch.float32
+    t = t.detach().to(dev, tdt).contiguous()
+    assert t.dim() >= 3, "expected (..., H, W, C)"
+    H, W, C = (int(v) for v in t.shape[-3:])
+    new = (int(H * factor), int(W * factor)) if shape is None else (int(shape[-3]), int(shape[-2]))   # image.py:49-50
+    if new == (H, W):
+        return t
+    n = int(np.prod(t.shape[:-3])) if t.dim() > 3 else 1
+    out = torch.empty(tuple(t.shape[:-3]) + (new[0], new[1], C), dtype=tdt, device=dev)
+    lib.resize_aa(t.data_ptr(), n, H, W, C, new[0], new[1], out.data_ptr(), _recon._stream_handle(dev))
+    return out
+
+
 def _load_array(fp):
     """``.npy`` / ``.npz`` only (io.py:122-123, 272-291): image decoding (cv2 / rawpy) is in front of the hot path."""
     import os
@@ -154,9 +178,9 @@ def load_data(psf_fp, data_fp, background_fp=None, return_bg=False, remove_backg
     ``.npy`` / ``.npz`` inputs: what ``scripts/recon/admm.py:30-51`` and ``apply_admm`` (admm.py:400-403) call.
     Arithmetic on the device (``preprocess_data``); ``use_torch=True, torch_device="cuda"`` keeps PSF and frame in
     HBM, otherwise NumPy arrays come back like the reference's default.  ``plot`` / ``gamma`` are accepted and
-    ignored (display only).  Not supported, each with an explicit error: image files, ``bayer=True``,
-    ``background_fp`` (a second capture), ``return_float=False``, ``shape=`` and ``downsample != 1`` unless the
-    arrays already have the PSF's size (resizing is cv2 / torchvision in the reference: no oracle here)."""
+    ignored (display only).  ``downsample`` / ``shape`` resize on the device (``resize``: the anti-aliased bilinear
+    filter of the reference's torch branch).  Not supported, each with an explicit error: image files,
+    ``bayer=True``, ``background_fp`` (a second capture), ``return_float=False``."""
     if shape is None:
         assert downsample is not None                                     # io.py:465-466
     if bayer or blue_gain is not None or red_gain is not None:
@@ -165,16 +189,29 @@ def load_data(psf_fp, data_fp, background_fp=None, return_bg=False, remove_backg
         raise NotImplementedError("background_fp: pass the background to apply(background=...) instead")
     if not return_float:
         raise NotImplementedError("return_float=False (integer outputs) is not a solver input")
-    if shape is not None or (downsample is not None and downsample != 1):
-        raise NotImplementedError("resizing (downsample != 1 / shape=) has no oracle here (cv2 / torchvision absent); "
-                                  "resize in your loader, or capture at the reconstruction size")
     raw_psf, raw_data = _load_array(psf_fp), _load_array(data_fp)
     if raw_psf.ndim == 3:                       # io.py:316-319 with use_3d (a .npy PSF): a 3-D stack is (D,H,W), gray
         raw_psf = raw_psf[..., None]
     assert raw_psf.ndim == 4, "a .npy / .npz PSF is a depth stack (D,H,W[,C]) (io.py:315-321)"
-    res = preprocess_data(raw_psf, raw_data, bg_pix=bg_pix, flip=flip, flip_ud=flip_ud, flip_lr=flip_lr, gray=gray,
-                          single_psf=single_psf, normalize=normalize, bgr_input=bgr_input, dtype=dtype, return_bg=True)
+    resizing = shape is not None or (downsample is not None and downsample != 1)
+    res = preprocess_data(raw_psf, raw_data, bg_pix=bg_pix, flip=flip, flip_ud=flip_ud, flip_lr=flip_lr,
+                          gray=gray and not resizing, single_psf=single_psf, normalize=normalize, bgr_input=bgr_input,
+                          dtype=dtype, return_bg=True)
     psf, data, bg = res
+    if resizing:
+        # load_psf resizes between the background removal and the normalisation (io.py:352-375); resampling is linear
+        # and its weights are positive, so it commutes with the scaling, the channel sum and rgb2gray that the device
+        # pass has already applied -- up to rounding: resize the prepared PSF and renormalise its l2 norm ...
+        # (rgb2gray comes last in the reference, AFTER the l2 normalisation of the colour PSF, io.py:550-552: it is
+        # applied by the second device pass, not the first)
+        dt = dtype or "float32"
+        psf = resize(psf, factor=None if shape is not None else 1 / downsample, shape=shape, dtype=dt)
+        psf = preprocess_psf(psf, bg_pix=None, gray=gray, dtype=dt)
+        # ... and the frame, already normalised, is resized to the PSF's size (io.py:527-529)
+        if tuple(data.shape[-3:-1]) != tuple(psf.shape[-3:-1]):
+            data = resize(data, shape=tuple(psf.shape), dtype=dt)
+        if gray and data.shape[-1] == 3:
+            data = preprocess_frames(data, normalize=False, gray=True, dtype=dt)
     if bg_pix is None:
         bg = torch.zeros((4,), dtype=psf.dtype, device=psf.device)         # io.py:338 (np.zeros(len(psf.shape)))
     if use_torch:

@@ -116,8 +116,10 @@ def test_script_flow_golden(backend, flow_files, tmp_path):
     saved = np.load(tmp_path / "out" / "final_reconstruction.npy")
     assert saved.shape == (36, 48, 3) and np.array_equal(saved, img)    # res[0] with plot=False: first depth plane
     assert rel(saved, g["script_np_res"][0]) <= 5e-6
-    with pytest.raises(NotImplementedError, match="resiz"):
-        load_data(pf, df, downsample=4)                                 # no oracle for cv2 / torchvision resizing
+    small_psf, small_data = load_data(pf, df, downsample=4)             # defaults.yaml's downsample: resized on the device
+    assert small_psf.shape == (1, 9, 12, 3) and small_data.shape == (1, 9, 12, 3)
+    with pytest.raises(NotImplementedError, match="Bayer"):
+        load_data(pf, df, downsample=1, bayer=True)
     with pytest.raises(AssertionError):
         load_data(pf, df)                                               # io.py:465-466: downsample or shape required
 

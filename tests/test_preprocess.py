@@ -102,3 +102,67 @@ def test_rejects_bad_arguments(backend):
         prep.preprocess_psf(np.ones((1, 8, 8, 3), dtype=np.uint8), bg_pix=(5, 25))   # window outside the frame
     with pytest.raises(AssertionError):
         prep.preprocess_frames(np.ones((4, 4, 3), dtype=np.uint8), bg=np.array([0.1, 0.2]))
+
+
+# ------------------------------------------------------------------------------------------------- resize --
+RESIZE_CASES = [((1, 40, 52, 3), dict(factor=1 / 4)), ((2, 37, 50, 3), dict(factor=1 / 4)),
+                ((1, 64, 48, 1), dict(factor=0.5)), ((1, 33, 47, 3), dict(shape=(1, 20, 31, 3))),
+                ((1, 20, 20, 3), dict(factor=1.5))]
+
+
+def _torch_resize(x, size):
+    """what image.py:59-64 does when torch + torchvision are installed: Resize(size, antialias=True) on (C, D, H, W)"""
+    import torch.nn.functional as F
+
+    t = torch.from_numpy(np.moveaxis(x, -1, 0).copy())
+    r = F.interpolate(t, size=size, mode="bilinear", align_corners=False, antialias=True).numpy()
+    return np.clip(np.moveaxis(r, 0, -1), x.min(), x.max())
+
+
+@pytest.mark.parametrize("shape,kw", RESIZE_CASES)
+def test_oracle_resize_matches_torch_antialias(shape, kw):
+    rng = np.random.default_rng(3)
+    for dt, tol in ((np.float32, 5e-6), (np.float64, 1e-14)):
+        x = rng.random(shape).astype(dt)
+        got = po.resize_aa(x, **kw)
+        assert got.dtype == dt
+        assert rel(got, _torch_resize(x, got.shape[-3:-1])) <= tol
+
+
+@pytest.mark.parametrize("shape,kw", RESIZE_CASES)
+def test_device_resize(backend, shape, kw):
+    rng = np.random.default_rng(4)
+    x = rng.random(shape).astype(np.float32)
+    got = prep.resize(x, **kw)
+    want = po.resize_aa(x, **kw)
+    assert tuple(got.shape) == want.shape
+    assert rel(got, want) <= 2e-6
+    assert rel(got, _torch_resize(x, want.shape[-3:-1])) <= 5e-6
+    x64 = rng.random(shape)
+    assert rel(prep.resize(x64, **kw), po.resize_aa(x64, **kw)) <= 1e-13
+    assert prep.resize(x, factor=1) is not None and tuple(prep.resize(x, factor=1).shape) == shape   # image.py:53-54
+
+
+def test_load_data_with_downsample(backend, tmp_path):
+    """profile/admm.py:19-26's load_data(..., downsample=4, gray=True) on .npy inputs: the oracle chains the restated
+    steps in the reference's order (background, clip, resize, norm; frame: normalise, resize to the PSF, gray)."""
+    rng = np.random.default_rng(6)
+    raw_psf = (rng.random((1, 64, 88, 3)) ** 8 * 3500 + rng.random((1, 64, 88, 3)) * 60 + 90).astype(np.uint16)
+    raw_dat = (rng.random((64, 88, 3)) * 3000 + 150).astype(np.uint16)
+    pf, df = str(tmp_path / "p.npy"), str(tmp_path / "d.npy")
+    np.save(pf, raw_psf)
+    np.save(df, raw_dat)
+    psf, data = prep.load_data(pf, df, downsample=4, gray=True, normalize=True, bgr_input=False, plot=False)
+    assert psf.shape == (1, 16, 22, 1) and data.shape == (1, 16, 22, 1)
+    # reference order (io.py:331-375, 505-552)
+    p = raw_psf.astype(np.float32)
+    bg = np.array([np.mean(p[:, 5:25, 5:25, i]) for i in range(3)], dtype=np.float32)
+    p = np.clip(p - bg, 0, None)
+    p = po.resize_aa(p, factor=1 / 4)
+    p = p / np.linalg.norm(p.ravel())
+    d = raw_dat.astype(np.float32)[None]
+    d = np.clip(d - (bg / po.get_max_val(raw_psf)) * po.get_max_val(raw_dat), 0, None)
+    d = d / d.max()
+    d = po.resize_aa(d, shape=p.shape)
+    want_psf, want_data = po.rgb2gray(p).astype(np.float32), po.rgb2gray(d).astype(np.float32)
+    assert rel(psf, want_psf) <= 5e-6 and rel(data, want_data) <= 5e-6
