@@ -167,7 +167,8 @@ def timed_config(name, rec, call, units_per_call, unit, reps, note):
     kern = kernel_table(rec._handle, prof)
     alg = sum(v["alg_GB"] * v["launches"] for v in kern.values()) / reps       # algorithmic GB per call
     busy = sum(v["ms"] * v["launches"] for v in kern.values()) / reps           # kernel ms per call
-    return {"config": name, "value": round(units_per_call / dt, 2), "unit": unit, "ms_per_call": round(dt * 1e3, 3),
+    return {"config": name, "engine_plan": rec._handle.plan_info(),
+            "value": round(units_per_call / dt, 2), "unit": unit, "ms_per_call": round(dt * 1e3, 3),
             "alg_GB_per_call": round(alg, 3),
             "whole_call_frac_of_peak": round(alg / dt / HBM_PEAK_GBS, 4),       # algorithmic bytes / wall time / 8 TB/s
             "kernel_ms_per_call": round(busy, 3), "kernels": kern, "note": note}
@@ -362,6 +363,7 @@ def main():
                                                   / HBM_PEAK_GBS, 4),
             "device_copy_GBps": round(copy_gbps, 1) if copy_gbps else None,
             "hbm_workspace_GB": round(rec._handle.workspace_bytes() / 1e9, 2),
+            "engine_plan": rec._handle.plan_info(),
         }
 
     # ---- CPU baseline + parity: rank 0, N == 1 only --------------------------------------

@@ -222,6 +222,9 @@ int lpc_kernel_bytes(lpc_handle h, int kernel_id, double* bytes);
  * R = padded real array, S = half spectrum, R0 = un-padded array (all planes).  Independent of how many passes the
  * engine really makes. */
 int lpc_model_bytes(lpc_handle h, double* bytes);
+/* one-line description of the launch plan the handle chose (row scheme, column split, which passes run on compile-time
+ * plans, whether the ADMM image-domain kernel is fused into the rows) -- for logs and tests */
+int lpc_plan_info(lpc_handle h, char* buf, size_t n);
 /* bytes of HBM the handle owns */
 int lpc_workspace_bytes(lpc_handle h, size_t* bytes);
 

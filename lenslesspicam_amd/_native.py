@@ -94,6 +94,7 @@ class Lib:
             "lpc_kernel_bytes": [vp, C.c_int, C.POINTER(C.c_double)],
             "lpc_workspace_bytes": [vp, C.POINTER(C.c_size_t)],
             "lpc_model_bytes": [vp, C.POINTER(C.c_double)],
+            "lpc_plan_info": [vp, C.c_char_p, C.c_size_t],
             "lpc_reconstruction_error": [vp, fp, fp, C.c_int, fp, vp],
             "lpc_image_metrics": [fp, fp, C.c_long, C.c_int, C.c_int, fp, vp],
             "lpc_preprocess_frames": [C.POINTER(PrepConfig), vp, C.c_int, fp, fp, vp],
@@ -238,6 +239,11 @@ class Handle:
         b = C.c_double()
         self._c(self.lib.dll.lpc_kernel_bytes(self.h, kid, C.byref(b)))
         return b.value
+
+    def plan_info(self):
+        buf = C.create_string_buffer(512)
+        self._c(self.lib.dll.lpc_plan_info(self.h, buf, 512))
+        return buf.value.decode()
 
     def model_bytes(self):
         b = C.c_double()

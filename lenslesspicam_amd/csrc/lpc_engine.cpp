@@ -179,6 +179,14 @@ static int setup_geometry(Engine* e) {
   // (ADMM in float32 only: 2 x 24 complex128 values do not fit a lane's registers)
   choose_split(g.Hp, g.Wc, &e->N1, &e->N2, &e->T,
                (c.algo != LPC_ALGO_ADMM || sizeof(real) == 4) && !std::getenv("LPC_MID_LDS"));
+  // DiffuserCam-sized ADMM frames (540 padded rows, single-pass columns): the fused middle takes the two spectra one
+  // after the other through a 16-column tile (k_cols_mid_admm_seq) instead of 2 x 8 columns side by side
+  // ... when the batch is large enough to fill the chip with the half as many workgroups (measured, profiles/r02_notes.md:
+  // 64 frames 1.20 -> 0.96 ms per launch; ONE frame 0.032 -> 0.042 ms: 93 workgroups for 256 CUs)
+  if (c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && e->N1 == 1 && g.Hp == 540 && e->T == 8 && g.Wc > 8 &&
+      ((long)e->P * ((g.Wc + 15) / 16) >= 512 || std::getenv("LPC_MID_SEQ")) && !std::getenv("LPC_MID_PAIR") && !std::getenv("LPC_NO_STATIC") && !std::getenv("LPC_NO_STATIC_COLS") &&
+      !std::getenv("LPC_COL_T"))
+    e->T = 16;
   LPC_OK(build_plan(e, e->planW, g.Wp));
   e->rows_r2 = e->planW.nst >= 2 && e->planW.radix[e->planW.nst - 1] == 2 && !std::getenv("LPC_NO_R2");
   if (e->rows_r2) {
@@ -202,11 +210,17 @@ static int setup_geometry(Engine* e) {
   if (e->rows_half && e->planWh.skew_ok && !std::getenv("LPC_NO_STATIC")) {
     if (RowPlan4096::matches(e->planWh)) e->static_rows = 4096;
     if (RowPlan1920::matches(e->planWh)) e->static_rows = 1920;
+    if (RowPlan1024::matches(e->planWh)) e->static_rows = 1024;
   }
 
   // float4 lanes and half-length rows: r_sp and a are computed by the row workgroups themselves (float32 build)
+  // ... an OPTION (LPC_FUSE_ROWS=1), not the default: it removes 4R of traffic and one launch per iteration, but its
+  // image-domain half runs at the row kernel's occupancy (4 workgroups per CU, LDS-bound) instead of the tiled kernel's
+  // 7.  Measured on one box with compile-time plans everywhere (profiles/r02_notes.md): 12 MP fused 2.01 ms vs
+  // stand-alone 1.51 + 0.45 ms (229.7 vs 236.3 it/s); 1080p x 16 planes 5.85 vs 4.31 + 1.52 ms.  (With the run-time
+  // plans of round 1 the forward rows took 0.61 ms and fusion won, 202 vs 196 it/s.)
   e->fuse_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && e->rows_half && g.Wp % 4 == 0 &&
-                 !std::getenv("LPC_NO_FUSE_ROWS") && !std::getenv("LPC_K1_SCALAR");
+                 std::getenv("LPC_FUSE_ROWS") && !std::getenv("LPC_K1_SCALAR");
   LPC_OK(build_plan(e, e->planB, e->N2));
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
   e->static_sk = !std::getenv("LPC_ROWS_NOSKEW");
@@ -214,11 +228,14 @@ static int setup_geometry(Engine* e) {
   // (same-box A/B, profiles/r02_notes.md: inverse rows 0.518 -> 0.487 ms, FISTA 412 -> 417 it/s); LPC_ROWS_R8 = the old plan
   e->rows_r16 = std::getenv("LPC_ROWS_R8") == nullptr;
   if (!std::getenv("LPC_NO_STATIC") && !std::getenv("LPC_NO_STATIC_COLS")) {
-    if (e->N1 > 1 && e->T == 16 && ColPlan128::matches(e->planA)) e->static_passA = 128;
+    if (e->N1 > 1 && (e->T == 16 || e->T == 32) && ColPlan128::matches(e->planA)) e->static_passA = 128;
     if (e->N1 > 1 && e->T == 16 && ColPlan90::matches(e->planA)) e->static_passA = 90;
-    if (e->N1 > 1 && e->T == 16 && ColPlan48::matches(e->planB)) e->static_mid = 48;
+    if (e->N1 > 1 && e->T == 16 && ColPlan64::matches(e->planA)) e->static_passA = 64;
+    if (e->N1 > 1 && (e->T == 16 || e->T == 32) && ColPlan48::matches(e->planB)) e->static_mid = 48;
     if (e->N1 == 1 && e->T == 8 && ColPlan540::matches(e->planB)) e->static_mid = 540;
+    if (e->N1 == 1 && e->T == 16 && c.algo == LPC_ALGO_ADMM && ColPlan540::matches(e->planB)) e->static_mid = 541;
     if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan960::matches(e->planW)) e->static_prow = 960;
+    if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan2048::matches(e->planW)) e->static_prow = 2048;
   }
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
   const int ntc = (g.Wc + e->T - 1) / e->T;
@@ -1058,6 +1075,25 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
     return fail("lpc_kernel_bytes: operator-only handle");
   }
   *bytes = b;
+  return 0;
+}
+
+int lpc_plan_info(lpc_handle e, char* buf, size_t n) {
+  if (!e || !buf || n == 0) return fail("null argument");
+  const PlaneGeom& g = e->g;
+  std::string s = "padded " + std::to_string(g.Hp) + "x" + std::to_string(g.Wp);
+  s += e->rows_half ? "; rows: half-length " + std::to_string(g.Wp / 2) : "; rows: paired " + std::to_string(g.Wp);
+  if (e->rows_half && e->static_rows) s += e->static_rows == 4096 && e->rows_r16 ? " [static 16.16.16]" : " [static]";
+  if (!e->rows_half && e->static_prow && e->cfg.algo == LPC_ALGO_ADMM) s += " [static]";
+  s += "; columns: " + (e->N1 > 1 ? std::to_string(e->N1) + " x " + std::to_string(e->N2) + " split" : std::string("single pass ") + std::to_string(e->N2));
+  s += ", T = " + std::to_string(e->T);
+  if (e->static_passA) s += ", pass A [static]";
+  if (e->cfg.algo == LPC_ALGO_ADMM) {
+    const bool reg = e->N1 > 1 && e->mid_reg && sizeof(real) == 4 && e->N2 == 24;
+    s += reg ? ", middle in registers" : (e->static_mid ? ", LDS middle [static]" : ", LDS middle");
+    s += e->fuse_rows ? "; image-domain kernel fused into the forward rows" : "; stand-alone image-domain kernel";
+  }
+  std::snprintf(buf, n, "%s", s.c_str());
   return 0;
 }
 

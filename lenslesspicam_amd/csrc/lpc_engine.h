@@ -80,9 +80,9 @@ struct lpc_engine {
   Fft1dPlan planWh{};   // length Wp/2: ADMM rows, one real row per half-length transform (rows_half)
   bool rows_half = false;
   bool static_sk = true;   // static-plan row kernels: LDS skew on (tuning knob LPC_ROWS_NOSKEW: 32 KiB tiles, 5 per CU)
-  int static_passA = 0;    // pass-A length served by a compile-time plan (128 | 90, 16-column tiles), else 0
+  int static_passA = 0;    // pass-A length served by a compile-time plan (128 | 90 | 64, 16-column tiles), else 0
   int static_mid = 0;      // ADMM LDS-middle length served by a compile-time plan (48 with T = 16 | 540 with T = 8)
-  int static_prow = 0;     // ADMM PAIRED-row length served by a compile-time plan (960), else 0
+  int static_prow = 0;     // ADMM PAIRED-row length served by a compile-time plan (960 | 2048), else 0
   bool rows_r16 = false;   // 4096-point rows as 16.16.16 instead of 8.8.8.8
   int static_rows = 0;     // length of the half-row transform when a compile-time plan serves it (lpc_sfft.h), else 0
   bool fuse_rows = false;  // ADMM: the image-domain kernel is fused into the forward row pass (k_admm_rows_fused)
@@ -238,7 +238,11 @@ typedef SPlan<6, 5, 3> ColPlan90;
 // paired rows of 960 = 8.8.5.3
 typedef SPlan<6, 6, 5, 3> ColPlan540;
 typedef SPlan<8, 8, 5, 3> RowPlan960;
+// 760 x 1014 frames (1536 x 2048 padded, 1536 = 64 x 24): pass A 64 = 8.8, ADMM's paired rows 2048 = 8.8.8.4
+typedef SPlan<8, 8> ColPlan64;
+typedef SPlan<8, 8, 8, 4> RowPlan2048;
 typedef SPlan<8, 8, 6, 5> RowPlan1920;      // half rows of 3840-column padded frames (1080 x 1920)
+typedef SPlan<8, 8, 8, 2> RowPlan1024;      // half rows of 2048-column padded frames (760 x 1014, the profile/*.py frame)
 // workgroup shape per static row plan: NT threads x EM points (the same table as dispatch_cfg)
 template <class P, int NT_, int EM_>
 struct RowShape { using plan = P; static constexpr int nt = NT_, em = EM_; };
@@ -254,6 +258,7 @@ static inline int with_row_shape(const lpc_engine* e, F&& f) {
   if (e->static_rows == 4096 && e->rows_r16) return f(RowShape<RowPlan4096r16, 256, 16>{});
   if (e->static_rows == 4096) return f(RowShape<RowPlan4096, 256, 16>{});
   if (e->static_rows == 1920) return f(RowShape<RowPlan1920, 256, 8>{});
+  if (e->static_rows == 1024) return f(RowShape<RowPlan1024, 256, 4>{});
   return fail("internal: no static row plan for this length");
 }
 

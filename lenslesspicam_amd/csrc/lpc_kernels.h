@@ -781,6 +781,77 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
     fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL>(s, plan, T2, t2div, tid, LdsNatural{}, out);
 }
 
+// ---- the same fused middle, ONE ARRAY AT A TIME through a tile of T image columns (single-pass columns only) ------
+// k_cols_mid_admm keeps both spectra in one [N][2T] tile; when a whole column is long (540 rows for the
+// DiffuserCam-sized frames of C1 / C4) that tile allows only T = 8 columns per array -- 64-byte row segments, half a
+// cache line per access.  Here the transform of `a` is parked in registers (N*T/NT values per lane) while the same
+// LDS tile transforms `r_sp`: T = 16 columns per workgroup in the same 69 KiB, every row access a whole 128-byte
+// line, half as many workgroups.  H and |G| are shared by all frames of a batch (L2-resident) and are loaded where
+// they are used.  Compile-time plans only (SBT == cp.T).
+template <int NT, int EMAX, class PL, int SBT>
+__global__ __launch_bounds__(NT) void k_cols_mid_admm_seq(PlaneGeom g, PL plan, ColPass cp, real2* LPC_RESTRICT SA,
+                                                           real2* LPC_RESTRICT SB, const real2* LPC_RESTRICT Hs,
+                                                           const real* LPC_RESTRICT Gabs, const real2* LPC_RESTRICT phr,
+                                                           const real2* LPC_RESTRICT phc, real mu1, real mu2, real mu3,
+                                                           real rscale) {
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int tid = threadIdx.x;
+  constexpr int T = SBT, N = PL::n, NELEM = N * T, EM = (NELEM + NT - 1) / NT;
+  static_assert(EM <= EMAX, "tile does not fit the workgroup shape");
+  const int c0 = (int)blockIdx.x * T;
+  real2* ba = SA + (long)blockIdx.y * g.cplane + c0;
+  real2* bb = SB + (long)blockIdx.y * g.cplane + c0;
+  const real2* hb = Hs + (long)((int)blockIdx.y % g.DC) * g.cplane + c0;
+  const real* rb = Gabs + c0;
+  const long rstep = g.cpitch;
+  const real2 zero = make_real2((real)0., (real)0.);
+  auto inB = [&](int i, int j) { return (c0 + j < g.Wc) ? bb[i * rstep + j] : zero; };
+  auto inA = [&](int i, int j) { return (c0 + j < g.Wc) ? ba[i * rstep + j] : zero; };
+  // 1. Ah = FFT(a), parked in registers in tile order e = tid + k NT
+  fft_tile<NT, EMAX, false, false, false, false, false, SBT>(s, plan, T, cp.tdiv, tid, inB, LdsNatural{});
+  real2 a[EM];
+#pragma unroll
+  for (int k = 0; k < EM; ++k) {
+    const int e = tid + k * NT;
+    a[k] = e < NELEM ? s[e] : zero;
+  }
+  __syncthreads();
+  // 2. Rh = FFT(r_sp) in the same tile
+  fft_tile<NT, EMAX, false, false, false, false, false, SBT>(s, plan, T, cp.tdiv, tid, inA, LdsNatural{});
+  // 3. Vh = Rdiv (Rh + s conj(H) Ah) -> tile;  HVh = s H Vh -> the registers that held Ah
+#pragma unroll
+  for (int k = 0; k < EM; ++k) {
+    const int e = tid + k * NT;
+    if (e < NELEM) {
+      const int i = e / T, j = e % T;
+      if (c0 + j < g.Wc) {
+        const real2 hh = hb[i * rstep + j];
+        const real rdiv = rscale * ((real)1.0 / (mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * rb[i * rstep + j] + mu3));
+        const real2 ph = cmul(phr[i], phc[c0 + j]);
+        const real2 t = cmul(cmul_conj(a[k], hh), ph);
+        const real2 vh = cscale(cadd(s[e], t), rdiv);
+        s[e] = vh;
+        a[k] = cmul(cmul(vh, hh), ph);
+      }
+    }
+  }
+  __syncthreads();
+  // 4. V-hat back through the inverse transform, straight to SA
+  auto outA = [&](int i, int j, real2 x) { if (c0 + j < g.Wc) ba[i * rstep + j] = x; };
+  fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, outA);
+  __syncthreads();
+  // 5. H V-hat: registers -> tile -> inverse transform -> SB
+#pragma unroll
+  for (int k = 0; k < EM; ++k) {
+    const int e = tid + k * NT;
+    if (e < NELEM) s[e] = a[k];
+  }
+  __syncthreads();
+  auto outB = [&](int i, int j, real2 x) { if (c0 + j < g.Wc) bb[i * rstep + j] = x; };
+  fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, outB);
+}
+
 // ============================================================ ADMM spatial kernel ==
 // K1: everything of one ADMM iteration that lives in the image domain, in ONE pass:
 //   (pending) dual updates of the previous iteration  xi, eta, rho

@@ -81,6 +81,10 @@ int admm_rows_fwd(Engine* e) {
                       LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real*)e->Rsp,
                       (const real*)e->Aarr, SA, SB);
     });
+  if (e->static_prow == 2048)    // 760 x 1014 frames: paired rows of 2048 points = 256 threads x 8
+    return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<256, 8, true, false, SPlanArg<RowPlan2048>>, dim3(g.Hp, e->P), 256,
+                    LPC_ROW_SMEM_BYTES(2048, true), g, splan_arg<RowPlan2048>(e->planW), (const real*)e->Rsp,
+                    (const real*)e->Aarr, SA, SB);
   if (e->static_prow == 960)     // C1 / C4: paired rows of 960 points = 256 threads x 4 (3.75)
     return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<256, 4, true, false, SPlanArg<RowPlan960>>, dim3(g.Hp, e->P), 256,
                     LPC_ROW_SMEM_BYTES(960, true), g, splan_arg<RowPlan960>(e->planW), (const real*)e->Rsp,
@@ -179,6 +183,10 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout) {
                       LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real2*)SA,
                       (const real2*)SB, Vout, HVout);
     });
+  if (e->static_prow == 2048)
+    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<256, 8, true, false, SPlanArg<RowPlan2048>>, dim3(g.Hp, e->P), 256,
+                    LPC_ROW_SMEM_BYTES(2048, true), g, splan_arg<RowPlan2048>(e->planW), (const real2*)SA, (const real2*)SB,
+                    Vout, HVout);
   if (e->static_prow == 960)
     return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<256, 4, true, false, SPlanArg<RowPlan960>>, dim3(g.Hp, e->P), 256,
                     LPC_ROW_SMEM_BYTES(960, true), g, splan_arg<RowPlan960>(e->planW), (const real2*)SA, (const real2*)SB,

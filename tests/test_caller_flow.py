@@ -207,4 +207,5 @@ def test_apply_display_loop_golden_fused_rows(backend, monkeypatch, tmp_path):
     """The same vectors through the 12-MP code path (half-length rows with the image-domain kernel fused into them):
     the clamped copies of the estimate that the W-update sees after a read-out travel through k_admm_rows_fused."""
     monkeypatch.setenv("LPC_ROWS_HALF", "1")
+    monkeypatch.setenv("LPC_FUSE_ROWS", "1")
     test_apply_display_loop_golden(backend, tmp_path)

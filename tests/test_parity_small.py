@@ -316,11 +316,12 @@ def test_admm_half_length_row_kernels(backend, monkeypatch, name, fused):
     """ADMM's row passes switch to one real row per half-length complex transform for wide frames only;
     LPC_ROWS_HALF forces them on the golden-vector sizes (row transforms of 32 and 30 points, the second one without
     the LDS skew): same trajectory checks as the regular golden test.  `fused`: the image-domain kernel computes the
-    rows of r_sp and a inside the forward row workgroups (k_admm_rows_fused) -- the 12-MP code path; LPC_NO_FUSE_ROWS
-    selects the stand-alone kernels (k_admm_spatial_v4 + k_rfwd_half) instead."""
+    rows of r_sp and a inside the forward row workgroups (k_admm_rows_fused, opt-in with LPC_FUSE_ROWS: measured slower
+    than the stand-alone pair once the rows run on compile-time plans); otherwise the stand-alone kernels
+    (k_admm_spatial_v4 + k_rfwd_half), the 12-MP default."""
     monkeypatch.setenv("LPC_ROWS_HALF", "1")
-    if not fused:
-        monkeypatch.setenv("LPC_NO_FUSE_ROWS", "1")
+    if fused:
+        monkeypatch.setenv("LPC_FUSE_ROWS", "1")
     test_admm_matches_reference_golden(backend, name)
 
 
@@ -341,14 +342,17 @@ def test_convolver_half_length_row_kernels(backend, monkeypatch):
     test_convolver_slice_commutes(backend)
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["standalone", "fused_rows"])
 @pytest.mark.parametrize("static", [True, False], ids=["static_plan", "runtime_plan"])
-def test_8192_column_rows_static_plan(backend, monkeypatch, static):
+def test_8192_column_rows_static_plan(backend, monkeypatch, static, fused):
     """12 MP's ROW shape on a frame with only a few rows: 4096 columns pad to 8192, the half-row transform has 4096
     points = 8.8.8.8, which is served by kernels instantiated on a compile-time plan (lpc_sfft.h) -- ADMM through the
     fused image-domain + row kernel, the gradient-descent family's residual / update kernels, and the convolver's
     pad-on-load / crop-on-store rows.  LPC_NO_STATIC runs the same frame through the run-time plan."""
     if not static:
         monkeypatch.setenv("LPC_NO_STATIC", "1")
+    if fused:
+        monkeypatch.setenv("LPC_FUSE_ROWS", "1")     # the image-domain kernel inside the forward rows (opt-in)
     H, W, C = 3, 4096, 1
     rng = np.random.default_rng(11)
     psf = orc.synthetic_psf(1, H, W, C, seed=4)
@@ -414,8 +418,9 @@ def _admm_fista_vs_oracle(H, W, C, padded, n_admm=3, n_fista=3, seed=13, tol=5e-
 
 @pytest.mark.parametrize("static", [True, False], ids=["static_plan", "runtime_plan"])
 @pytest.mark.parametrize("shape,padded", [((3, 1920, 1), (5, 3840)), ((1080, 9, 1), (2160, 18)),
-                                          ((270, 480, 1), (540, 960))],
-                         ids=["rows1920", "cols90x24", "c1_540x960"])
+                                          ((270, 480, 1), (540, 960)), ((3, 1014, 1), (5, 2048)),
+                                          ((760, 9, 1), (1536, 18))],
+                         ids=["rows1920", "cols90x24", "c1_540x960", "rows2048", "cols64x24"])
 def test_other_baseline_shapes_static_plans(backend, monkeypatch, static, shape, padded):
     """The remaining BASELINE shapes with compile-time plans, each on a frame that keeps the emulator fast:
     1080p's half rows (1920 = 8.8.6.5; ADMM through the fused image-domain + row kernel), its column split
@@ -424,3 +429,16 @@ def test_other_baseline_shapes_static_plans(backend, monkeypatch, static, shape,
     if not static:
         monkeypatch.setenv("LPC_NO_STATIC", "1")
     _admm_fista_vs_oracle(*shape, padded, n_admm=2 if shape[0] == 270 else 3, n_fista=2 if shape[0] == 270 else 3)
+    psf = orc.synthetic_psf(1, *shape, seed=1)
+    info = lpa.ADMM(torch.from_numpy(psf))._handle.plan_info() + " | " + lpa.FISTA(torch.from_numpy(psf))._handle.plan_info()
+    assert ("[static" in info) == static, info        # the plan tables really matched (no silent run-time fallback)
+
+
+def test_c4_sequential_middle_on_one_frame(backend, monkeypatch):
+    """C4's fused ADMM middle takes the two spectra one after the other through a 16-column tile
+    (k_cols_mid_admm_seq); the engine selects it for large batches only, LPC_MID_SEQ forces it onto one
+    DiffuserCam-sized frame so that the CPU suite executes it.  Batches must equal single-frame runs either way."""
+    monkeypatch.setenv("LPC_MID_SEQ", "1")
+    _admm_fista_vs_oracle(270, 480, 1, (540, 960), n_admm=2, n_fista=1)
+    psf = orc.synthetic_psf(1, 270, 480, 1, seed=1)
+    assert "T = 16" in lpa.ADMM(torch.from_numpy(psf))._handle.plan_info()

@@ -32,11 +32,34 @@ def main():
     ap.add_argument("--rgb", action="store_true", help="reference default is gray=True")
     ap.add_argument("--psf")
     ap.add_argument("--data")
+    ap.add_argument("--raw", action="store_true",
+                    help="the reference's own plumbing from a RAW capture: synthetic 12-bit 3040 x 4056 x 3 PSF and frame "
+                         "written as .npy, then load_data(psf_fp, data_fp, downsample=4, gray=True) like profile/admm.py:19-26")
     args = ap.parse_args()
     n_iter = args.n_iter or (5 if args.algo == "admm" else 300)
     n_trials = args.n_trials or (10 if args.algo == "admm" else 3)
     dev = torch.device("cuda")
-    if args.psf:
+    if args.raw:
+        import tempfile
+
+        from lenslesspicam_amd.prep import load_data
+
+        rng = np.random.default_rng(0)
+        tmp = tempfile.mkdtemp()
+        H0, W0 = 3040, 4056
+        raw_psf = (rng.random((1, H0, W0, 3), dtype=np.float32) ** 12 * 3800 + 64).astype(np.uint16)
+        raw_dat = (rng.random((H0, W0, 3), dtype=np.float32) * 3500 + 64).astype(np.uint16)
+        np.save(os.path.join(tmp, "psf.npy"), raw_psf)
+        np.save(os.path.join(tmp, "raw.npy"), raw_dat)
+        torch.cuda.synchronize()
+        t0 = time.time()
+        psf, data = load_data(os.path.join(tmp, "psf.npy"), os.path.join(tmp, "raw.npy"), downsample=4, plot=False,
+                              gray=True, dtype="float32", use_torch=True, torch_device="cuda", bgr_input=False)
+        torch.cuda.synchronize()
+        print(f"load_data(downsample=4, gray=True) from 2 x {raw_psf.nbytes / 1e6:.0f} MB .npy files: "
+              f"{(time.time() - t0) * 1e3:.1f} ms (file read + upload + device preparation and resize) -> {tuple(psf.shape)}")
+        data = data[0]
+    elif args.psf:
         psf = torch.from_numpy(np.load(args.psf).astype(np.float32)).to(dev)
         data = torch.from_numpy(np.load(args.data).astype(np.float32)).to(dev)
     else:
