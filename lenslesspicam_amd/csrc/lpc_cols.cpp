@@ -14,24 +14,23 @@ int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1,
     cp.needn = g.H;
   }
   const dim3 grid(cp.G * cp.ntile_c, nplanes);
-  // 16 columns per tile; 128 x 16 = 256 x 8 points, 90 x 16 = 1440 <= 256 x 8, 64 x 16 = 256 x 4
-  auto static_passA = [&](auto plan_tag, auto em_tag) {
+  // compile-time plans: 32 columns per tile (512 threads: 128 x 32 = 512 x 8 points, 90 x 32 <= 512 x 6, 64 x 32 = 512 x 4),
+  // or 16 (256 threads) when the engine kept the narrow tile (narrow frames, tuning knobs)
+  auto static_passA = [&](auto plan_tag) {
     using P = decltype(plan_tag);
-    constexpr int em = decltype(em_tag)::value;
-    const size_t smem = (size_t)P::n * 16 * sizeof(real2);
     const SPlanArg<P> pa = splan_arg<P>(e->planA);
-    if (inverse) return launch_k(e, kid, k_cols<256, em, true, SPlanArg<P>, 16>, grid, 256, smem, g, pa, cp, S);
-    return launch_k(e, kid, k_cols<256, em, false, SPlanArg<P>, 16>, grid, 256, smem, g, pa, cp, S);
+    if (cp.T == 32) {
+      const size_t smem = (size_t)P::n * 32 * sizeof(real2);
+      if (inverse) return launch_k(e, kid, k_cols<512, 8, true, SPlanArg<P>, 32>, grid, 512, smem, g, pa, cp, S);
+      return launch_k(e, kid, k_cols<512, 8, false, SPlanArg<P>, 32>, grid, 512, smem, g, pa, cp, S);
+    }
+    const size_t smem = (size_t)P::n * 16 * sizeof(real2);
+    if (inverse) return launch_k(e, kid, k_cols<256, 8, true, SPlanArg<P>, 16>, grid, 256, smem, g, pa, cp, S);
+    return launch_k(e, kid, k_cols<256, 8, false, SPlanArg<P>, 16>, grid, 256, smem, g, pa, cp, S);
   };
-  if (e->static_passA == 128 && cp.T == 32) {   // tuning knob LPC_COL_T=32: 256-byte row segments, 128 x 32 = 512 x 8 points
-    const size_t smem = (size_t)128 * 32 * sizeof(real2);
-    const SPlanArg<ColPlan128> pa = splan_arg<ColPlan128>(e->planA);
-    if (inverse) return launch_k(e, kid, k_cols<512, 8, true, SPlanArg<ColPlan128>, 32>, grid, 512, smem, g, pa, cp, S);
-    return launch_k(e, kid, k_cols<512, 8, false, SPlanArg<ColPlan128>, 32>, grid, 512, smem, g, pa, cp, S);
-  }
-  if (e->static_passA == 128) return static_passA(ColPlan128{}, std::integral_constant<int, 8>{});
-  if (e->static_passA == 90) return static_passA(ColPlan90{}, std::integral_constant<int, 8>{});
-  if (e->static_passA == 64) return static_passA(ColPlan64{}, std::integral_constant<int, 4>{});
+  if (e->static_passA == 128) return static_passA(ColPlan128{});
+  if (e->static_passA == 90) return static_passA(ColPlan90{});
+  if (e->static_passA == 64) return static_passA(ColPlan64{});
   return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
     const size_t smem = (size_t)cp.N * cp.T * sizeof(real2);
@@ -119,12 +118,6 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
     else if (e->static_mid == 540) {   // C1 / C4: 540 points x 2 x 8 tile columns = 8640 points = 512 threads x 17
       LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<512, 18, SPlanArg<ColPlan540>, 16>, grid, 512,
                       (size_t)540 * 16 * sizeof(real2), g, splan_arg<ColPlan540>(e->planB), cp, SA, SB,
-                      (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2,
-                      sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
-    }
-    else if (e->static_mid == 48 && cp.T == 32) {   // LPC_COL_T=32: 48 x 64 = 3072 points = 512 threads x 6
-      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<512, 8, SPlanArg<ColPlan48>, 64>, grid, 512,
-                      (size_t)48 * 64 * sizeof(real2), g, splan_arg<ColPlan48>(e->planB), cp, SA, SB,
                       (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2,
                       sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
     }

@@ -228,10 +228,10 @@ static int setup_geometry(Engine* e) {
   // (same-box A/B, profiles/r02_notes.md: inverse rows 0.518 -> 0.487 ms, FISTA 412 -> 417 it/s); LPC_ROWS_R8 = the old plan
   e->rows_r16 = std::getenv("LPC_ROWS_R8") == nullptr;
   if (!std::getenv("LPC_NO_STATIC") && !std::getenv("LPC_NO_STATIC_COLS")) {
-    if (e->N1 > 1 && (e->T == 16 || e->T == 32) && ColPlan128::matches(e->planA)) e->static_passA = 128;
+    if (e->N1 > 1 && e->T == 16 && ColPlan128::matches(e->planA)) e->static_passA = 128;
     if (e->N1 > 1 && e->T == 16 && ColPlan90::matches(e->planA)) e->static_passA = 90;
     if (e->N1 > 1 && e->T == 16 && ColPlan64::matches(e->planA)) e->static_passA = 64;
-    if (e->N1 > 1 && (e->T == 16 || e->T == 32) && ColPlan48::matches(e->planB)) e->static_mid = 48;
+    if (e->N1 > 1 && e->T == 16 && ColPlan48::matches(e->planB)) e->static_mid = 48;
     if (e->N1 == 1 && e->T == 8 && ColPlan540::matches(e->planB)) e->static_mid = 540;
     if (e->N1 == 1 && e->T == 16 && c.algo == LPC_ALGO_ADMM && ColPlan540::matches(e->planB)) e->static_mid = 541;
     if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan960::matches(e->planW)) e->static_prow = 960;
@@ -246,6 +246,16 @@ static int setup_geometry(Engine* e) {
   ColPass& B = e->passB;
   B = A;
   B.N = e->N2; B.G = e->N1; B.istride = 1; B.gstride = e->N2;
+  // Pass A on a compile-time plan takes 32 columns per tile (256-byte row segments at its long row stride) while the
+  // fused middle keeps 16: the two passes tile the columns independently.  Same-box A/B at 12 MP with T = 32 for both
+  // (profiles/r02_notes.md): pass A 0.578 / 0.575 -> 0.530 / 0.510 ms, the middle 0.655 -> 0.71 ms.
+  if (e->static_passA && e->T == 16 && (g.Wc >= 256 || std::getenv("LPC_PASSA_T32")) && !std::getenv("LPC_COL_T") &&
+      !std::getenv("LPC_PASSA_T16")) {
+    A.T = 32;
+    A.ntile_c = (g.Wc + 31) / 32;
+    A.tdiv = make_fastdiv(32u);
+    A.tcdiv = make_fastdiv((unsigned)A.ntile_c);
+  }
   // ifftshift phases: out[i] = in[(i + n/2) mod n]  <=>  multiply bin k by exp(+2 pi i k (n/2) / n)
   std::vector<real2> pr((size_t)g.Hp), pc((size_t)g.Wc);
   for (int p = 0; p < g.Hp; ++p) {

@@ -442,3 +442,13 @@ def test_c4_sequential_middle_on_one_frame(backend, monkeypatch):
     _admm_fista_vs_oracle(270, 480, 1, (540, 960), n_admm=2, n_fista=1)
     psf = orc.synthetic_psf(1, 270, 480, 1, seed=1)
     assert "T = 16" in lpa.ADMM(torch.from_numpy(psf))._handle.plan_info()
+
+
+@pytest.mark.parametrize("shape,padded", [((3072, 20, 1), (6144, 40)), ((1080, 20, 1), (2160, 40)), ((760, 20, 1), (1536, 40))],
+                         ids=["passA128", "passA90", "passA64"])
+def test_pass_a_32_column_tiles(backend, monkeypatch, shape, padded):
+    """Wide frames run pass A (compile-time plans) on 32-column tiles while the fused middle keeps 16; LPC_PASSA_T32
+    forces that split tiling onto frames only 21 spectrum columns wide (one partly filled pass-A tile, two middle
+    tiles)."""
+    monkeypatch.setenv("LPC_PASSA_T32", "1")
+    _admm_fista_vs_oracle(*shape, padded, n_admm=2, n_fista=2)
