@@ -221,6 +221,11 @@ static int setup_geometry(Engine* e) {
   // plans of round 1 the forward rows took 0.61 ms and fusion won, 202 vs 196 it/s.)
   e->fuse_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && e->rows_half && g.Wp % 4 == 0 &&
                  std::getenv("LPC_FUSE_ROWS") && !std::getenv("LPC_K1_SCALAR");
+  // The half of it that needs no neighbours IS fused by default where a compile-time row plan exists: the forward row
+  // blocks of `a` compute xi' and a = mu1 X - xi' from xi, HV, HV_old, y themselves (-2R per iteration), the tiled
+  // kernel keeps the stencil half at its own occupancy.  LPC_NO_XHALF = the full stand-alone kernel.
+  e->xhalf_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && e->rows_half && g.Wp % 4 == 0 && e->static_rows &&
+                  !e->fuse_rows && !std::getenv("LPC_NO_XHALF") && !std::getenv("LPC_K1_SCALAR");
   LPC_OK(build_plan(e, e->planB, e->N2));
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
   e->static_sk = !std::getenv("LPC_ROWS_NOSKEW");
@@ -408,8 +413,11 @@ static int admm_reset(Engine* e) {
 
 // (r_sp, a) in e->Rsp / e->Aarr  ->  Vout = irfft2(R_div (rfft2 r_sp + s H* rfft2 a)),  HVout = H Vout:
 // forward rows, [pass A], fused middle, [inverse pass A], inverse rows
-static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real* HVout, bool rows_done = false) {
-  if (!rows_done) LPC_OK(admm_rows_fwd(e));   // else k_admm_rows_fused has already written the row spectra
+static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real* HVout, bool rows_done = false,
+                              bool xhalf = false) {
+  if (rows_done) {}                            // k_admm_rows_fused has already written the row spectra
+  else if (xhalf) LPC_OK(admm_rows_fwd_x(e, sc));
+  else LPC_OK(admm_rows_fwd(e));
   LPC_OK(admm_cols(e, sc));
   return admm_rows_inv(e, Vout, HVout);
 }
@@ -444,7 +452,13 @@ static int admm_iterate(Engine* e, int n_iter) {
     if (e->fuse_rows) {
       LPC_OK(admm_rows_fused(e, sc, (const real*)Vc, (const real*)Vo));
       rows_done = true;
-    } else if (vec4)
+    } else if (vec4 && e->xhalf_rows)
+      LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT, false>, k1_grid4, NT, k1_smem4, g, sc, (const real*)Vc,
+                      (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
+                      (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
+                      (const real*)e->Y, e->Rsp, e->Aarr, tiles_x4,
+                      (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
+    else if (vec4)
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT>, k1_grid4, NT, k1_smem4, g, sc, (const real*)Vc,
                       (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
                       (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
@@ -462,7 +476,9 @@ static int admm_iterate(Engine* e, int n_iter) {
     e->vw_cur = false;
     e->ecur ^= 1;
     e->first = false;
-    LPC_OK(admm_spectral_step(e, sc, Vo, e->HVb[e->hcur ^ 1], rows_done));
+    // (hcur still names the CURRENT H V here: the X half inside the forward rows reads HVb[hcur] and HVb[hcur ^ 1]
+    // before the inverse rows of this same step overwrite HVb[hcur ^ 1] -- stream order)
+    LPC_OK(admm_spectral_step(e, sc, Vo, e->HVb[e->hcur ^ 1], rows_done, vec4 && e->xhalf_rows && !rows_done));
     e->vcur ^= 1;  // Vo now holds the new image estimate
     e->hcur ^= 1;  // ... and the other H V buffer its forward model
     for (int k = 0; k < 4; ++k) e->last_par[k] = par[k];
@@ -1071,8 +1087,11 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
       // SURVEY 8(d) figure for the stand-alone kernel (reads 8R+R0, writes 7R; the kernel itself moves 14R + R0: X is
       // recomputed instead of stored).  Fused into the forward rows it reads 8R + R0 (V, V_old, HV, HV_old, xi, eta0,
       // eta1, rho; y) and writes xi, eta0, eta1, rho (4R) + the two row spectra (2S): r_sp and a never reach HBM.
-      case LPC_K_SPATIAL: b = e->fuse_rows ? 12.0 * R + R0 + 2.0 * S : 15.0 * R + R0; break;
-      case LPC_K_ROW_FWD: b = e->fuse_rows ? 0.0 : 2.0 * R + 2.0 * S; break;
+      // X half in the forward rows (default with compile-time row plans): the tiled kernel reads V, V_old, eta0, eta1,
+      // rho and writes eta0, eta1, rho, r_sp = 9R (SURVEY's 15R + R0 minus its X part: reads HV, X, xi, y, writes xi, X,
+      // a); the row kernel reads r_sp (R) and xi, HV, HV_old, y (3R + R0), writes xi (R) and the two spectra (2S).
+      case LPC_K_SPATIAL: b = e->fuse_rows ? 12.0 * R + R0 + 2.0 * S : (e->xhalf_rows ? 9.0 * R : 15.0 * R + R0); break;
+      case LPC_K_ROW_FWD: b = e->fuse_rows ? 0.0 : (e->xhalf_rows ? 5.0 * R + R0 + 2.0 * S : 2.0 * R + 2.0 * S); break;
       case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
       case LPC_K_COL_MID: b = 4.0 * S + Sc + eb * g.Hp * g.Wc; break;  // + H (complex) + |G| (real, one plane)
       case LPC_K_COL_A_INV: b = split ? 4.0 * S : 0.0; break;
@@ -1101,7 +1120,8 @@ int lpc_plan_info(lpc_handle e, char* buf, size_t n) {
   if (e->cfg.algo == LPC_ALGO_ADMM) {
     const bool reg = e->N1 > 1 && e->mid_reg && sizeof(real) == 4 && e->N2 == 24;
     s += reg ? ", middle in registers" : (e->static_mid ? ", LDS middle [static]" : ", LDS middle");
-    s += e->fuse_rows ? "; image-domain kernel fused into the forward rows" : "; stand-alone image-domain kernel";
+    s += e->fuse_rows ? "; image-domain kernel fused into the forward rows"
+                      : (e->xhalf_rows ? "; tiled TV / W kernel + X half inside the forward rows" : "; stand-alone image-domain kernel");
   }
   std::snprintf(buf, n, "%s", s.c_str());
   return 0;

@@ -85,6 +85,7 @@ struct lpc_engine {
   int static_prow = 0;     // ADMM PAIRED-row length served by a compile-time plan (960 | 2048), else 0
   bool rows_r16 = false;   // 4096-point rows as 16.16.16 instead of 8.8.8.8
   int static_rows = 0;     // length of the half-row transform when a compile-time plan serves it (lpc_sfft.h), else 0
+  bool xhalf_rows = false; // ADMM: xi / a = mu1 X - xi computed by the forward row kernel (k_admm_rows_fused<.., TVHALF = false>)
   bool fuse_rows = false;  // ADMM: the image-domain kernel is fused into the forward row pass (k_admm_rows_fused)
   bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (LPC_MID_LDS=1: off)
   bool rows_r2 = false; // row plans end in a radix-2 stage: fold it into the Hermitian (un)tangling
@@ -267,6 +268,7 @@ static inline int with_row_shape(const lpc_engine* e, F&& f) {
 int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int kid);
 int rows_inv_single(Engine* e, const real2* S, const RealDst& dst, int nplanes, int kid);
 int admm_rows_fwd(Engine* e);                                   // e->Rsp, e->Aarr -> the two work spectra
+int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc);          // e->Rsp and (xi, HV, HV_old, y) -> the two work spectra
 int admm_rows_inv(Engine* e, real* Vout, real* HVout);          // the two work spectra -> V, H V
 int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real* Vo);   // k_admm_rows_fused
 // lpc_cols.cpp

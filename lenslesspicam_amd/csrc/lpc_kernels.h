@@ -1074,7 +1074,9 @@ static __device__ __forceinline__ void tv_component2(const AdmmScalars& p, v2f v
   q = p.mu2 * un - eta;
 }
 
-template <int TH, int NT>
+// XHALF == false: the TV / W half only (eta, rho, r_sp); xi and a = mu1 X - xi are then produced by the forward row
+// kernel itself (k_rfwd_half_x), which needs nothing but its own row for them.
+template <int TH, int NT, bool XHALF = true>
 __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars p,
                                                          const float* LPC_RESTRICT V,
                                                          const float* LPC_RESTRICT Vold,
@@ -1135,11 +1137,12 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
     const long o_dn = poff + (long)wrap_r(gr + 1) * g.rpitch + gc;        // eta0 of the row below
     const long o_rt = poff + (long)gr * g.rpitch + wrap_c(gc + 4);        // eta1 of the pixel right of the quad
     // global loads first (all independent)
-    const float4 hv4 = ld4(HV + o), xi4 = ld4(xi + o), rho4 = ld4(rho + o);
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 hv4 = XHALF ? ld4(HV + o) : z4, xi4 = XHALF ? ld4(xi + o) : z4, rho4 = ld4(rho + o);
     const float4 e04 = ld4(eta0 + o), e14 = ld4(eta1 + o), e0d4 = ld4(eta0 + o_dn);
     const float e1r = eta1[o_rt];
-    float4 ho4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (!p.first) ho4 = ld4(HVold + o);      // previous H V: lets the previous X be recomputed instead of stored
+    float4 ho4 = z4;
+    if (XHALF && !p.first) ho4 = ld4(HVold + o);      // previous H V: lets the previous X be recomputed instead of stored
     // the image estimate as the W-update sees it: differs from V only for the two iterations that follow
     // an in-place clamp by _form_image (admm.py:331-338), see lpc_form_image
     float4 vwc4 = make_float4(0.f, 0.f, 0.f, 0.f), vwo4 = vwc4;
@@ -1179,10 +1182,12 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
       float xiv = xis[i], rhov = rhs[i];
       const int cc = gc + i;
       const bool inside = row_in && (cc >= g.sw) && (cc < g.sw + g.W);
-      const float yv = inside ? y[(long)(gr - g.sh) * g.W + (cc - g.sw)] : 0.f;
+      const float yv = (XHALF && inside) ? y[(long)(gr - g.sh) * g.W + (cc - g.sw)] : 0.f;
       if (!p.first) {
-        const float xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
-        xiv = xiv + p.mu1p * (hv - xo);
+        if (XHALF) {
+          const float xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
+          xiv = xiv + p.mu1p * (hv - xo);
+        }
         const float wo = fmaxf(div_by(rhov, p.mu3p, p.r_mu3p) + (VWo ? vwos[i] : ocs[i + 1]), 0.f);
         rhov = rhov + p.mu3p * (vc - wo);
       }
@@ -1194,12 +1199,12 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
       rs[i] = (p.mu3 * wn - rhov) + (d1 + d2);
       as[i] = p.mu1 * xnew - xiv;
     }
-    st4(xi + o, make_float4(xin[0], xin[1], xin[2], xin[3]));
+    if (XHALF) st4(xi + o, make_float4(xin[0], xin[1], xin[2], xin[3]));
     st4(rho + o, make_float4(rhn[0], rhn[1], rhn[2], rhn[3]));
     st4(eta0_out + o, make_float4(e0n[0], e0n[1], e0n[2], e0n[3]));
     st4(eta1_out + o, make_float4(e1n[0], e1n[1], e1n[2], e1n[3]));
     st4(Rsp + o, make_float4(rs[0], rs[1], rs[2], rs[3]));
-    st4(Aout + o, make_float4(as[0], as[1], as[2], as[3]));
+    if (XHALF) st4(Aout + o, make_float4(as[0], as[1], as[2], as[3]));
   }
 }
 
@@ -1214,7 +1219,12 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
 // k_admm_spatial_v4.  The rows above / below are re-read from L2: blocks are handed out
 // in an XCD-aware order (block b runs on XCD b % 8: each XCD gets a contiguous band of rows), so rows r and r+1 are
 // in flight together on ONE L2.  grid = (2 * Hp, planes); `plan` has length Wp/2, `twW` is the length-Wp table.
-template <int NT, int EMAX, bool SK, int UNR = 1, int MINW = 1, class PL = Fft1dPlan>
+// TVHALF == false ("X half only", the default launch sequence): block (row, 0) transforms the row of r_sp that the tiled
+// image-domain kernel (k_admm_spatial_v4<.., XHALF = false>) wrote, exactly like k_rfwd_half; only `a` and the xi update
+// -- which need no neighbours -- ride in the row kernel: the tiled kernel no longer touches xi, HV, HV_old, y and `a`
+// makes no round trip through HBM (-2R per iteration), while the stencil half keeps its own occupancy.  `Vold` then
+// carries the r_sp array.
+template <int NT, int EMAX, bool SK, int UNR = 1, int MINW = 1, class PL = Fft1dPlan, bool TVHALF = true>
 __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmScalars p, PL plan,
                                                          const real2* LPC_RESTRICT twW,
                                                          const float* LPC_RESTRICT V, const float* LPC_RESTRICT Vold,
@@ -1236,6 +1246,15 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
   const long poff = pl * g.rplane;
   const long o_row = poff + (long)gr * g.rpitch;
   const int n4 = g.Wp >> 2;
+  if constexpr (!TVHALF) {
+    if (arr == 0) {      // the stored row of r_sp: first stage fused into the fill, like k_rfwd_half
+      const real2* a2 = (const real2*)(Vold + o_row);
+      auto src = [&](int i, int) { return a2[i]; };
+      fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
+      untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, SA + pl * g.cplane + (long)gr * g.cpitch, tid);
+      return;
+    }
+  }
 #ifdef LPC_DEBUG_KNOBS   // timing experiments only: MINW == 3 skips the image-domain half (the tile is filled with junk)
   if (MINW == 3) {
     for (int q = tid; q < n4; q += NT) {
@@ -1244,7 +1263,7 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
     }
   } else
 #endif
-  if (arr == 0) {
+  if (TVHALF && arr == 0) {
     const long o_up = poff + (long)(gr == 0 ? g.Hp - 1 : gr - 1) * g.rpitch;
     const long o_dn = poff + (long)(gr + 1 == g.Hp ? 0 : gr + 1) * g.rpitch;
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);

@@ -97,6 +97,31 @@ int admm_rows_fwd(Engine* e) {
   });
 }
 
+// ---- ADMM: forward rows of r_sp (stored) and of a = mu1 X - xi' (computed here from xi, HV, HV_old, y) -------------
+int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc) {
+#ifdef LPC_DOUBLE
+  (void)sc;
+  return fail("internal: the X-half row kernel is float32-only");
+#else
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  return with_row_shape(e, [&](auto SHc) {
+    using SH = decltype(SHc);
+    using PA = SPlanArg<typename SH::plan>;
+    return with_sk(e->static_sk, [&](auto SKc) {
+      constexpr bool sk = decltype(SKc)::value;
+      return launch_k(e, LPC_K_ROW_FWD, k_admm_rows_fused<SH::nt, SH::em, sk, 1, 1, PA, false>, dim3(2 * g.Hp, e->P),
+                      SH::nt, LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, sc, splan_arg<typename SH::plan>(e->planWh),
+                      (const real2*)e->planW.tw, (const real*)nullptr, (const real*)e->Rsp,
+                      (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)nullptr,
+                      (const real*)nullptr, (real*)nullptr, (real*)nullptr, (real*)nullptr, (const real*)e->Y, SA, SB,
+                      (const real*)nullptr, (const real*)nullptr);
+    });
+  });
+#endif
+}
+
 // ---- ADMM: the image-domain kernel fused into the forward rows (float32, half-length rows, Wp % 4 == 0) -------
 int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real* Vo) {
 #ifdef LPC_DOUBLE

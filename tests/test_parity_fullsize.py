@@ -133,10 +133,24 @@ def test_c4_batch64_vs_oracle_and_singles(c4_inputs):
         o = orc.ADMMOracle(psf)
         o.set_data(frames[b])
         assert rel(full[b], o.apply(20)) <= 1e-5, b
-    single = lpa.ADMM(psf_d)
-    for b in range(64):                                        # batch == singles, bit for bit
+    # batch == singles (test/test_algos.py:198-229).  Bit for bit when the single-frame solver runs the kernels the
+    # batch ran: the engine picks the sequential 16-column middle for large batches only, LPC_MID_SEQ selects it for one
+    # frame too.  The default single-frame plan (two spectra side by side, 8 columns each) is another instruction
+    # stream for the same arithmetic: equal to float32 round-off.
+    os.environ["LPC_MID_SEQ"] = "1"
+    try:
+        single = lpa.ADMM(psf_d)
+    finally:
+        del os.environ["LPC_MID_SEQ"]
+    assert "T = 16" in single._handle.plan_info() and "T = 16" in rec._handle.plan_info()
+    for b in range(64):
         single.set_data(frames_d[b])
         assert torch.equal(single.apply(n_iter=20, disp_iter=None), full[b]), b
+    plain = lpa.ADMM(psf_d)
+    assert "T = 8" in plain._handle.plan_info()
+    for b in (0, 31, 63):
+        plain.set_data(frames_d[b])
+        assert rel(plain.apply(n_iter=20, disp_iter=None), full[b]) <= 2e-6, b
 
 
 def test_c4_sharded_through_rccl_world1(c4_inputs):
