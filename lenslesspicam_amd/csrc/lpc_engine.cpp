@@ -221,11 +221,7 @@ static int setup_geometry(Engine* e) {
   // plans of round 1 the forward rows took 0.61 ms and fusion won, 202 vs 196 it/s.)
   e->fuse_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && e->rows_half && g.Wp % 4 == 0 &&
                  std::getenv("LPC_FUSE_ROWS") && !std::getenv("LPC_K1_SCALAR");
-  // The half of it that needs no neighbours IS fused by default where a compile-time row plan exists: the forward row
-  // blocks of `a` compute xi' and a = mu1 X - xi' from xi, HV, HV_old, y themselves (-2R per iteration), the tiled
-  // kernel keeps the stencil half at its own occupancy.  LPC_NO_XHALF = the full stand-alone kernel.
-  e->xhalf_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && e->rows_half && g.Wp % 4 == 0 && e->static_rows &&
-                  !e->fuse_rows && !std::getenv("LPC_NO_XHALF") && !std::getenv("LPC_K1_SCALAR");
+
   LPC_OK(build_plan(e, e->planB, e->N2));
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
   e->static_sk = !std::getenv("LPC_ROWS_NOSKEW");
@@ -242,6 +238,12 @@ static int setup_geometry(Engine* e) {
     if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan960::matches(e->planW)) e->static_prow = 960;
     if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan2048::matches(e->planW)) e->static_prow = 2048;
   }
+  // The half of the image-domain work that needs no neighbours IS fused by default where a compile-time row plan
+  // exists: the forward row blocks of `a` compute xi' and a = mu1 X - xi' from xi, HV, HV_old, y themselves (-2R per
+  // iteration), the tiled kernel keeps the stencil half at its own occupancy.  LPC_NO_XHALF = the full stand-alone kernel.
+  e->xhalf_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && g.Wp % 4 == 0 &&
+                  ((e->rows_half && e->static_rows) || (!e->rows_half && e->static_prow)) &&
+                  !e->fuse_rows && !std::getenv("LPC_NO_XHALF") && !std::getenv("LPC_K1_SCALAR");
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
   const int ntc = (g.Wc + e->T - 1) / e->T;
   ColPass& A = e->passA;

@@ -1424,6 +1424,43 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
   untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, (arr ? SB : SA) + pl * g.cplane + (long)gr * g.cpitch, tid);
 }
 
+// ---- paired forward rows with the X half computed on the fly (narrow frames: C1 / C4, 760 x 1014) ---------------
+// Same split of the image-domain work as k_admm_rows_fused<.., TVHALF = false>, for frames whose rows ride in pairs:
+// row r of r_sp (stored by k_admm_spatial_v4<.., XHALF = false>) is the real part, and the imaginary part
+// a = mu1 X - xi' is formed element by element from xi, HV, HV_old and y inside the source functor of the first FFT
+// stage (which also stores xi').  Compile-time plans only.
+template <int NT, int EMAX, bool SK, class PL>
+__global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p, PL plan, const float* LPC_RESTRICT Rsp,
+                                                       const float* LPC_RESTRICT HV, const float* LPC_RESTRICT HVold,
+                                                       float* LPC_RESTRICT xi, const float* LPC_RESTRICT Y,
+                                                       real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB) {
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int tid = threadIdx.x, row = blockIdx.x;
+  const long pl = blockIdx.y;
+  const long o_row = pl * g.rplane + (long)row * g.rpitch;
+  const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
+  const bool row_in = (row >= g.sh) && (row < g.sh + g.H);
+  const float* y = Y + (long)dpl * g.uplane + (long)(row - g.sh) * g.W;     // dereferenced only when row_in
+  auto src = [&](int i, int) {
+    const long o = o_row + i;
+    const bool inside = row_in && (i >= g.sw) && (i < g.sw + g.W);
+    const float yv = inside ? y[i - g.sw] : 0.f;
+    const float hv = HV[o];
+    float xiv = xi[o];
+    if (!p.first) {
+      const float xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * HVold[o] + yv);   // previous X
+      xiv = xiv + p.mu1p * (hv - xo);
+    }
+    const float xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
+    xi[o] = xiv;
+    return make_real2(Rsp[o], p.mu1 * xnew - xiv);
+  };
+  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
+  untangle_store<NT, SK>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
+                         SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
+}
+
 #endif  // !LPC_DOUBLE
 
 // ---- plug-and-play ADMM: the U-prox is an external denoiser (admm.py:126-133,235-243,266-275,300-311) ----------

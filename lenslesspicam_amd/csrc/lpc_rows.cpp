@@ -106,6 +106,18 @@ int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
+  if (!e->rows_half) {     // paired rows (static_prow): 960 = 256 threads x 4, 2048 = 256 x 8
+    auto go = [&](auto plan_tag, auto em_tag) {
+      using P = decltype(plan_tag);
+      constexpr int em = decltype(em_tag)::value;
+      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<256, em, true, SPlanArg<P>>, dim3(g.Hp, e->P), 256,
+                      LPC_ROW_SMEM_BYTES(P::n, true), g, sc, splan_arg<P>(e->planW), (const real*)e->Rsp,
+                      (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->Y, SA, SB);
+    };
+    if (e->static_prow == 960) return go(RowPlan960{}, std::integral_constant<int, 4>{});
+    if (e->static_prow == 2048) return go(RowPlan2048{}, std::integral_constant<int, 8>{});
+    return fail("internal: no static paired-row plan");
+  }
   return with_row_shape(e, [&](auto SHc) {
     using SH = decltype(SHc);
     using PA = SPlanArg<typename SH::plan>;
