@@ -349,7 +349,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "fused ADMM prox / dual-update kernel (LPC_K_SPATIAL)" if args.algo == "admm"
+                "kernel": ("LPC_K_SPATIAL = ADMM prox / dual-update kernel; split of the image-domain work: "
+                           + rec._handle.plan_info().split(";")[-1].strip()) if args.algo == "admm"
                 else "k_rinv_gd_update (inverse rows + fused projected update)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
