@@ -327,8 +327,11 @@ static int check_channels(const Engine* e, int ch, const char* who) {
 static int planar_to_hwc(Engine* e, real* src, real* dst, int nimg, int rows, int cols, int pitch, long splane,
                          int row0, int col0, int clamp) {
   const long n = (long)rows * cols * e->cfg.channels;
+  // clamp: 0 none, 1 everywhere, 2 inside the sensor window only (rows / cols then span the padded frame)
+  const PlaneGeom& g = e->g;
   return launch_k(e, -1, k_planar_to_hwc<256>, grid1d(n, 256, nimg), 256, 0, src, dst, rows, cols,
-                  e->cfg.channels, pitch, splane, row0, col0, clamp, 0);
+                  e->cfg.channels, pitch, splane, row0, col0, clamp, 0, clamp == 2 ? g.sh : 0,
+                  clamp == 2 ? g.sh + g.H : rows, clamp == 2 ? g.sw : 0, clamp == 2 ? g.sw + g.W : cols);
 }
 
 // ------------------------------------------------------------------------------ ADMM --
@@ -356,6 +359,8 @@ static AdmmScalars admm_scalars(const Engine* e, const double cur[4]) {
   p.m_out_p = (real)1.0 / ((real)0.0 + p.mu1p);
   p.r_mu2 = (real)(1.0 / (double)p.mu2); p.r_mu3 = (real)(1.0 / (double)p.mu3);      // RN(1/d): see div_by
   p.r_mu2p = (real)(1.0 / (double)p.mu2p); p.r_mu3p = (real)(1.0 / (double)p.mu3p);
+  p.clamp_cur = e->vw_cur ? 1 : 0;
+  p.clamp_old = e->vw_old ? 1 : 0;
   return p;
 }
 
@@ -458,23 +463,19 @@ static int admm_iterate(Engine* e, int n_iter) {
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT, false>, k1_grid4, NT, k1_smem4, g, sc, (const real*)Vc,
                       (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
                       (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
-                      (const real*)e->Y, e->Rsp, e->Aarr, tiles_x4,
-                      (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
+                      (const real*)e->Y, e->Rsp, e->Aarr, tiles_x4));
     else if (vec4)
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4, NT>, k1_grid4, NT, k1_smem4, g, sc, (const real*)Vc,
                       (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
                       (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
-                      (const real*)e->Y, e->Rsp, e->Aarr, tiles_x4,
-                      (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
+                      (const real*)e->Y, e->Rsp, e->Aarr, tiles_x4));
     else
 #endif
     LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial<TH, TW, NT>, k1_grid, NT, k1_smem, g, sc, (const real*)Vc,
                     (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
                     (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
-                    (const real*)e->Y, e->Rsp, e->Aarr, tiles_x,
-                    (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr)));
-    std::swap(e->Vw[0], e->Vw[1]);  // this iteration's "V for W" becomes the next one's "V_old for W_old"
-    e->vw_old = e->vw_cur;
+                    (const real*)e->Y, e->Rsp, e->Aarr, tiles_x));
+    e->vw_old = e->vw_cur;          // this iteration's "V as W saw it" becomes the next one's "V_old as W_old saw it"
     e->vw_cur = false;
     e->ecur ^= 1;
     e->first = false;
@@ -806,15 +807,9 @@ int lpc_form_image(lpc_handle e, real* dev_out, void* stream) {
   }
   if (e->cfg.algo == LPC_ALGO_ADMM) {  // crop + clamp (admm.py:331-338)
     LPC_OK(planar_to_hwc(e, e->V[e->vcur], dev_out, nimg, g.H, g.W, g.rpitch, g.rplane, g.sh, g.sw, 1));
-    // ... which the reference applies IN PLACE to its state: remember the clamped estimate for the
-    // W-updates of the next two iterations (everything else keeps using the un-clamped V, exactly
-    // like the reference's cached _Psi_out / _forward_out do)
-    if (!e->Vw[0]) {
-      LPC_OK(dev_alloc(e, &e->Vw[0], (size_t)g.rplane * e->P));
-      LPC_OK(dev_alloc(e, &e->Vw[1], (size_t)g.rplane * e->P));
-    }
-    LPC_OK(launch_k(e, -1, k_clamp_window_copy<256>, grid1d((long)g.Hp * g.rpitch, 256, e->P), 256, 0, g,
-                    (const real*)e->V[e->vcur], e->Vw[0]));
+    // ... which the reference applies IN PLACE to its state: the W-updates of the next two iterations see the clamped
+    // estimate (everything else keeps using the un-clamped V, exactly like the reference's cached _Psi_out /
+    // _forward_out do).  clamp(V) is recomputed where it is needed (AdmmScalars::clamp_cur / clamp_old): no copy.
     e->vw_cur = true;
     return 0;
   }
@@ -845,35 +840,32 @@ int lpc_get_state(lpc_handle e, const char* name, real* dev_out, void* stream) {
     if (nm == "W") return out_padded(e->eta1[1]);
     return fail("lpc_get_state: unknown name '" + nm + "'");
   }
-  if (nm == "image_est") return out_padded(e->vw_cur ? e->Vw[0] : e->V[e->vcur]);
+  if (nm == "image_est")     // after a read-out: the clamped estimate, like the reference's attribute
+    return planar_to_hwc(e, e->V[e->vcur], dev_out, nimg, g.Hp, g.Wp, g.rpitch, g.rplane, 0, 0, e->vw_cur ? 2 : 0);
   if (nm == "forward_out") return out_padded(e->HVb[e->hcur]);
-  // the rest needs the pending dual update applied: materialise into scratch
-  const long ostride = (long)g.rplane * e->P;
-  real* scratch = nullptr;
-  LPC_RT(rt::dev_malloc((void**)&scratch, (size_t)ostride * 8 * sizeof(real)));
+  // the rest needs the pending dual update applied: materialise what was asked for into the two padded arrays that are
+  // idle between iterations (r_sp and a: no allocation, no host synchronisation)
+  int w0 = -1, w1 = -1;
+  if (nm == "xi") w0 = 0;
+  else if (nm == "rho") w0 = 3;
+  else if (nm == "W") w0 = 6;
+  else if (nm == "X") w0 = 7;
+  else if (nm == "eta") { w0 = 1; w1 = 2; }
+  else if (nm == "U") { w0 = 4; w1 = 5; }
+  else return fail("lpc_get_state: unknown name '" + nm + "'");
   double par[4];
   admm_params(e, e->iters_done, par);
   AdmmScalars sc = admm_scalars(e, par);
-  int rc = launch_k(e, -1, k_admm_flush<256>, grid1d((long)g.Hp * g.Wp, 256, e->P), 256, 0, g, sc,
-                    (const real*)e->V[e->vcur], (const real*)e->V[e->vcur ^ 1], (const real*)e->HVb[e->hcur],
-                    (const real*)e->HVb[e->hcur ^ 1], (const real*)e->Y, (const real*)e->xi, (const real*)e->eta0[e->ecur],
-                    (const real*)e->eta1[e->ecur], (const real*)e->rho, scratch, ostride,
-                    (const real*)(e->vw_old ? e->Vw[1] : nullptr));
-  if (!rc) {
-    if (nm == "xi") rc = out_padded(scratch + 0 * ostride);
-    else if (nm == "rho") rc = out_padded(scratch + 3 * ostride);
-    else if (nm == "W") rc = out_padded(scratch + 6 * ostride);
-    else if (nm == "X") rc = out_padded(scratch + 7 * ostride);
-    else if (nm == "eta" || nm == "U") {
-      real* a = scratch + (nm == "eta" ? 1 : 4) * ostride;
-      const long n = (long)g.Hp * g.Wp * e->cfg.channels;
-      rc = launch_k(e, -1, k_planar2_to_hwc2<256>, grid1d(n, 256, nimg), 256, 0, (const real*)a,
-                    (const real*)(a + ostride), dev_out, g.Hp, g.Wp, e->cfg.channels, g.rpitch, g.rplane);
-    } else rc = fail("lpc_get_state: unknown name '" + nm + "'");
-  }
-  (void)rt::stream_sync(e->stream);
-  (void)rt::dev_free(scratch);
-  return rc;
+  sc.clamp_old = e->vw_old ? 1 : 0;
+  LPC_OK(launch_k(e, -1, k_admm_flush<256>, grid1d((long)g.Hp * g.Wp, 256, e->P), 256, 0, g, sc,
+                  (const real*)e->V[e->vcur], (const real*)e->V[e->vcur ^ 1], (const real*)e->HVb[e->hcur],
+                  (const real*)e->HVb[e->hcur ^ 1], (const real*)e->Y, (const real*)e->xi, (const real*)e->eta0[e->ecur],
+                  (const real*)e->eta1[e->ecur], (const real*)e->rho, e->Rsp, w1 >= 0 ? e->Aarr : (real*)nullptr, w0,
+                  w1 >= 0 ? w1 : 0));
+  if (w1 < 0) return out_padded(e->Rsp);
+  const long n = (long)g.Hp * g.Wp * e->cfg.channels;
+  return launch_k(e, -1, k_planar2_to_hwc2<256>, grid1d(n, 256, nimg), 256, 0, (const real*)e->Rsp,
+                  (const real*)e->Aarr, dev_out, g.Hp, g.Wp, e->cfg.channels, g.rpitch, g.rplane);
 }
 
 // ---- evaluation reductions (section 8f row N2): nothing here synchronises with the host ----

@@ -109,10 +109,9 @@ struct lpc_engine {
         *Rsp = nullptr, *Aarr = nullptr;
   real *eta0[2] = {nullptr, nullptr}, *eta1[2] = {nullptr, nullptr};  // ping-pong (halo reads)
   int vcur = 0, ecur = 0, hcur = 0;  // HVb[hcur] = H V of the current estimate, HVb[hcur^1] = of the previous one
-  // the reference clamps the image estimate IN PLACE whenever _form_image runs (admm.py:331-338);
-  // only the W-update ever sees that clamped copy: Vw[0] = V as seen by the next iteration's W,
-  // Vw[1] = V as seen by the previous iteration's W (needed to recompute W_old).  Null = same as V.
-  real* Vw[2] = {nullptr, nullptr};
+  // the reference clamps the image estimate IN PLACE whenever _form_image runs (admm.py:331-338); only the W-update ever
+  // sees that clamped copy, and it is a pure function of V: vw_cur = the next iteration's W sees clamp(V),
+  // vw_old = the previous iteration's W saw clamp(V_old) (needed to recompute W_old) -- AdmmScalars::clamp_cur / _old
   bool vw_cur = false, vw_old = false;
   // GD family state (un-padded planes)
   real *gx = nullptr, *gaux = nullptr;  // x and (p | xk_prev)

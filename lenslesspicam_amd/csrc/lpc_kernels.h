@@ -873,7 +873,16 @@ struct AdmmScalars {
   real m_in_p, m_out_p;  // X_divmat of the previous iteration (its X is recomputed, never stored)
   // correctly rounded reciprocals of the step sizes the kernels divide by (see div_by)
   real r_mu2, r_mu3, r_mu2p, r_mu3p;
+  // The reference clamps the image estimate IN PLACE whenever _form_image runs (admm.py:331-338: negative entries of
+  // the sensor window become 0), and only the W-update ever sees that clamped copy (everything else works from the
+  // cached Psi V / H V).  The clamp is a pure function of V, so no copy is kept: clamp_cur / clamp_old say that the
+  // W-update of this / of the previous iteration saw clamp(V) / clamp(V_old).
+  int clamp_cur, clamp_old;
 };
+// the estimate as the W-update saw it
+static __device__ __forceinline__ real w_sees(real v, bool clamped, bool inside) {
+  return (clamped && inside && v < (real)0.) ? (real)0. : v;
+}
 
 // x / d for a wave-uniform divisor d whose reciprocal r = RN(1 / d) was rounded on the host: one Newton step on
 // q0 = RN(x r) with the exact residual (Markstein's sequence), q = RN(q0 + RN(x - d q0) r), is the correctly
@@ -921,8 +930,7 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
                                                       real* LPC_RESTRICT rho,
                                                       const real* LPC_RESTRICT Y,
                                                       real* LPC_RESTRICT Rsp, real* LPC_RESTRICT Aout,
-                                                      unsigned tiles_x, const real* LPC_RESTRICT VWc,
-                                                      const real* LPC_RESTRICT VWo) {
+                                                      unsigned tiles_x) {
   LPC_DYN_SMEM(smem);
   constexpr int VW = TW + 2, VH = TH + 2;
   real* sV = (real*)smem;                 // [VH][VW], local (ly+1, lx+1)
@@ -1010,11 +1018,11 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
       // X of the previous iteration, recomputed bit-for-bit from what it was computed from (admm.py:252-254)
       const real xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * HVold[o] + yv);
       xiv = xiv + p.mu1p * (hv - xo);
-      const real wo = rmax(div_by(rhov, p.mu3p, p.r_mu3p) + (VWo ? VWo[o] : sO[li]), (real)0);
+      const real wo = rmax(div_by(rhov, p.mu3p, p.r_mu3p) + w_sees(sO[li], p.clamp_old, inside), (real)0);
       rhov = rhov + p.mu3p * (vc - wo);
     }
     const real xn = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
-    const real wn = rmax(div_by(rhov, p.mu3, p.r_mu3) + (VWc ? VWc[o] : vc), (real)0);
+    const real wn = rmax(div_by(rhov, p.mu3, p.r_mu3) + w_sees(vc, p.clamp_cur, inside), (real)0);
     const real d1 = sQ0[(ly + 1) * TW + lx] - sQ0[ly * TW + lx];
     const real d2 = sQ1[ly * (TW + 1) + lx + 1] - sQ1[ly * (TW + 1) + lx];
     xi[o] = xiv;
@@ -1089,8 +1097,7 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
                                                          float* LPC_RESTRICT rho,
                                                          const float* LPC_RESTRICT Y,
                                                          float* LPC_RESTRICT Rsp, float* LPC_RESTRICT Aout,
-                                                         unsigned tiles_x, const float* LPC_RESTRICT VWc,
-                                                         const float* LPC_RESTRICT VWo) {
+                                                         unsigned tiles_x) {
   LPC_DYN_SMEM(smem);
   constexpr int TW = 256, LP = TW + 8;          // LDS row: [3] = col -1, [4..259] = cols 0..255, [260] = col 256
   constexpr int VH = TH + 2;
@@ -1143,12 +1150,6 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
     const float e1r = eta1[o_rt];
     float4 ho4 = z4;
     if (XHALF && !p.first) ho4 = ld4(HVold + o);      // previous H V: lets the previous X be recomputed instead of stored
-    // the image estimate as the W-update sees it: differs from V only for the two iterations that follow
-    // an in-place clamp by _form_image (admm.py:331-338), see lpc_form_image
-    float4 vwc4 = make_float4(0.f, 0.f, 0.f, 0.f), vwo4 = vwc4;
-    if (VWc) vwc4 = ld4(VWc + o);
-    if (VWo) vwo4 = ld4(VWo + o);
-    const float vwcs[4] = {vwc4.x, vwc4.y, vwc4.z, vwc4.w}, vwos[4] = {vwo4.x, vwo4.y, vwo4.z, vwo4.w};
     // LDS neighbourhood: rows ly-1, ly, ly+1 of the quad, plus the pixel left and right of it
     const float* rowm = sV + ly * LP + 4 + 4 * lane;        // global row gr-1  (local ly)
     const float* rowc = rowm + LP;                          // gr
@@ -1188,11 +1189,11 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
           const float xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
           xiv = xiv + p.mu1p * (hv - xo);
         }
-        const float wo = fmaxf(div_by(rhov, p.mu3p, p.r_mu3p) + (VWo ? vwos[i] : ocs[i + 1]), 0.f);
+        const float wo = fmaxf(div_by(rhov, p.mu3p, p.r_mu3p) + w_sees(ocs[i + 1], p.clamp_old, inside), 0.f);
         rhov = rhov + p.mu3p * (vc - wo);
       }
       const float xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
-      const float wn = fmaxf(div_by(rhov, p.mu3, p.r_mu3) + (VWc ? vwcs[i] : vc), 0.f);
+      const float wn = fmaxf(div_by(rhov, p.mu3, p.r_mu3) + w_sees(vc, p.clamp_cur, inside), 0.f);
       const float d1 = q0d - q0c;
       const float d2 = q1[i + 1] - q1[i];
       xin[i] = xiv; rhn[i] = rhov;
@@ -1233,8 +1234,7 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
                                                          const float* LPC_RESTRICT eta1, float* LPC_RESTRICT eta0_out,
                                                          float* LPC_RESTRICT eta1_out, float* LPC_RESTRICT rho,
                                                          const float* LPC_RESTRICT Y, real2* LPC_RESTRICT SA,
-                                                         real2* LPC_RESTRICT SB, const float* LPC_RESTRICT VWc,
-                                                         const float* LPC_RESTRICT VWo) {
+                                                         real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
@@ -1290,10 +1290,8 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
     auto do_quad = [&](const Quad& c, int q, auto vw_tag) {
       constexpr bool VW = decltype(vw_tag)::value;
       const int gc = 4 * q;
-      float4 vwc4 = z4, vwo4 = z4;      // only for the two iterations after a read-out clamped the estimate
-      if (VW && VWc) vwc4 = ld4(VWc + o_row + gc);
-      if (VW && VWo) vwo4 = ld4(VWo + o_row + gc);
-      const float vwcs[4] = {vwc4.x, vwc4.y, vwc4.z, vwc4.w}, vwos[4] = {vwo4.x, vwo4.y, vwo4.z, vwo4.w};
+      // only for the two iterations after a read-out clamped the estimate: what the W-update saw (w_sees)
+      const bool rin = VW && (gr >= g.sh) && (gr < g.sh + g.H);
       const float vcs[6] = {c.vl, c.vc.x, c.vc.y, c.vc.z, c.vc.w, c.vr};       // cols gc-1 .. gc+4 of row gr
       const float ocs[6] = {c.ol, c.oc.x, c.oc.y, c.oc.z, c.oc.w, c.orr};
       const float vms[4] = {c.vm.x, c.vm.y, c.vm.z, c.vm.w}, vps[4] = {c.vp.x, c.vp.y, c.vp.z, c.vp.w};
@@ -1324,12 +1322,16 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
         e0n[i] = en.x; e0n[i + 1] = en.y;
         v2f rhov = mk2(rhs[i], rhs[i + 1]);
         if (!p.first) {
-          const v2f vo2 = (VW && VWo) ? mk2(vwos[i], vwos[i + 1]) : oc2;
+          const v2f vo2 = VW ? mk2(w_sees(oc2.x, p.clamp_old, rin && gc + i >= g.sw && gc + i < g.sw + g.W),
+                                   w_sees(oc2.y, p.clamp_old, rin && gc + i + 1 >= g.sw && gc + i + 1 < g.sw + g.W))
+                             : oc2;
           const v2f t = div_by2(rhov, p.mu3p, p.r_mu3p) + vo2;
           const v2f wo = mk2(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f));
           rhov = rhov + p.mu3p * (vc2 - wo);
         }
-        const v2f vw2 = (VW && VWc) ? mk2(vwcs[i], vwcs[i + 1]) : vc2;
+        const v2f vw2 = VW ? mk2(w_sees(vc2.x, p.clamp_cur, rin && gc + i >= g.sw && gc + i < g.sw + g.W),
+                                 w_sees(vc2.y, p.clamp_cur, rin && gc + i + 1 >= g.sw && gc + i + 1 < g.sw + g.W))
+                           : vc2;
         const v2f t = div_by2(rhov, p.mu3, p.r_mu3) + vw2;
         const v2f wn = mk2(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f));
         const v2f d1 = q0d - q0c;
@@ -1348,7 +1350,7 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
     // quad: 176 VGPRs, 2 workgroups per CU; first-touch rows only: 142 VGPRs) is SLOWER than this plain loop at 70
     // VGPRs and 4 workgroups per CU (1.84 vs 2.21 / 1.98 ms): the kernel is bound by instruction issue (VALU 38 %,
     // all instructions 55 % of every SIMD cycle, PMC), not by exposed latency.
-    if (!VWc && !VWo) {
+    if (!p.clamp_cur && !p.clamp_old) {
 #pragma unroll 1
       for (int q = tid; q < n4; q += NT) do_quad(load_quad(q), q, std::false_type{});
     } else {
@@ -1533,9 +1535,10 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
                                                     const real* LPC_RESTRICT xi,
                                                     const real* LPC_RESTRICT eta0,
                                                     const real* LPC_RESTRICT eta1,
-                                                    const real* LPC_RESTRICT rho, real* LPC_RESTRICT out,
-                                                    long ostride, const real* LPC_RESTRICT VWo) {
-  // out planes of size ostride*: 0 xi', 1 eta0', 2 eta1', 3 rho', 4 U0, 5 U1, 6 W, 7 X
+                                                    const real* LPC_RESTRICT rho, real* LPC_RESTRICT out0,
+                                                    real* LPC_RESTRICT out1, int which0, int which1) {
+  // quantities: 0 xi', 1 eta0', 2 eta1', 3 rho', 4 U0, 5 U1, 6 W, 7 X; out0 receives `which0`, out1 (if not null)
+  // `which1` -- the caller asks for what it reads out, the scratch is two padded arrays the loop leaves idle
   const long n = (long)g.Hp * g.Wp;
   const long pl = blockIdx.y;
   for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
@@ -1553,20 +1556,15 @@ __global__ __launch_bounds__(NT) void k_admm_flush(PlaneGeom g, AdmmScalars p,
       const real oc = Vold[o], vc = V[o];
       u0 = soft_thresh_dev((Vold[ou] - oc) + div_by(e0, p.mu2p, p.r_mu2p), p.thrp);
       u1 = soft_thresh_dev((Vold[ol] - oc) + div_by(e1, p.mu2p, p.r_mu2p), p.thrp);
-      w = rmax(div_by(rh, p.mu3p, p.r_mu3p) + (VWo ? VWo[o] : oc), (real)0.);
+      w = rmax(div_by(rh, p.mu3p, p.r_mu3p) + w_sees(oc, p.clamp_old, inside), (real)0.);
       xiv = xiv + p.mu1p * (HV[o] - x);
       e0 = e0 + p.mu2p * ((V[ou] - vc) - u0);
       e1 = e1 + p.mu2p * ((V[ol] - vc) - u1);
       rh = rh + p.mu3p * (vc - w);
     }
-    out[0 * ostride + o] = xiv;
-    out[1 * ostride + o] = e0;
-    out[2 * ostride + o] = e1;
-    out[3 * ostride + o] = rh;
-    out[4 * ostride + o] = u0;
-    out[5 * ostride + o] = u1;
-    out[6 * ostride + o] = w;
-    out[7 * ostride + o] = x;
+    const real val[8] = {xiv, e0, e1, rh, u0, u1, w, x};
+    out0[o] = val[which0];
+    if (out1) out1[o] = val[which1];
   }
 }
 
@@ -1595,7 +1593,8 @@ __global__ __launch_bounds__(NT) void k_hwc_to_planar(const real* LPC_RESTRICT s
 template <int NT>
 __global__ __launch_bounds__(NT) void k_planar_to_hwc(real* LPC_RESTRICT src, real* LPC_RESTRICT dst,
                                                        int rows, int cols, int C, int pitch, long splane,
-                                                       int row0, int col0, int clamp, int clamp_src) {
+                                                       int row0, int col0, int clamp, int clamp_src, int wr0, int wr1,
+                                                       int wc0, int wc1) {
   const long n = (long)rows * cols * C;
   const long img = blockIdx.y;
   for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
@@ -1605,7 +1604,7 @@ __global__ __launch_bounds__(NT) void k_planar_to_hwc(real* LPC_RESTRICT src, re
     const int row = (int)(rc / cols);
     const long so = (img * C + c) * splane + (long)(row0 + row) * pitch + (col0 + col);
     real v = src[so];
-    if (clamp && v < (real)0.) {
+    if (clamp && v < (real)0. && row >= wr0 && row < wr1 && col >= wc0 && col < wc1) {   // [wr0,wr1) x [wc0,wc1): where
       v = (real)0.;
       if (clamp_src) src[so] = (real)0.;
     }
@@ -1613,21 +1612,8 @@ __global__ __launch_bounds__(NT) void k_planar_to_hwc(real* LPC_RESTRICT src, re
   }
 }
 
-// dst = src with the sensor window clamped at 0 (the reference's in-place clamp of ADMM._form_image)
-template <int NT>
-__global__ __launch_bounds__(NT) void k_clamp_window_copy(PlaneGeom g, const real* LPC_RESTRICT src,
-                                                           real* LPC_RESTRICT dst) {
-  const long n = (long)g.Hp * g.rpitch;
-  const long pl = blockIdx.y;
-  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
-    const int r = (int)(e / g.rpitch), c = (int)(e - (long)r * g.rpitch);
-    real v = src[pl * g.rplane + e];
-    if (r >= g.sh && r < g.sh + g.H && c >= g.sw && c < g.sw + g.W && v < (real)0.) v = (real)0.;
-    dst[pl * g.rplane + e] = v;
-  }
-}
-
-// the same clamp in place (plug-and-play ADMM keeps its image estimate in one explicit array)
+// the in-place clamp of ADMM._form_image on the sensor window (plug-and-play ADMM keeps its image estimate in one
+// explicit array; also applied to the stored initial estimate, see lpc_form_image)
 template <int NT>
 __global__ __launch_bounds__(NT) void k_clamp_window_inplace(PlaneGeom g, real* x) {
   const long n = (long)g.H * g.W;

@@ -127,8 +127,7 @@ int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc) {
                       SH::nt, LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, sc, splan_arg<typename SH::plan>(e->planWh),
                       (const real2*)e->planW.tw, (const real*)nullptr, (const real*)e->Rsp,
                       (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)nullptr,
-                      (const real*)nullptr, (real*)nullptr, (real*)nullptr, (real*)nullptr, (const real*)e->Y, SA, SB,
-                      (const real*)nullptr, (const real*)nullptr);
+                      (const real*)nullptr, (real*)nullptr, (real*)nullptr, (real*)nullptr, (const real*)e->Y, SA, SB);
     });
   });
 #endif
@@ -156,8 +155,7 @@ int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real
                           sc, splan_arg<typename SH::plan>(e->planWh), (const real2*)e->planW.tw, Vc, Vo,
                           (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi,
                           (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
-                          e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB,
-                          (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr));
+                          e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB);
         };
 #ifdef LPC_DEBUG_KNOBS
         if (std::getenv("LPC_DEBUG_FUSED_NOFFT")) return go(k_admm_rows_fused<SH::nt, SH::em, sk, 1, 2, PA>);
@@ -174,8 +172,7 @@ int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real
                     LPC_ROW_SMEM_BYTES(g.Wp / 2, false), g, sc, e->planWh, (const real2*)e->planW.tw, Vc, Vo,
                     (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi,
                     (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
-                    e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB,
-                    (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr));
+                    e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB);
   return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
     constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
     constexpr bool sk = decltype(SK)::value;
@@ -184,8 +181,7 @@ int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real
                       LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, sc, e->planWh, (const real2*)e->planW.tw, Vc, Vo,
                       (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi,
                       (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
-                      e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB,
-                      (const real*)(e->vw_cur ? e->Vw[0] : nullptr), (const real*)(e->vw_old ? e->Vw[1] : nullptr));
+                      e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB);
     };
     if constexpr (nt == 256 && em == 16 && sk) {
       if (unr == 2) return go(k_admm_rows_fused<nt, em, sk, 2>);
