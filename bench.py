@@ -320,7 +320,13 @@ def main():
         if os.path.exists(tf) and args.algo == "admm" and (H, W) == (3040, 4056):
             try:
                 tj = json.load(open(tf))
-                traffic = tj.get("hbm_bytes_per_launch")
+                # the counters must belong to the kernel this run launched as LPC_K_SPATIAL
+                xhalf = "X half" in rec._handle.plan_info()
+                fused = "fused into the forward rows" in rec._handle.plan_info()
+                kn = tj.get("kernel", "")
+                same = (fused and kn.startswith("k_admm_rows_fused")) or \
+                       (not fused and kn.startswith("k_admm_spatial") and (", false>" in kn) == xhalf)
+                traffic = tj.get("hbm_bytes_per_launch") if same else None
                 traffic_src = ("read from profiles/k1_traffic.json (separate rocprofv3 --pmc passes of "
                                f"{tj.get('kernel', 'the kernel')}, snapshot {tj.get('snapshot', '?')}; PMC counters cannot "
                                "be collected inside this run)")

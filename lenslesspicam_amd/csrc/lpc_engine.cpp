@@ -244,6 +244,7 @@ static int setup_geometry(Engine* e) {
   e->xhalf_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && g.Wp % 4 == 0 &&
                   ((e->rows_half && e->static_rows) || (!e->rows_half && e->static_prow)) &&
                   !e->fuse_rows && !std::getenv("LPC_NO_XHALF") && !std::getenv("LPC_K1_SCALAR");
+  e->gd_fuse_fwd = c.algo >= LPC_ALGO_GD && e->rows_half && e->static_rows && !std::getenv("LPC_GD_NO_FUSE_FWD");
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
   const int ntc = (g.Wc + e->T - 1) / e->T;
   ColPass& A = e->passA;
@@ -877,6 +878,7 @@ int lpc_reconstruction_error(lpc_handle e, const real* dev_pred, const real* dev
   e->stream = (lpcStream_t)stream;
   const PlaneGeom& g = e->g;
   const size_t up = (size_t)g.uplane * e->P;
+  e->gd_fwd_done = false;     // the work spectrum is about to be overwritten
   // two un-padded planar staging arrays out of buffers that are dead between iterations
   real *xin = nullptr, *xout = nullptr;
   if (e->cfg.algo == LPC_ALGO_ADMM) { xin = e->Rsp; xout = e->Aarr; }

@@ -129,6 +129,8 @@ struct lpc_engine {
   real* init_est = nullptr;  // planar copy of the initial estimate (or null)
   real* psf_planar = nullptr;
   bool has_init = false, psf_set = false, data_set = false, first = true;
+  bool gd_fwd_done = false;    // the row spectra of H x's input are already in S (written by the fused update kernel)
+  bool gd_fuse_fwd = false;    // gradient-descent family: update kernel + next forward rows in one launch
   bool split_pending = false;  // lpc_iterate_begin ran, lpc_iterate_end has not yet
   // plug-and-play ADMM (lpc_admm_pnp_begin / _end): explicit state in the arrays the fused path uses for the TV duals
   //   eta0[0] = eta, eta1[0] = U, eta0[1] = X, eta1[1] = W   (all image-shaped)
@@ -279,3 +281,4 @@ int admm_cols(Engine* e, const AdmmScalars& sc);                // [pass A] -> f
 struct GdScalars;
 int gd_rows_mid(Engine* e);                                     // irfft rows -> residual -> rfft rows (S -> S2)
 int gd_rows_update(Engine* e, const GdScalars& sc, const real* alpha);   // irfft rows -> fused projected update
+int gd_rows_update_fwd(Engine* e, const GdScalars& sc, const real* alpha);   // ... -> next iteration's forward rows (S)

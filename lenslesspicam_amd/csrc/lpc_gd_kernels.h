@@ -66,37 +66,42 @@ struct GdScalars {
   int split;       // 1: stop in front of the projection (plug-and-play hook, lpc_iterate_begin / _end)
 };
 
-static __device__ __forceinline__ void gd_update_one(real* LPC_RESTRICT X, real* LPC_RESTRICT AUX, long o,
+// returns the value stored in X[o] (the point the next iteration's forward model is evaluated at)
+static __device__ __forceinline__ real gd_update_one(real* LPC_RESTRICT X, real* LPC_RESTRICT AUX, long o,
                                                       real gr, real al, const GdScalars& p) {
   const real x = X[o];
   if (p.split) {   // everything up to `self._form_image()` of the three _update()s; k_gd_post finishes
+    real xs;
     if (p.kind == 1) {
       const real pp = AUX[o];
       const real pn = p.mu * pp - al * gr;
       AUX[o] = pn;
-      X[o] = x + (p.negmu * pp + p.onepmu * pn);
+      xs = x + (p.negmu * pp + p.onepmu * pn);
     } else {
-      const real x1 = x - al * gr;
-      X[o] = x1;
-      if (p.kind == 2 && p.first) AUX[o] = x1;   // x_k aliases the iterate before the first projection
+      xs = x - al * gr;
+      if (p.kind == 2 && p.first) AUX[o] = xs;   // x_k aliases the iterate before the first projection
     }
-    return;
+    X[o] = xs;
+    return xs;
   }
+  real xs;
   if (p.kind == 0) {                       // gd.py:132-134
-    X[o] = rmax(x - al * gr, (real)0.);
+    xs = rmax(x - al * gr, (real)0.);
   } else if (p.kind == 1) {                // gd.py:183-188
     const real pp = AUX[o];
     const real pn = p.mu * pp - al * gr;
     const real xn = x + (p.negmu * pp + p.onepmu * pn);
     AUX[o] = pn;
-    X[o] = rmax(xn, (real)0.);
+    xs = rmax(xn, (real)0.);
   } else {                                 // gd.py:235-241
     const real x1 = x - al * gr;
     const real xk = rmax(x1, (real)0.);
     const real xp = p.first ? x1 : AUX[o];
-    X[o] = xk + p.coef * (xk - xp);
+    xs = xk + p.coef * (xk - xp);
     AUX[o] = xk;
   }
+  X[o] = xs;
+  return xs;
 }
 
 template <int NT, int EMAX, bool SK, bool R2>
@@ -184,6 +189,42 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update_half(PlaneGeom g, PL plan
     if (c1 < g.W) gd_update_one(X, AUX, base + c1, z.y, al, p);
   };
   fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, upd);
+}
+
+// ---- the same update with the NEXT iteration's forward rows fused behind it -------------------------------------
+// irfft row -> shift + crop = gradient -> fused update of x (+ momentum, projection) -> the updated row, re-padded, goes
+// straight back through the forward row transform: the next iteration finds the row spectra of its iterate already in
+// `Sout` and skips its forward row pass (one launch and one read of x less per iteration).  Same structure as
+// k_rinv_gd_mid_half: the update is the source functor of the forward transform's first stage.
+template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+__global__ __launch_bounds__(NT) void k_rinv_gd_update_fwd_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
+                                                                 const real2* LPC_RESTRICT Sin,
+                                                                 real2* LPC_RESTRICT Sout, real* LPC_RESTRICT X,
+                                                                 real* LPC_RESTRICT AUX,
+                                                                 const real* LPC_RESTRICT alpha, GdScalars p) {
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int tid = threadIdx.x, u = blockIdx.x;
+  const long pl = blockIdx.y;
+  const int hh = g.Hp / 2, hw = g.Wp / 2, M = g.Wp >> 1;
+  const int sr = wrap_add(g.sh + u, hh, g.Hp);
+  tangle_half_load<NT, EMAX, SK>(s, M, twW, Sin + pl * g.cplane + (long)sr * g.cpitch, tid);
+  __syncthreads();
+  fft_tile<NT, EMAX, true, SK, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
+  // slot j now holds gradient samples (2j, 2j+1) before the shift; padded sample m of the NEW row =
+  // (m in window) ? updated x[m - sw] : 0, where x[c] takes gradient sample (m + Wp/2) mod Wp
+  const real al = alpha[pl % g.C];
+  const long base = pl * g.uplane + (long)u * g.W;
+  auto sample = [&](int m) {
+    const int c = m - g.sw;
+    if (c < 0 || c >= g.W) return (real)0.;
+    const int q = wrap_add(m, hw, g.Wp);
+    const real2 z = s[lds_slot<SK>(q >> 1)];
+    return gd_update_one(X, AUX, base + c, (q & 1) ? z.y : z.x, al, p);
+  };
+  auto newrow = [&](int i, int) { return make_real2(sample(2 * i), sample(2 * i + 1)); };
+  fft_tile<NT, EMAX, false, SK, true, true>(s, plan, 1, make_fastdiv_dev1(), tid, newrow, LdsNatural{});
+  untangle_half_store<NT, SK>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
 }
 
 // second half of a split iteration: PROJ = proj(image_est) as the caller computed it, channels-last (n,H,W,C)

@@ -452,3 +452,31 @@ def test_pass_a_32_column_tiles(backend, monkeypatch, shape, padded):
     tiles)."""
     monkeypatch.setenv("LPC_PASSA_T32", "1")
     _admm_fista_vs_oracle(*shape, padded, n_admm=2, n_fista=2)
+
+
+@pytest.mark.parametrize("kind,cls", [("fista", lpa.FISTA), ("nesterov", lpa.NesterovGradientDescent),
+                                       ("vanilla", lpa.GradientDescent)])
+def test_gd_update_with_fused_forward_rows(backend, monkeypatch, kind, cls):
+    """Wide frames on compile-time plans: the update kernel also transforms the updated rows, so the next iteration
+    skips its forward row pass (k_rinv_gd_update_fwd_half).  The cached row spectra must survive `reset=False`
+    continuations and be dropped when something else overwrites the work spectrum (reconstruction_error) or the
+    iterate (reset, warm start)."""
+    H, W, C = 3, 4096, 1
+    rng = np.random.default_rng(21)
+    psf = orc.synthetic_psf(1, H, W, C, seed=6)
+    y = rng.random((H, W, C), dtype=np.float32)
+    rec = cls(torch.from_numpy(psf))
+    rec.set_data(torch.from_numpy(y))
+    o = orc.GDOracle(psf, kind=kind, dtype=torch.float64)
+    o.set_data(y)
+    rec.apply(n_iter=2, disp_iter=None)
+    err = rec.reconstruction_error()                      # one convolution through the same work spectrum
+    assert np.isfinite(float(err[0]))
+    got = rec.apply(n_iter=3, disp_iter=None, reset=False)
+    assert rel(got, o.apply(5)) <= 5e-6
+    got2 = rec.apply(n_iter=4, disp_iter=None)            # reset: the cached spectra of the old iterate are dropped
+    assert rel(got2, o.apply(4)) <= 5e-6
+    monkeypatch.setenv("LPC_GD_NO_FUSE_FWD", "1")
+    plain = cls(torch.from_numpy(psf))
+    plain.set_data(torch.from_numpy(y))
+    assert rel(plain.apply(n_iter=4, disp_iter=None), got2) <= 1e-6

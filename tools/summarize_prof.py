@@ -64,8 +64,10 @@ for k in sorted(agg):
     lines[-1] += " | ".join(f"{mean[c]:.3g}" if mean.get(c) is not None else "-" for c in cols) + " |"
 open(os.path.join(out, f"{tag}_counters.md"), "w").write("\n".join(lines) + "\n")
 for k, v in traffic.items():
-    if k.startswith("k_admm_rows_fused") or (k.startswith("k_admm_spatial") and not any(
-            q.startswith("k_admm_rows_fused") for q in traffic)):
+    # LPC_K_SPATIAL: the tiled kernel; only when the whole image-domain work is fused into the rows (LPC_FUSE_ROWS) is
+    # it k_admm_rows_fused (which otherwise is the forward row kernel carrying the X half)
+    if k.startswith("k_admm_spatial") or (k.startswith("k_admm_rows_fused") and not any(
+            q.startswith("k_admm_spatial") for q in traffic)):
         json.dump({"kernel": k, "hbm_bytes_per_launch": v, "source": f"profiles/{tag}_counters.md", "snapshot": tag,
                    "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes"},
                   open(os.path.join(out, "k1_traffic.json"), "w"), indent=1)
