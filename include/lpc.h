@@ -140,6 +140,19 @@ int lpc_iterate_end(lpc_handle h, const lpc_real* dev_projected, void* stream);
 int lpc_admm_pnp_begin(lpc_handle h, int use_dual, lpc_real* dev_denoiser_in, void* stream);
 int lpc_admm_pnp_end(lpc_handle h, int use_dual, const lpc_real* dev_U, void* stream);
 
+/* ADMM with a caller-supplied sparsifying operator `psi / psi_adj / psi_gram` (admm.py:44-46,104-120): the operator
+ * cannot be fused, so the caller keeps U, eta and Psi(V) (their shape is the operator's) and runs Psi, Psi^T and the
+ * soft-threshold itself; the engine does everything else of `_update` (admm.py:252-329) in one call:
+ *   lpc_set_psi_gram   |psi_gram(padded_shape)| (real, (Hp, Wc), NATURAL frequency order, one plane shared by all
+ *                      channels) replaces the finite-difference gram in R_divmat (admm.py:186-190).  Call after
+ *                      lpc_set_psf (which restores the default gram).
+ *   lpc_admm_psi_step  dev_psit = Psi^T(mu2 U - eta) as (B,D,Hp,Wp,C): X and W updates, r_k = (mu3 W - rho) + dev_psit +
+ *                      H^T(mu1 X - xi), the spectral image update, the xi and rho updates.  The new estimate is
+ *                      lpc_get_state("image_est"); the caller then updates Psi(V) and eta (admm.py:302-308).
+ * A handle runs either these or lpc_iterate between two resets. */
+int lpc_set_psi_gram(lpc_handle h, const lpc_real* dev_gabs, void* stream);
+int lpc_admm_psi_step(lpc_handle h, const lpc_real* dev_psit, void* stream);
+
 /* _form_image(): ADMM crop + clamp (admm.py:331-338), GD family projection (gd.py:136-140).
  * dev_out: (B,D,H,W,C).  Like the reference, the ADMM clamp is an in-place side effect on the image
  * estimate: it is visible to the W-update of the following iterations (and to "image_est"). */

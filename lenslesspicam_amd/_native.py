@@ -82,6 +82,8 @@ class Lib:
             "lpc_iterate": [vp, C.c_int, vp],
             "lpc_admm_pnp_begin": [vp, C.c_int, fp, vp],
             "lpc_admm_pnp_end": [vp, C.c_int, fp, vp],
+            "lpc_set_psi_gram": [vp, fp, vp],
+            "lpc_admm_psi_step": [vp, fp, vp],
             "lpc_iterate_begin": [vp, vp],
             "lpc_iterate_end": [vp, fp, vp],
             "lpc_set_admm_schedule": [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -210,6 +212,12 @@ class Handle:
 
     def admm_pnp_end(self, use_dual, u_ptr, stream=0):
         self._c(self.lib.dll.lpc_admm_pnp_end(self.h, int(bool(use_dual)), u_ptr, stream))
+
+    def set_psi_gram(self, gabs_ptr, stream=0):
+        self._c(self.lib.dll.lpc_set_psi_gram(self.h, gabs_ptr, stream))
+
+    def admm_psi_step(self, psit_ptr, stream=0):
+        self._c(self.lib.dll.lpc_admm_psi_step(self.h, psit_ptr, stream))
 
     def iterate_begin(self, stream=0):
         self._c(self.lib.dll.lpc_iterate_begin(self.h, stream))

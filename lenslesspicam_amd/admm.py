@@ -25,11 +25,17 @@ class ADMM(ReconstructionAlgorithm):
                  psi_gram=None, pad=False, norm="backward", denoiser=None, **kwargs):
         self._mu1, self._mu2, self._mu3, self._tau = mu1, mu2, mu3, tau
         assert len(psf.shape) == 4, "PSF must be 4D: (depth, height, width, channels)."
-        if psi is not None or psi_adj is not None or psi_gram is not None:
-            raise NotImplementedError(
-                "custom psi/psi_adj/psi_gram callables cannot be fused into the HIP kernels; "
-                "only the built-in finite-difference TV prior is supported"
-            )
+        # A caller-supplied sparsifying operator (admm.py:104-120) cannot be fused into the kernels: U, eta and Psi(V)
+        # then live here, in the caller's array kind, Psi / Psi^T / the soft-threshold run as the caller's code, and
+        # the engine does the rest of every iteration in one call (lpc_admm_psi_step).
+        self._custom_psi = None
+        if psi is not None:
+            assert psi_adj is not None
+            assert psi_gram is not None
+            assert callable(psi)
+            assert callable(psi_adj)
+            assert callable(psi_gram)
+            self._custom_psi = (psi, psi_adj, psi_gram)
         if pad:
             raise NotImplementedError("ADMM iterates on the padded frame (pad=False), like the reference default")
         # Depth > 1: the reference raises NotImplementedError (admm.py:92-96).  The engine runs
@@ -51,9 +57,65 @@ class ADMM(ReconstructionAlgorithm):
         super().__init__(psf, dtype, pad=False, norm=norm, denoiser=None, reset=False, **kwargs)
         if self._pnp is not None:
             self._denoiser, self._denoiser_noise_level, self._denoiser_use_dual = self._pnp
+        if self._custom_psi is not None:
+            if self._pnp is not None:
+                raise NotImplementedError("a denoiser replaces the prior: pass either psi or denoiser")
+            self._Psi, self._PsiT = self._custom_psi[0], self._custom_psi[1]
+            self._push_psi_gram()
         self.reset()
 
+    # -- caller-supplied prior -------------------------------------------------------------------------------------
+    def _push_psi_gram(self):
+        """``self._PsiTPsi = psi_gram(self._padded_shape)`` (admm.py:118) -> |.| in R_divmat (admm.py:186-190)."""
+        gram = self._custom_psi[2](self._padded_shape)
+        gabs = torch.abs(gram if isinstance(gram, torch.Tensor) else torch.from_numpy(np.asarray(gram)))
+        D, Hp, Wp, C = self._padded_shape
+        assert tuple(gabs.shape) == (D, Hp, Wp // 2 + 1, C), f"psi_gram must return the rfft2 spectrum, got {tuple(gabs.shape)}"
+        plane = gabs[0, :, :, 0]
+        if not torch.allclose(gabs, plane[None, :, :, None].expand_as(gabs), rtol=1e-6, atol=0):
+            raise NotImplementedError("psi_gram must be the same for every depth plane and channel")
+        self._gabs_dev = plane.to(device=self._device, dtype=self._tdtype).contiguous()
+        self._handle.set_psi_gram(self._gabs_dev.data_ptr(), self._stream())
+
+    def _after_new_handle(self):
+        if getattr(self, "_custom_psi", None) is not None:
+            self._push_psi_gram()
+
+    def _set_psf(self, psf):
+        super()._set_psf(psf)                       # restores the finite-difference gram inside the engine
+        if self._custom_psi is not None:
+            self._push_psi_gram()
+            self.reset()
+
+    def reset(self):
+        super().reset()
+        if getattr(self, "_custom_psi", None) is not None:     # admm.py:163-184
+            v = self._image_est
+            psi_v = self._Psi(v)
+            zeros = psi_v * 0
+            self._U_c, self._eta_c = zeros, zeros * 1
+            self._Psi_out = psi_v if float(v.max()) else zeros * 1
+
+    @staticmethod
+    def _soft_thresh(x, thresh):                    # admm.py:341-346
+        if isinstance(x, torch.Tensor):
+            return torch.sign(x) * torch.max(torch.abs(x) - thresh, torch.zeros_like(x))
+        return np.sign(x) * np.maximum(0, np.abs(x) - thresh)
+
+    def _iterate_custom_psi(self, n):
+        B = self._handle_batch
+        D, Hp, Wp, C = self._padded_shape
+        for _ in range(int(n)):
+            self._U_c = self._soft_thresh(self._Psi_out + self._eta_c / self._mu2, self._tau / self._mu2)   # :245-247
+            t = self._to_dev(self._PsiT(self._mu2 * self._U_c - self._eta_c))                                # :279
+            assert tuple(t.shape) == (B, D, Hp, Wp, C), "psi_adj must return the padded image shape"
+            self._handle.admm_psi_step(t.data_ptr(), self._stream())        # X, W, image, xi, rho  (:252-300, :310-311)
+            self._Psi_out = self._Psi(self._image_est)                      # :322
+            self._eta_c = self._eta_c + self._mu2 * (self._Psi_out - self._U_c)                             # :308
+
     def _iterate(self, n):
+        if self._custom_psi is not None:
+            return self._iterate_custom_psi(n)
         if self._pnp is None:
             return super()._iterate(n)
         B = self._handle_batch
@@ -80,9 +142,11 @@ class ADMM(ReconstructionAlgorithm):
 
     _X = property(lambda self: self._padded_state("X"))
     _W = property(lambda self: self._padded_state("W"))
-    _U = property(lambda self: self._padded_state("U", self._pnp is None))      # image-shaped with a denoiser
+    _U = property(lambda self: self._U_c if self._custom_psi is not None
+                  else self._padded_state("U", self._pnp is None))              # image-shaped with a denoiser
     _xi = property(lambda self: self._padded_state("xi"))
-    _eta = property(lambda self: self._padded_state("eta", self._pnp is None))
+    _eta = property(lambda self: self._eta_c if self._custom_psi is not None
+                    else self._padded_state("eta", self._pnp is None))
     _rho = property(lambda self: self._padded_state("rho"))
     _forward_out = property(lambda self: self._padded_state("forward_out"))
 

@@ -789,6 +789,49 @@ int lpc_admm_pnp_end(lpc_handle e, int use_dual, const real* dev_U, void* stream
   return 0;
 }
 
+// ---- ADMM with a caller-supplied sparsifying operator (admm.py:104-120): one iteration around the caller's Psi / Psi^T ----
+int lpc_set_psi_gram(lpc_handle e, const real* dev_gabs, void* stream) {
+  if (!e || !dev_gabs) return fail("lpc_set_psi_gram: null argument");
+  if (e->cfg.algo != LPC_ALGO_ADMM) return fail("lpc_set_psi_gram: ADMM handles only");
+  e->stream = (lpcStream_t)stream;
+  const PlaneGeom& g = e->g;
+  LPC_RT(rt::memset_async(e->Gabs, 0, (size_t)g.cplane * sizeof(real), e->stream));
+  return launch_k(e, -1, k_permute_spectrum_rows<256>, grid1d((long)g.Hp * g.Wc, 256), 256, 0, dev_gabs, e->Gabs, g.Hp,
+                  g.Wc, g.cpitch, e->N1, e->N2);
+}
+
+int lpc_admm_psi_step(lpc_handle e, const real* dev_psit, void* stream) {
+  LPC_OK(pnp_check(e, "lpc_admm_psi_step"));
+  if (!dev_psit) return fail("lpc_admm_psi_step: null argument");
+  if (e->pnp_pending) return fail("lpc_admm_psi_step: a plug-and-play iteration is in flight");
+  if (!e->pnp_mode && e->iters_done != 0)
+    return fail("lpc_admm_psi_step: fused iterations already ran since the last reset");
+  e->stream = (lpcStream_t)stream;
+  e->pnp_mode = true;       // explicit state from here on; lpc_iterate refuses until the next reset
+  const PlaneGeom& g = e->g;
+  const int nimg = e->cfg.batch * e->cfg.depth;
+  real *T = e->eta1[0], *X = e->eta0[1], *W = e->eta1[1];
+  LPC_OK(hwc_to_planar(e, dev_psit, T, nimg, g.Hp, g.Wp, g.rpitch, g.rplane));
+  double par[4];
+  admm_params(e, e->iters_done, par);
+  const AdmmScalars sc = admm_scalars(e, par);
+  const dim3 grid = grid1d((long)g.Hp * g.Wp, 256, e->P);
+  real* Vc = e->V[e->vcur];
+  real* Vn = e->V[e->vcur ^ 1];
+  real* HVn = e->HVb[e->hcur ^ 1];
+  LPC_OK(launch_k(e, LPC_K_SPATIAL, k_pnp_pre<256>, grid, 256, 0, g, sc, 2, (const real*)Vc,
+                  (const real*)e->HVb[e->hcur], (const real*)e->xi, (const real*)e->rho, (const real*)T,
+                  (const real*)e->eta0[0], (const real*)e->Y, X, W, e->Rsp, e->Aarr));
+  LPC_OK(admm_spectral_step(e, sc, Vn, HVn));
+  LPC_OK(launch_k(e, LPC_K_SPATIAL, k_pnp_post<256>, grid, 256, 0, g, sc, 0, (const real*)Vn, (const real*)HVn,
+                  (const real*)X, (const real*)W, (const real*)T, e->xi, e->eta0[0], e->rho));   // xi and rho (eta is the caller's)
+  e->vcur ^= 1;
+  e->hcur ^= 1;
+  e->first = false;
+  ++e->iters_done;
+  return 0;
+}
+
 int lpc_form_image(lpc_handle e, real* dev_out, void* stream) {
   if (!e || !dev_out) return fail("lpc_form_image: null argument");
   e->stream = (lpcStream_t)stream;

@@ -1496,7 +1496,10 @@ __global__ __launch_bounds__(NT) void k_pnp_pre(PlaneGeom g, AdmmScalars p, int 
     const real w = rmax(div_by(rho[o], p.mu3, p.r_mu3) + V[o], (real)0.);                        // admm.py:256-262
     X[o] = x;
     W[o] = w;
-    if (dual) {
+    if (dual == 2) {   // caller-supplied prior (admm.py:104-120, 277-281): U holds Psi^T(mu2 U - eta), computed by the caller
+      Rsp[o] = (p.mu3 * w - rho[o]) + U[o];
+      Aout[o] = p.mu1 * x - xi[o];
+    } else if (dual) {
       Rsp[o] = (p.mu3 * w - rho[o]) + p.mu2 * U[o] - eta[o];
       Aout[o] = (real)0.;
     } else {
@@ -1631,6 +1634,19 @@ __global__ __launch_bounds__(NT) void k_abs_complex(const real2* LPC_RESTRICT Gs
   for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
     const real2 gg = Gs[e];
     out[e] = rsqrt_of(gg.x * gg.x + gg.y * gg.y);
+  }
+}
+
+// a real spectrum plane in natural row order [Hp][Wc] -> the engine's stored (four-step) row order [Hp][cpitch]:
+// stored row p = k1*N2 + k2 holds frequency k1 + N1*k2
+template <int NT>
+__global__ __launch_bounds__(NT) void k_permute_spectrum_rows(const real* LPC_RESTRICT nat, real* LPC_RESTRICT out,
+                                                               int Hp, int Wc, int cpitch, int N1, int N2) {
+  const long n = (long)Hp * Wc;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const int prow = (int)(e / Wc), c = (int)(e - (long)prow * Wc);
+    const int k = (prow / N2) + N1 * (prow % N2);
+    out[(long)prow * cpitch + c] = nat[(long)k * Wc + c];
   }
 }
 

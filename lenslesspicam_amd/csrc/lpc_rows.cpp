@@ -142,52 +142,31 @@ int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
-  static int unr = -1;     // tuning knob: chunks of a row in flight per thread (12-MP shape only)
-  if (unr < 0) unr = std::getenv("LPC_FUSED_UNROLL") ? atoi(std::getenv("LPC_FUSED_UNROLL")) : 1;
-  if (e->static_rows && !std::getenv("LPC_FUSED_OCC5") && !std::getenv("LPC_FUSED_UNROLL")) {
+  auto launch = [&](auto kernel, int nt, size_t smem, auto plan_arg) {
+    return launch_k(e, LPC_K_SPATIAL, kernel, dim3(2 * g.Hp, e->P), nt, smem, g, sc, plan_arg,
+                    (const real2*)e->planW.tw, Vc, Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1],
+                    e->xi, (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
+                    e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB);
+  };
+  if (e->static_rows)
     return with_row_shape(e, [&](auto SHc) {
       using SH = decltype(SHc);
       using PA = SPlanArg<typename SH::plan>;
       return with_sk(e->static_sk, [&](auto SKc) {
         constexpr bool sk = decltype(SKc)::value;
-        auto go = [&](auto kernel) {
-          return launch_k(e, LPC_K_SPATIAL, kernel, dim3(2 * g.Hp, e->P), SH::nt, LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g,
-                          sc, splan_arg<typename SH::plan>(e->planWh), (const real2*)e->planW.tw, Vc, Vo,
-                          (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi,
-                          (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
-                          e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB);
-        };
-#ifdef LPC_DEBUG_KNOBS
-        if (std::getenv("LPC_DEBUG_FUSED_NOFFT")) return go(k_admm_rows_fused<SH::nt, SH::em, sk, 1, 2, PA>);
-        if (std::getenv("LPC_DEBUG_FUSED_NOSPATIAL")) return go(k_admm_rows_fused<SH::nt, SH::em, sk, 1, 3, PA>);
+        const size_t smem = LPC_ROW_SMEM_BYTES(SH::plan::n, sk);
+        const PA pa = splan_arg<typename SH::plan>(e->planWh);
+#ifdef LPC_DEBUG_KNOBS   // phase-timing experiments of profiles/r02_notes.md (results are garbage)
+        if (std::getenv("LPC_DEBUG_FUSED_NOFFT")) return launch(k_admm_rows_fused<SH::nt, SH::em, sk, 1, 2, PA>, SH::nt, smem, pa);
+        if (std::getenv("LPC_DEBUG_FUSED_NOSPATIAL")) return launch(k_admm_rows_fused<SH::nt, SH::em, sk, 1, 3, PA>, SH::nt, smem, pa);
 #endif
-        return go(k_admm_rows_fused<SH::nt, SH::em, sk, 1, 1, PA>);
+        return launch(k_admm_rows_fused<SH::nt, SH::em, sk, 1, 1, PA>, SH::nt, smem, pa);
       });
     });
-  }
-  static int occ5 = -1;    // tuning knob: un-skewed 32 KiB tile + 96-VGPR budget = 5 workgroups per CU (12-MP shape only)
-  if (occ5 < 0) occ5 = std::getenv("LPC_FUSED_OCC5") ? 1 : 0;
-  if (occ5 && g.Wp == 8192)
-    return launch_k(e, LPC_K_SPATIAL, k_admm_rows_fused<256, 16, false, 1, 5>, dim3(2 * g.Hp, e->P), 256,
-                    LPC_ROW_SMEM_BYTES(g.Wp / 2, false), g, sc, e->planWh, (const real2*)e->planW.tw, Vc, Vo,
-                    (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi,
-                    (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
-                    e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB);
   return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
     constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
     constexpr bool sk = decltype(SK)::value;
-    auto go = [&](auto kernel) {
-      return launch_k(e, LPC_K_SPATIAL, kernel, dim3(2 * g.Hp, e->P), nt,
-                      LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, sc, e->planWh, (const real2*)e->planW.tw, Vc, Vo,
-                      (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi,
-                      (const real*)e->eta0[e->ecur], (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1],
-                      e->eta1[e->ecur ^ 1], e->rho, (const real*)e->Y, SA, SB);
-    };
-    if constexpr (nt == 256 && em == 16 && sk) {
-      if (unr == 2) return go(k_admm_rows_fused<nt, em, sk, 2>);
-      if (unr == 4) return go(k_admm_rows_fused<nt, em, sk, 4>);
-    }
-    return go(k_admm_rows_fused<nt, em, sk, 1>);
+    return launch(k_admm_rows_fused<nt, em, sk>, nt, LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), e->planWh);
   });
 #endif
 }

@@ -167,12 +167,14 @@ class ADMMOracle:
     """
 
     def __init__(self, psf, dtype=torch.float32, mu1=1e-6, mu2=1e-5, mu3=4e-5, tau=1e-4,
-                 initial_est=None, schedule=None, denoiser=None):
+                 initial_est=None, schedule=None, denoiser=None, psi=None):
         """``denoiser``: optional (fn, noise_level, use_dual) -- the plug-and-play branch of admm.py:126-133,
         235-243,266-275,300-311, restated as written (U and eta image-shaped, Psi^T = identity).
         ``schedule``: optional dict of per-iteration sequences mu1/mu2/mu3/tau -- the arithmetic of
         ``lensless/recon/unrolled_admm.py:133-234`` (UnrolledADMM inference, no pre/post processors):
         iteration i uses the i-th entries everywhere, R_divmat and X_divmat included."""
+        """``psi``: optional (psi, psi_adj, psi_gram) callables, the caller-supplied prior of admm.py:44-46,104-120
+        (``psi_gram(padded_shape)`` returns the rfft2 spectrum of Psi^T Psi)."""
         psf = _as_tensor(psf, dtype)
         assert psf.dim() == 4 and psf.shape[0] == 1, "reference refuses D>1 (admm.py:92-96)"
         self.dtype = dtype
@@ -184,7 +186,11 @@ class ADMMOracle:
         self.geom = g
         self.padded_shape = [1, g.hp, g.wp, psf.shape[-1]]
         self.psf = psf
+        self.Psi, self.PsiT = finite_diff, finite_diff_adj
         self.gram = finite_diff_gram(self.padded_shape, dtype)  # admm.py:107
+        if psi is not None:                                     # admm.py:108-118
+            self.Psi, self.PsiT = psi[0], psi[1]
+            self.gram = psi[2](self.padded_shape)
         self.initial_est = None if initial_est is None else _as_tensor(initial_est, dtype)
         self.schedule = schedule
         self.denoiser = denoiser
@@ -220,11 +226,11 @@ class ADMMOracle:
         else:
             self.V = torch.zeros([1] + self.padded_shape, dtype=self.dtype)
         self.X = torch.zeros_like(self.V)
-        self.U = torch.zeros_like(self.V if self.denoiser is not None else finite_diff(self.V))  # admm.py:163-169
+        self.U = torch.zeros_like(self.V if self.denoiser is not None else self.Psi(self.V))  # admm.py:163-169
         self.W = torch.zeros_like(self.X)
         if self.V.max():  # admm.py:172
             self.HV = self.conv.convolve(self.V)
-            self.PsiV = finite_diff(self.V)
+            self.PsiV = self.Psi(self.V)
         else:
             self.HV = torch.zeros_like(self.X)
             self.PsiV = torch.zeros_like(self.U)
@@ -252,13 +258,13 @@ class ADMMOracle:
         self.W = torch.maximum(self.rho / mu3 + self.V, torch.zeros_like(self.V))  # :259-261
         rk = (
             (mu3 * self.W - self.rho)
-            + finite_diff_adj(mu2 * self.U - self.eta)
+            + self.PsiT(mu2 * self.U - self.eta)
             + self.conv.deconvolve(mu1 * self.X - self.xi)
         )                                                                         # :277-281
         freq = self.R_divmat * torch.fft.rfft2(rk, dim=(-3, -2))                  # :286
         self.V = torch.fft.irfft2(freq, dim=(-3, -2), s=(g.hp, g.wp))             # :287-289
         self.HV = self.conv.convolve(self.V)                                      # :320
-        self.PsiV = finite_diff(self.V)                                           # :322
+        self.PsiV = self.Psi(self.V)                                              # :322
         self.xi = self.xi + mu1 * (self.HV - self.X)                              # :298-300
         self.eta = self.eta + mu2 * (self.PsiV - self.U)                          # :302-308
         self.rho = self.rho + mu3 * (self.V - self.W)                             # :310-311

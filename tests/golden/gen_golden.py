@@ -389,6 +389,50 @@ def caller_flow_case(name):
     print("wrote", name, {k: (v.shape, str(v.dtype)) for k, v in out.items()})
 
 
+# a caller-supplied sparsifying operator for ADMM (admm.py:44-46,104-120): two weighted circular differences, one of
+# them over a distance of 2 pixels; psi_gram = rfft2 of the stencil of Psi^T Psi, like finite_diff_gram
+def _psi2(x):
+    return torch.stack((1.5 * (torch.roll(x, 1, dims=-3) - x), 0.5 * (torch.roll(x, 2, dims=-2) - x)), dim=len(x.shape))
+
+
+def _psi2_adj(u):
+    return 1.5 * (torch.roll(u[..., 0], -1, dims=-3) - u[..., 0]) + 0.5 * (torch.roll(u[..., 1], -2, dims=-2) - u[..., 1])
+
+
+def _psi2_gram(shape, dtype=torch.float32):
+    gram = torch.zeros([int(v) for v in shape], dtype=dtype)
+    gram[0, 0, 0] = 2 * 1.5 ** 2 + 2 * 0.5 ** 2
+    gram[0, 1, 0] = gram[0, -1, 0] = -(1.5 ** 2)
+    gram[0, 0, 2] = gram[0, 0, -2] = -(0.5 ** 2)
+    return torch.fft.rfft2(gram, dim=(-3, -2))
+
+
+def custom_psi_case(name):
+    """ADMM(psf, psi=..., psi_adj=..., psi_gram=...) through the public API, cold and warm start, with a continuation."""
+    out = {}
+    psf, data = make_inputs(22, 30, 3, 91)
+    kw = dict(mu1=1e-4, mu2=2e-4, mu3=3e-4, tau=2e-6)
+    out.update(psf=psf, data=data, params=np.array([1e-4, 2e-4, 3e-4, 2e-6]), iters=np.array(8))
+    rec = ADMM(t(psf), psi=_psi2, psi_adj=_psi2_adj, psi_gram=_psi2_gram, **kw)
+    # the operators are consistent: <Psi x, u> == <x, Psi^T u>
+    x = torch.randn([1] + [int(v) for v in rec._padded_shape])
+    u = torch.randn(list(x.shape) + [2])
+    assert abs(float((_psi2(x) * u).sum() - (x * _psi2_adj(u)).sum())) < 1e-2
+    rec.set_data(t(data))
+    out["final"] = rec.apply(n_iter=8, disp_iter=None, plot=False).numpy().copy()
+    for k in ("_image_est", "_U", "_X", "_W", "_xi", "_eta", "_rho"):
+        out["state" + k] = getattr(rec, k).numpy().copy()
+    out["more"] = rec.apply(n_iter=3, disp_iter=None, plot=False, reset=False).numpy().copy()
+    init = (np.random.default_rng(92).random([1, 1, 45, 60, 3]).astype(np.float32) - 0.3) * 0.2
+    out["initial_est"] = init
+    rec2 = ADMM(t(psf), psi=_psi2, psi_adj=_psi2_adj, psi_gram=_psi2_gram, initial_est=t(init.copy()), **kw)
+    rec2.set_data(t(data))
+    out["warm_final"] = rec2.apply(n_iter=6, disp_iter=None, plot=False).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, {k: float(np.abs(v).max()) for k, v in out.items() if "final" in k or k == "more"},
+          float(np.count_nonzero(out["state_U"]) / out["state_U"].size))
+
+
 def operator_case():
     rng = np.random.default_rng(5)
     out = {}
@@ -445,6 +489,9 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "preprocess":
         preprocess_case("preprocess")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "custom_psi":
+        custom_psi_case("admm_custom_psi")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "display":
         display_case("apply_display")
         sys.exit(0)
@@ -487,6 +534,7 @@ if __name__ == "__main__":
     hook_case("pnp_hook")
     admm_pnp_case("pnp_admm")
     display_case("apply_display")
+    custom_psi_case("admm_custom_psi")
     caller_flow_case("caller_flow")
     # profile/gradient_descent.py settings (n_iter=300, gray, float32) at reduced size
     gd_case("fista_profile_gray", FISTA, 38, 50, 1, seed=18, iters=[300])
