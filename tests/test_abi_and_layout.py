@@ -105,8 +105,8 @@ def test_reference_api_surface_and_errors(backend):
         lpa.ADMM(psf, dtype="float16")
     with pytest.raises(NotImplementedError):
         lpa.ADMM(psf, denoiser={"network": "DruNet", "noise_level": 10})
-    with pytest.raises(NotImplementedError):
-        lpa.ADMM(psf, psi=lambda x: x, psi_adj=lambda x: x, psi_gram=lambda s: 1)
+    with pytest.raises(AssertionError):                          # admm.py:109-110: psi needs psi_adj and psi_gram
+        lpa.ADMM(psf, psi=lambda x: x)
     res = lpa.FISTA(psf, n_iter=2)
     res.set_data(psf[0])
     out = res.apply(disp_iter=None, plot=False)                 # n_iter from the constructor
