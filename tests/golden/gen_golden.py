@@ -490,7 +490,7 @@ if __name__ == "__main__":
         preprocess_case("preprocess")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "custom_psi":
-        custom_psi_case("admm_custom_psi")
+        custom_psi_case("custom_psi_admm")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "display":
         display_case("apply_display")
@@ -534,7 +534,7 @@ if __name__ == "__main__":
     hook_case("pnp_hook")
     admm_pnp_case("pnp_admm")
     display_case("apply_display")
-    custom_psi_case("admm_custom_psi")
+    custom_psi_case("custom_psi_admm")
     caller_flow_case("caller_flow")
     # profile/gradient_descent.py settings (n_iter=300, gray, float32) at reduced size
     gd_case("fista_profile_gray", FISTA, 38, 50, 1, seed=18, iters=[300])

@@ -43,7 +43,7 @@ def psi2_gram(shape, dtype=torch.float32):
 
 @pytest.fixture(scope="module")
 def g():
-    return np.load(os.path.join(GOLDEN, "admm_custom_psi.npz"))
+    return np.load(os.path.join(GOLDEN, "custom_psi_admm.npz"))
 
 
 def _kw(g):
