@@ -233,8 +233,9 @@ static int setup_geometry(Engine* e) {
     if (e->N1 > 1 && e->T == 16 && ColPlan90::matches(e->planA)) e->static_passA = 90;
     if (e->N1 > 1 && e->T == 16 && ColPlan64::matches(e->planA)) e->static_passA = 64;
     if (e->N1 > 1 && e->T == 16 && ColPlan48::matches(e->planB)) e->static_mid = 48;
-    if (e->N1 == 1 && e->T == 8 && ColPlan540::matches(e->planB)) e->static_mid = 540;
-    if (e->N1 == 1 && e->T == 16 && c.algo == LPC_ALGO_ADMM && ColPlan540::matches(e->planB)) e->static_mid = 541;
+    // (540: the static plan is 30.18, not build_plan()'s 6.6.5.3 -- only the length and the twiddle table are shared)
+    if (e->N1 == 1 && e->T == 8 && e->planB.n == 540) e->static_mid = 540;
+    if (e->N1 == 1 && e->T == 16 && c.algo == LPC_ALGO_ADMM && e->planB.n == 540) e->static_mid = 541;
     if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan960::matches(e->planW)) e->static_prow = 960;
     if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan2048::matches(e->planW)) e->static_prow = 2048;
   }

@@ -236,9 +236,10 @@ typedef SPlan<8, 8, 2> ColPlan128;
 typedef SPlan<8, 6> ColPlan48;
 // 1080 x 1920 frames: 2160 = 90 x 24, pass A 90 = 6.5.3 (the 24-point middle lives in registers)
 typedef SPlan<6, 5, 3> ColPlan90;
-// DiffuserCam-sized frames (270 x 480 -> 540 x 960): single-pass 540-point columns = 6.6.5.3 over 2 x 8 tile columns,
+// DiffuserCam-sized frames (270 x 480 -> 540 x 960): single-pass 540-point columns = 30.18 over 2 x 8 tile columns,
 // paired rows of 960 = 8.8.5.3
-typedef SPlan<6, 6, 5, 3> ColPlan540;
+typedef SPlan<30, 18> ColPlan540;          // two fat register butterflies (lpc_fft.h); build_plan() makes 6.6.5.3
+typedef SPlan<6, 10, 9> ColPlan540Seq;     // one-spectrum-at-a-time middle: small butterflies, two workgroups per CU
 typedef SPlan<8, 8, 5, 3> RowPlan960;
 // 760 x 1014 frames (1536 x 2048 padded, 1536 = 64 x 24): pass A 64 = 8.8, ADMM's paired rows 2048 = 8.8.8.4
 typedef SPlan<8, 8> ColPlan64;

@@ -184,10 +184,56 @@ struct Dft<16, INV> {  // 16 = 4 x 4: X[k1 + 4 k2] = sum_n2 w16^(n2 k1) [sum_n1 
   }
 };
 
+
+// ---- fat butterflies for the 540-point columns of DiffuserCam-sized frames: 540 = 30 x 18 in TWO stages ----------
+// A radix-30 (= 6 x 5) and a radix-18 (= 6 x 3) butterfly held in registers, each a two-factor Cooley-Tukey with
+// compile-time inner twiddles: the 540-point transform makes ONE trip through LDS between its two stages instead of
+// three (plan 6.6.5.3), with half the barriers.  Natural order in, natural order out, both directions.
+struct WPair { real re, im; };
+template <int N> struct WTab;
+template <> struct WTab<30> { static constexpr WPair w[30] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)9.78147600733805688833e-01, (real)-2.07911690817759314820e-01}, {(real)9.13545457642600866599e-01, (real)-4.06736643075800152758e-01}, {(real)8.09016994374947451263e-01, (real)-5.87785252292473137103e-01}, {(real)6.69130606358858237570e-01, (real)-7.43144825477394133095e-01}, {(real)5.00000000000000111022e-01, (real)-8.66025403784438596588e-01}, {(real)3.09016994374947451263e-01, (real)-9.51056516295153531182e-01}, {(real)1.04528463267653456970e-01, (real)-9.94521895368273289861e-01}, {(real)-1.04528463267653332069e-01, (real)-9.94521895368273400884e-01}, {(real)-3.09016994374947340241e-01, (real)-9.51056516295153642204e-01}, {(real)-4.99999999999999777955e-01, (real)-8.66025403784438707611e-01}, {(real)-6.69130606358857904503e-01, (real)-7.43144825477394466162e-01}, {(real)-8.09016994374947340241e-01, (real)-5.87785252292473248126e-01}, {(real)-9.13545457642600977621e-01, (real)-4.06736643075800041736e-01}, {(real)-9.78147600733805688833e-01, (real)-2.07911690817759314820e-01}, {(real)-1.00000000000000000000e+00, (real)-5.66553889764797961539e-16}, {(real)-9.78147600733805688833e-01, (real)2.07911690817759065020e-01}, {(real)-9.13545457642600866599e-01, (real)4.06736643075800208269e-01}, {(real)-8.09016994374947562285e-01, (real)5.87785252292473026081e-01}, {(real)-6.69130606358858459615e-01, (real)7.43144825477394022073e-01}, {(real)-5.00000000000000444089e-01, (real)8.66025403784438374544e-01}, {(real)-3.09016994374947562285e-01, (real)9.51056516295153531182e-01}, {(real)-1.04528463267654234126e-01, (real)9.94521895368273289861e-01}, {(real)1.04528463267652985125e-01, (real)9.94521895368273400884e-01}, {(real)3.09016994374947229218e-01, (real)9.51056516295153642204e-01}, {(real)5.00000000000000111022e-01, (real)8.66025403784438596588e-01}, {(real)6.69130606358858459615e-01, (real)7.43144825477394022073e-01}, {(real)8.09016994374947340241e-01, (real)5.87785252292473359148e-01}, {(real)9.13545457642600977621e-01, (real)4.06736643075800152758e-01}, {(real)9.78147600733805688833e-01, (real)2.07911690817758981753e-01}}; };
+template <> struct WTab<18> { static constexpr WPair w[18] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)9.39692620785908427905e-01, (real)-3.42020143325668712908e-01}, {(real)7.66044443118978013452e-01, (real)-6.42787609686539251896e-01}, {(real)5.00000000000000111022e-01, (real)-8.66025403784438596588e-01}, {(real)1.73648177666930414453e-01, (real)-9.84807753012208020316e-01}, {(real)-1.73648177666930303431e-01, (real)-9.84807753012208020316e-01}, {(real)-4.99999999999999777955e-01, (real)-8.66025403784438707611e-01}, {(real)-7.66044443118977902429e-01, (real)-6.42787609686539473941e-01}, {(real)-9.39692620785908316883e-01, (real)-3.42020143325668879442e-01}, {(real)-1.00000000000000000000e+00, (real)-1.22464679914735320717e-16}, {(real)-9.39692620785908427905e-01, (real)3.42020143325668657397e-01}, {(real)-7.66044443118978346519e-01, (real)6.42787609686538918830e-01}, {(real)-5.00000000000000444089e-01, (real)8.66025403784438374544e-01}, {(real)-1.73648177666930331187e-01, (real)9.84807753012208020316e-01}, {(real)1.73648177666929970364e-01, (real)9.84807753012208131338e-01}, {(real)4.99999999999999333866e-01, (real)8.66025403784439040678e-01}, {(real)7.66044443118977791407e-01, (real)6.42787609686539584963e-01}, {(real)9.39692620785908427905e-01, (real)3.42020143325668601886e-01}}; };
+
+template <> struct WTab<9> { static constexpr WPair w[9] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)7.66044443118978013452e-01, (real)-6.42787609686539251896e-01}, {(real)1.73648177666930414453e-01, (real)-9.84807753012208020316e-01}, {(real)-4.99999999999999777955e-01, (real)-8.66025403784438707611e-01}, {(real)-9.39692620785908316883e-01, (real)-3.42020143325668879442e-01}, {(real)-9.39692620785908427905e-01, (real)3.42020143325668657397e-01}, {(real)-5.00000000000000444089e-01, (real)8.66025403784438374544e-01}, {(real)1.73648177666929970364e-01, (real)9.84807753012208131338e-01}, {(real)7.66044443118977791407e-01, (real)6.42787609686539584963e-01}}; };
+template <> struct WTab<10> { static constexpr WPair w[10] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)8.09016994374947451263e-01, (real)-5.87785252292473137103e-01}, {(real)3.09016994374947451263e-01, (real)-9.51056516295153531182e-01}, {(real)-3.09016994374947340241e-01, (real)-9.51056516295153642204e-01}, {(real)-8.09016994374947340241e-01, (real)-5.87785252292473248126e-01}, {(real)-1.00000000000000000000e+00, (real)-1.22464679914735320717e-16}, {(real)-8.09016994374947562285e-01, (real)5.87785252292473026081e-01}, {(real)-3.09016994374947562285e-01, (real)9.51056516295153531182e-01}, {(real)3.09016994374947229218e-01, (real)9.51056516295153642204e-01}, {(real)8.09016994374947340241e-01, (real)5.87785252292473359148e-01}}; };
+
+// v[n], n = j1*R2 + j2  ->  v[k], k = k1 + R1*k2  (X[k1 + R1 k2] = sum_j2 w_N^(j2 k1) [sum_j1 x[j1 R2 + j2] w_R1^(j1 k1)] w_R2^(j2 k2))
+template <int R1, int R2, bool INV>
+static __device__ __forceinline__ void dft_two_factor(real2* v) {
+  constexpr int N = R1 * R2;
+  real2 y[R2][R1];
+#pragma unroll
+  for (int j2 = 0; j2 < R2; ++j2) {
+    real2 t[R1];
+#pragma unroll
+    for (int j1 = 0; j1 < R1; ++j1) t[j1] = v[j1 * R2 + j2];
+    Dft<R1, INV>::run(t);
+#pragma unroll
+    for (int k1 = 0; k1 < R1; ++k1) {
+      const int q = (k1 * j2) % N;
+      const real2 w = make_real2(WTab<N>::w[q].re, INV ? -WTab<N>::w[q].im : WTab<N>::w[q].im);
+      y[j2][k1] = q ? cmul(t[k1], w) : t[k1];
+    }
+  }
+#pragma unroll
+  for (int k1 = 0; k1 < R1; ++k1) {
+    real2 t[R2];
+#pragma unroll
+    for (int j2 = 0; j2 < R2; ++j2) t[j2] = y[j2][k1];
+    Dft<R2, INV>::run(t);
+#pragma unroll
+    for (int k2 = 0; k2 < R2; ++k2) v[k1 + R1 * k2] = t[k2];
+  }
+}
+template <bool INV> struct Dft<30, INV> { static __device__ __forceinline__ void run(real2* v) { dft_two_factor<6, 5, INV>(v); } };
+template <bool INV> struct Dft<18, INV> { static __device__ __forceinline__ void run(real2* v) { dft_two_factor<6, 3, INV>(v); } };
+template <bool INV> struct Dft<10, INV> { static __device__ __forceinline__ void run(real2* v) { dft_two_factor<5, 2, INV>(v); } };
+template <bool INV> struct Dft<9, INV> { static __device__ __forceinline__ void run(real2* v) { dft_two_factor<3, 3, INV>(v); } };
+
 // v[m] *= w^m (m = 1..R-1), w = exp(-+ 2 pi i q1 / n) = tw[q1] (conjugated for the inverse).
 template <int R, bool INV>
 static __device__ __forceinline__ void twiddle_mul(real2* v, const real2* LPC_RESTRICT tw, int q1) {
-  if (R <= 6) {  // exact table entries for every power
+  if constexpr (R != 8 && R != 16) {  // exact table entries for every power
 #pragma unroll
     for (int m = 1; m < R; ++m) {
       real2 t = tw[q1 * m];

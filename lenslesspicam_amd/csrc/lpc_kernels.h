@@ -788,8 +788,8 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
 // LDS tile transforms `r_sp`: T = 16 columns per workgroup in the same 69 KiB, every row access a whole 128-byte
 // line, half as many workgroups.  H and |G| are shared by all frames of a batch (L2-resident) and are loaded where
 // they are used.  Compile-time plans only (SBT == cp.T).
-template <int NT, int EMAX, class PL, int SBT>
-__global__ __launch_bounds__(NT) void k_cols_mid_admm_seq(PlaneGeom g, PL plan, ColPass cp, real2* LPC_RESTRICT SA,
+template <int NT, int EMAX, class PL, int SBT, int MINW = 1>
+__global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL plan, ColPass cp, real2* LPC_RESTRICT SA,
                                                            real2* LPC_RESTRICT SB, const real2* LPC_RESTRICT Hs,
                                                            const real* LPC_RESTRICT Gabs, const real2* LPC_RESTRICT phr,
                                                            const real2* LPC_RESTRICT phc, real mu1, real mu2, real mu3,
