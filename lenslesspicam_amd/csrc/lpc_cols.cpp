@@ -19,12 +19,21 @@ int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1,
   auto static_passA = [&](auto plan_tag) {
     using P = decltype(plan_tag);
     const SPlanArg<P> pa = splan_arg<P>(e->planA);
+    static const bool twl = getenv("LPC_NO_TW_LDS") == nullptr;   // plan + four-step twiddles staged in LDS
     if (cp.T == 32) {
-      const size_t smem = (size_t)P::n * 32 * sizeof(real2);
+      const size_t smem = (size_t)P::n * (32 + (twl ? 2 : 0)) * sizeof(real2);
+      if (twl) {
+        if (inverse) return launch_k(e, kid, k_cols<512, 8, true, SPlanArg<P>, 32, true>, grid, 512, smem, g, pa, cp, S);
+        return launch_k(e, kid, k_cols<512, 8, false, SPlanArg<P>, 32, true>, grid, 512, smem, g, pa, cp, S);
+      }
       if (inverse) return launch_k(e, kid, k_cols<512, 8, true, SPlanArg<P>, 32>, grid, 512, smem, g, pa, cp, S);
       return launch_k(e, kid, k_cols<512, 8, false, SPlanArg<P>, 32>, grid, 512, smem, g, pa, cp, S);
     }
-    const size_t smem = (size_t)P::n * 16 * sizeof(real2);
+    const size_t smem = (size_t)P::n * (16 + (twl ? 2 : 0)) * sizeof(real2);
+    if (twl) {
+      if (inverse) return launch_k(e, kid, k_cols<256, 8, true, SPlanArg<P>, 16, true>, grid, 256, smem, g, pa, cp, S);
+      return launch_k(e, kid, k_cols<256, 8, false, SPlanArg<P>, 16, true>, grid, 256, smem, g, pa, cp, S);
+    }
     if (inverse) return launch_k(e, kid, k_cols<256, 8, true, SPlanArg<P>, 16>, grid, 256, smem, g, pa, cp, S);
     return launch_k(e, kid, k_cols<256, 8, false, SPlanArg<P>, 16>, grid, 256, smem, g, pa, cp, S);
   };
@@ -114,6 +123,14 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
       // another's loads and barriers -- 0.650 ms per launch at 64 frames against 0.84 ms for the two-stage 30.18
       // plan (184 registers, one workgroup per CU) and 0.95 ms for 6.6.5.3 (profiles/r02_notes.md section 4)
       constexpr int minw = sizeof(real) == 4 ? 4 : 1;
+      static const bool twlds = getenv("LPC_NO_TW_LDS") == nullptr;
+      if (twlds)
+      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<512, 18, SPlanArg<ColPlan540Seq>, 16, minw, true>,
+                      dim3(cp.ntile_c, e->P), 512, (size_t)540 * 17 * sizeof(real2), g,
+                      splan_arg<ColPlan540Seq>(e->planB), cp, SA, SB, (const real2*)e->Hs, (const real*)e->Gabs,
+                      (const real2*)e->phr, (const real2*)e->phc, sc.mu1, sc.mu2, sc.mu3,
+                      (real)1.0 / ((real)g.Hp * (real)g.Wp)));
+      else
       LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<512, 18, SPlanArg<ColPlan540Seq>, 16, minw>,
                       dim3(cp.ntile_c, e->P), 512, (size_t)540 * 16 * sizeof(real2), g,
                       splan_arg<ColPlan540Seq>(e->planB), cp, SA, SB, (const real2*)e->Hs, (const real*)e->Gabs,
@@ -121,12 +138,19 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
                       (real)1.0 / ((real)g.Hp * (real)g.Wp)));
     }
     else if (e->static_mid == 540) {   // C1 / C4: 540 points x 2 x 8 tile columns = 8640 points = 512 threads x 17
-      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<512, 18, SPlanArg<ColPlan540>, 16>, grid, 512,
-                      (size_t)540 * 16 * sizeof(real2), g, splan_arg<ColPlan540>(e->planB), cp, SA, SB,
+      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<512, 18, SPlanArg<ColPlan540>, 16, true>, grid, 512,
+                      (size_t)540 * 17 * sizeof(real2), g, splan_arg<ColPlan540>(e->planB), cp, SA, SB,
                       (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2,
                       sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
     }
     else if (e->static_mid == 48) {   // 48-point middle, 2 x 16 tile columns: 1536 points = 256 threads x 6
+      static const bool twl = getenv("LPC_NO_TW_LDS") == nullptr;
+      if (twl)
+      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<256, 8, SPlanArg<ColPlan48>, 32, true>, grid, 256,
+                      (size_t)48 * 33 * sizeof(real2), g, splan_arg<ColPlan48>(e->planB), cp, SA, SB,
+                      (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2,
+                      sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
+      else
       LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<256, 8, SPlanArg<ColPlan48>, 32>, grid, 256,
                       (size_t)48 * 32 * sizeof(real2), g, splan_arg<ColPlan48>(e->planB), cp, SA, SB,
                       (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2,

@@ -66,41 +66,62 @@ struct GdScalars {
   int split;       // 1: stop in front of the projection (plug-and-play hook, lpc_iterate_begin / _end)
 };
 
-// returns the value stored in X[o] (the point the next iteration's forward model is evaluated at)
-static __device__ __forceinline__ real gd_update_one(real* LPC_RESTRICT X, real* LPC_RESTRICT AUX, long o,
-                                                      real gr, real al, const GdScalars& p) {
-  const real x = X[o];
+// One element of the three _update()s as a function of values (x = iterate, pp = the auxiliary state, gr = gradient):
+// returns the value to store in X (the point the next iteration's forward model is evaluated at) and sets aux_out to
+// the value AUX takes where the variant writes it (gd_aux_access says whether it reads / writes AUX at all).
+static __device__ __forceinline__ real gd_update_val(real x, real pp, real gr, real al, const GdScalars& p,
+                                                      real& aux_out) {
+  aux_out = pp;
   if (p.split) {   // everything up to `self._form_image()` of the three _update()s; k_gd_post finishes
-    real xs;
     if (p.kind == 1) {
-      const real pp = AUX[o];
       const real pn = p.mu * pp - al * gr;
-      AUX[o] = pn;
-      xs = x + (p.negmu * pp + p.onepmu * pn);
-    } else {
-      xs = x - al * gr;
-      if (p.kind == 2 && p.first) AUX[o] = xs;   // x_k aliases the iterate before the first projection
+      aux_out = pn;
+      return x + (p.negmu * pp + p.onepmu * pn);
     }
-    X[o] = xs;
+    const real xs = x - al * gr;
+    aux_out = xs;              // stored only when kind == 2 && first: x_k aliases the iterate before the first projection
     return xs;
   }
-  real xs;
-  if (p.kind == 0) {                       // gd.py:132-134
-    xs = rmax(x - al * gr, (real)0.);
-  } else if (p.kind == 1) {                // gd.py:183-188
-    const real pp = AUX[o];
+  if (p.kind == 0) return rmax(x - al * gr, (real)0.);   // gd.py:132-134
+  if (p.kind == 1) {                                      // gd.py:183-188
     const real pn = p.mu * pp - al * gr;
     const real xn = x + (p.negmu * pp + p.onepmu * pn);
-    AUX[o] = pn;
-    xs = rmax(xn, (real)0.);
-  } else {                                 // gd.py:235-241
-    const real x1 = x - al * gr;
-    const real xk = rmax(x1, (real)0.);
-    const real xp = p.first ? x1 : AUX[o];
-    xs = xk + p.coef * (xk - xp);
-    AUX[o] = xk;
+    aux_out = pn;
+    return rmax(xn, (real)0.);
   }
+  const real x1 = x - al * gr;                            // gd.py:235-241
+  const real xk = rmax(x1, (real)0.);
+  const real xp = p.first ? x1 : pp;
+  aux_out = xk;
+  return xk + p.coef * (xk - xp);
+}
+static __device__ __forceinline__ void gd_aux_access(const GdScalars& p, bool& rd, bool& wr) {
+  rd = p.kind == 1 || (p.kind == 2 && !p.split && !p.first);
+  wr = p.kind == 1 || (p.kind == 2 && (!p.split || p.first));
+}
+static __device__ __forceinline__ real gd_update_one(real* LPC_RESTRICT X, real* LPC_RESTRICT AUX, long o,
+                                                      real gr, real al, const GdScalars& p) {
+  bool rd, wr;
+  gd_aux_access(p, rd, wr);
+  real an;
+  const real xs = gd_update_val(X[o], rd ? AUX[o] : (real)0., gr, al, p, an);
+  if (wr) AUX[o] = an;
   X[o] = xs;
+  return xs;
+}
+// two neighbouring columns at once (o even: 8-byte accesses; the half-row kernels use it when the window offset,
+// the frame width and Wp / 2 are all even, so that gradient samples 2i and 2i + 1 are one aligned pair of x)
+static __device__ __forceinline__ real2 gd_update_pair(real* LPC_RESTRICT X, real* LPC_RESTRICT AUX, long o,
+                                                        real2 gr, real al, const GdScalars& p) {
+  bool rd, wr;
+  gd_aux_access(p, rd, wr);
+  const real2 x = *(const real2*)(X + o);
+  const real2 pp = rd ? *(const real2*)(AUX + o) : make_real2((real)0., (real)0.);
+  real2 an, xs;
+  xs.x = gd_update_val(x.x, pp.x, gr.x, al, p, an.x);
+  xs.y = gd_update_val(x.y, pp.y, gr.y, al, p, an.y);
+  if (wr) *(real2*)(AUX + o) = an;
+  *(real2*)(X + o) = xs;
   return xs;
 }
 
@@ -161,7 +182,17 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid_half(PlaneGeom g, PL plan, c
     const real2 z = s[lds_slot<SK>(q >> 1)];
     return ((q & 1) ? z.y : z.x) - y[c];
   };
-  auto resid = [&](int i, int) { return make_real2(sample(2 * i), sample(2 * i + 1)); };
+  const bool pair = ((g.sw | g.W | hw) & 1) == 0;   // samples 2i, 2i + 1 = one aligned pair of y and one LDS slot
+  auto resid = [&](int i, int) {
+    if (pair) {
+      const int c = 2 * i - g.sw;
+      if (c < 0 || c >= g.W) return make_real2((real)0., (real)0.);
+      const real2 z = s[lds_slot<SK>(wrap_add(2 * i, hw, g.Wp) >> 1)];
+      const real2 yy = *(const real2*)(y + c);
+      return make_real2(z.x - yy.x, z.y - yy.y);
+    }
+    return make_real2(sample(2 * i), sample(2 * i + 1));
+  };
   fft_tile<NT, EMAX, false, SK, true, true>(s, plan, 1, make_fastdiv_dev1(), tid, resid, LdsNatural{});
   untangle_half_store<NT, SK>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
 }
@@ -182,8 +213,13 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update_half(PlaneGeom g, PL plan
   __syncthreads();
   const real al = alpha[pl % g.C];
   const long base = pl * g.uplane + (long)u * g.W;
+  const bool pair = ((g.sw | g.W | hw) & 1) == 0;
   auto upd = [&](int i, int, real2 z) {     // gradient samples 2i, 2i+1 -> shift + crop -> fused update
     const int c0 = shifted_col(2 * i, hw, g.sw, g.Wp);
+    if (pair) {
+      if (c0 < g.W) gd_update_pair(X, AUX, base + c0, z, al, p);
+      return;
+    }
     if (c0 < g.W) gd_update_one(X, AUX, base + c0, z.x, al, p);
     const int c1 = shifted_col(2 * i + 1, hw, g.sw, g.Wp);
     if (c1 < g.W) gd_update_one(X, AUX, base + c1, z.y, al, p);
@@ -222,7 +258,16 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update_fwd_half(PlaneGeom g, PL 
     const real2 z = s[lds_slot<SK>(q >> 1)];
     return gd_update_one(X, AUX, base + c, (q & 1) ? z.y : z.x, al, p);
   };
-  auto newrow = [&](int i, int) { return make_real2(sample(2 * i), sample(2 * i + 1)); };
+  const bool pair = ((g.sw | g.W | hw) & 1) == 0;
+  auto newrow = [&](int i, int) {
+    if (pair) {
+      const int c = 2 * i - g.sw;
+      if (c < 0 || c >= g.W) return make_real2((real)0., (real)0.);
+      const real2 z = s[lds_slot<SK>(wrap_add(2 * i, hw, g.Wp) >> 1)];
+      return gd_update_pair(X, AUX, base + c, z, al, p);
+    }
+    return make_real2(sample(2 * i), sample(2 * i + 1));
+  };
   fft_tile<NT, EMAX, false, SK, true, true>(s, plan, 1, make_fastdiv_dev1(), tid, newrow, LdsNatural{});
   untangle_half_store<NT, SK>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
 }

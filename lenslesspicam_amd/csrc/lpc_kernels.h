@@ -438,7 +438,7 @@ struct ColPass {
 
 // plain pass over ONE spectrum array, in place (global -> registers -> [LDS] -> registers -> global)
 // PL / SBT: run-time plan (SBT unused), or a compile-time plan with SBT == cp.T columns per tile (lpc_sfft.h)
-template <int NT, int EMAX, bool INV, class PL = Fft1dPlan, int SBT = 0>
+template <int NT, int EMAX, bool INV, class PL = Fft1dPlan, int SBT = 0, bool TWLDS = false>
 __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
                                               real2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
@@ -455,12 +455,24 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
     if (c0 + c < g.Wc && (INV || (row >= cp.zr0 && row < cp.zr1))) x = base[i * rstep + c];
     return x;
   };
+  // compile-time plans (short transforms): the plan's twiddles and this group's four-step twiddles
+  // twH[grp * i] live in LDS behind the tile (the host adds 2 n entries to the launch's LDS size)
+  constexpr bool TWL = is_static_plan<PL>::value && TWLDS;
+  const real2* tws = nullptr;
+  if constexpr (TWL) {
+    real2* t0 = s + PL::n * SBT;
+    plan = twiddles_to_lds<NT>(plan, t0, tid);
+    if ((!INV && cp.tw_mode == 1) || (INV && cp.tw_mode == 2)) {
+      for (int i = tid; i < PL::n; i += NT) t0[PL::n + i] = cp.twH[grp * i];
+      tws = t0 + PL::n;
+    }
+  }
   auto untwiddle = [&](int i, int, real2 x) {   // inverse pass A: conj four-step twiddle on the way in
-    return (INV && cp.tw_mode == 2) ? cmul_conj(x, cp.twH[grp * i]) : x;
+    return (INV && cp.tw_mode == 2) ? cmul_conj(x, TWL ? tws[i] : cp.twH[grp * i]) : x;
   };
   auto out = [&](int i, int c, real2 x) {
     if (c0 + c < g.Wc) {
-      if (!INV && cp.tw_mode == 1) x = cmul(x, cp.twH[grp * i]);
+      if (!INV && cp.tw_mode == 1) x = cmul(x, TWL ? tws[i] : cp.twH[grp * i]);
       if (INV && cp.needn < g.Hp) {
         int d = row0 + i * cp.istride - cp.need0;
         d = d < 0 ? d + g.Hp : d;
@@ -470,7 +482,8 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
     }
   };
   if constexpr (is_static_plan<PL>::value) {
-    if (INV) fft_tile<NT, EMAX, INV, false, false, true, LPC_COLS_FUSEL, SBT>(s, plan, cp.T, cp.tdiv, tid, in, out, untwiddle);
+    // (SRC_LDS = TWL: the barrier between the tile's loads and `untwiddle` makes the staged twiddles visible)
+    if (INV) fft_tile<NT, EMAX, INV, false, TWL, true, LPC_COLS_FUSEL, SBT>(s, plan, cp.T, cp.tdiv, tid, in, out, untwiddle);
     else fft_tile<NT, EMAX, INV, false, false, false, LPC_COLS_FUSEL, SBT>(s, plan, cp.T, cp.tdiv, tid, in, out);
   } else {
     if (INV) fft_tile<NT, EMAX, INV, false, false, true, LPC_COLS_FUSEL>(s, plan, cp.T, cp.tdiv, tid, in, out, untwiddle);
@@ -702,7 +715,7 @@ __global__ __launch_bounds__(64) void k_cols_mid_admm_reg(PlaneGeom g, Fft1dPlan
 // then inverse pass B; SA <- Vh path, SB <- HVh path.
 // Tile: [N][2T] -- columns 0..T-1 belong to SA, T..2T-1 to SB.
 // PL / SBT2: run-time plan, or a compile-time plan with SBT2 == 2 * cp.T tile columns (both arrays)
-template <int NT, int EMAX, class PL = Fft1dPlan, int SBT2 = 0>
+template <int NT, int EMAX, class PL = Fft1dPlan, int SBT2 = 0, bool TWLDS = false>
 __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColPass cp,
                                                        real2* LPC_RESTRICT SA,
                                                        real2* LPC_RESTRICT SB,
@@ -744,6 +757,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
     const int j = c < T ? c : c - T;
     return (c0 + j < g.Wc) ? (c < T ? ba : bb)[i * rstep + j] : make_real2((real)0., (real)0.);
   };
+  if constexpr (is_static_plan<PL>::value && TWLDS) plan = twiddles_to_lds<NT>(plan, s + PL::n * SBT2, tid);
   if constexpr (is_static_plan<PL>::value)
     fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1, false, SBT2>(s, plan, T2, t2div, tid, in, LdsNatural{});
   else
@@ -788,7 +802,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
 // LDS tile transforms `r_sp`: T = 16 columns per workgroup in the same 69 KiB, every row access a whole 128-byte
 // line, half as many workgroups.  H and |G| are shared by all frames of a batch (L2-resident) and are loaded where
 // they are used.  Compile-time plans only (SBT == cp.T).
-template <int NT, int EMAX, class PL, int SBT, int MINW = 1>
+template <int NT, int EMAX, class PL, int SBT, int MINW = 1, bool TWLDS = false>
 __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL plan, ColPass cp, real2* LPC_RESTRICT SA,
                                                            real2* LPC_RESTRICT SB, const real2* LPC_RESTRICT Hs,
                                                            const real* LPC_RESTRICT Gabs, const real2* LPC_RESTRICT phr,
@@ -808,6 +822,8 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   const real2 zero = make_real2((real)0., (real)0.);
   auto inB = [&](int i, int j) { return (c0 + j < g.Wc) ? bb[i * rstep + j] : zero; };
   auto inA = [&](int i, int j) { return (c0 + j < g.Wc) ? ba[i * rstep + j] : zero; };
+  // the twiddle table moves into LDS behind the tile (lpc_sfft.h twiddles_to_lds)
+  if (TWLDS) plan = twiddles_to_lds<NT>(plan, s + NELEM, tid);
   // 1. Ah = FFT(a), parked in registers in tile order e = tid + k NT
   fft_tile<NT, EMAX, false, false, false, false, false, SBT>(s, plan, T, cp.tdiv, tid, inB, LdsNatural{});
   real2 a[EM];

@@ -164,6 +164,14 @@ static __device__ __forceinline__ v2f mk2(float a, float b) { v2f r; r.x = a; r.
 static __device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
 #endif
 
+// 24-bit multiply (full-rate v_mul_u32_u24 / v_mad_u32_u24; a 32-bit v_mul_lo_u32 issues at quarter rate): tile-local
+// row indices times a row pitch in bytes, both far below 2^24
+#if defined(LPC_SIMT_EMU)
+static inline unsigned mul24(unsigned a, unsigned b) { return a * b; }
+#else
+static __device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) { return __umul24(a, b); }
+#endif
+
 // ------------------------------------------------------------ small helpers --
 static __host__ __device__ __forceinline__ real2 cmul(real2 a, real2 b) {
   return make_real2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
