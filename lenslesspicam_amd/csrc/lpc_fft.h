@@ -37,7 +37,7 @@ struct Fft1dPlan {
 // multiply by -i (forward) / +i (inverse)
 template <bool INV>
 static __device__ __forceinline__ real2 rot90(real2 a) {
-  return INV ? make_real2(-a.y, a.x) : make_real2(a.y, -a.x);
+  return INV ? cmul_pi(a) : cmul_mi(a);
 }
 // multiply by exp(-+ 2 pi i q / 16) for the constants a radix-16 butterfly needs
 template <bool INV, int Q>
@@ -48,7 +48,7 @@ static __device__ __forceinline__ real2 mul_w16(real2 a) {
   constexpr real wr = Q == 1 ? C1 : Q == 2 ? C8 : Q == 3 ? S1 : Q == 6 ? -C8 : -C1;   // Q in {1,2,3,6,9}
   constexpr real wf = Q == 1 ? -S1 : Q == 2 ? -C8 : Q == 3 ? -C1 : Q == 6 ? -C8 : S1;  // forward imag part
   constexpr real wi = INV ? -wf : wf;
-  return make_real2(a.x * wr - a.y * wi, a.x * wi + a.y * wr);
+  return cmul(a, make_real2(wr, wi));
 }
 
 template <int R, bool INV>
@@ -80,12 +80,12 @@ struct Dft<3, INV> {
   static __device__ __forceinline__ void run(real2* v) {
     const real S = (real)0.86602540378443864676;  // sin(2 pi / 3)
     real2 t = cadd(v[1], v[2]);
-    real2 m = make_real2(v[0].x - (real)0.5 * t.x, v[0].y - (real)0.5 * t.y);
-    real2 d = cscale(csub(v[1], v[2]), S);
+    real2 m = caxpy(t, -(real)0.5, v[0]);
+    real2 d = cmul_mi(cscale(csub(v[1], v[2]), S));   // -i d
     v[0] = cadd(v[0], t);
     // forward: X1 = m - i d, X2 = m + i d ; inverse swaps them
-    real2 p = make_real2(m.x + d.y, m.y - d.x);
-    real2 q = make_real2(m.x - d.y, m.y + d.x);
+    real2 p = cadd(m, d);
+    real2 q = csub(m, d);
     v[1] = INV ? q : p;
     v[2] = INV ? p : q;
   }
@@ -101,16 +101,16 @@ struct Dft<5, INV> {
     real2 a0 = v[0];
     real2 t1 = cadd(v[1], v[4]), t2 = cadd(v[2], v[3]);
     real2 t3 = csub(v[1], v[4]), t4 = csub(v[2], v[3]);
-    real2 m1 = make_real2(a0.x + C1 * t1.x + C2 * t2.x, a0.y + C1 * t1.y + C2 * t2.y);
-    real2 m2 = make_real2(a0.x + C2 * t1.x + C1 * t2.x, a0.y + C2 * t1.y + C1 * t2.y);
-    real2 n1 = make_real2(S1 * t3.x + S2 * t4.x, S1 * t3.y + S2 * t4.y);
-    real2 n2 = make_real2(S2 * t3.x - S1 * t4.x, S2 * t3.y - S1 * t4.y);
-    v[0] = make_real2(a0.x + t1.x + t2.x, a0.y + t1.y + t2.y);
+    real2 m1 = caxpy(t2, C2, caxpy(t1, C1, a0));
+    real2 m2 = caxpy(t2, C1, caxpy(t1, C2, a0));
+    real2 n1 = cmul_mi(caxpy(t4, S2, cscale(t3, S1)));    // -i n1
+    real2 n2 = cmul_mi(caxpy(t4, -S1, cscale(t3, S2)));   // -i n2
+    v[0] = cadd(cadd(a0, t1), t2);
     // forward: X1 = m1 - i n1, X4 = m1 + i n1, X2 = m2 - i n2, X3 = m2 + i n2
-    real2 x1 = make_real2(m1.x + n1.y, m1.y - n1.x);
-    real2 x4 = make_real2(m1.x - n1.y, m1.y + n1.x);
-    real2 x2 = make_real2(m2.x + n2.y, m2.y - n2.x);
-    real2 x3 = make_real2(m2.x - n2.y, m2.y + n2.x);
+    real2 x1 = cadd(m1, n1);
+    real2 x4 = csub(m1, n1);
+    real2 x2 = cadd(m2, n2);
+    real2 x3 = csub(m2, n2);
     v[1] = INV ? x4 : x1;
     v[4] = INV ? x1 : x4;
     v[2] = INV ? x3 : x2;
@@ -128,8 +128,8 @@ struct Dft<6, INV> {  // 6 = 2 x 3 (decimation in time over the even / odd input
     Dft<3, INV>::run(o);
     // w6^1 = (1/2, -+ S), w6^2 = (-1/2, -+ S)
     const real si = INV ? S : -S;
-    real2 o1 = make_real2((real)0.5 * o[1].x - si * o[1].y, (real)0.5 * o[1].y + si * o[1].x);
-    real2 o2 = make_real2(-(real)0.5 * o[2].x - si * o[2].y, -(real)0.5 * o[2].y + si * o[2].x);
+    real2 o1 = caxpy(cmul_pi(o[1]), si, cscale(o[1], (real)0.5));    // o * (1/2 + i si)
+    real2 o2 = caxpy(cmul_pi(o[2]), si, cscale(o[2], -(real)0.5));   // o * (-1/2 + i si)
     v[0] = cadd(e[0], o[0]); v[3] = csub(e[0], o[0]);
     v[1] = cadd(e[1], o1);   v[4] = csub(e[1], o1);
     v[2] = cadd(e[2], o2);   v[5] = csub(e[2], o2);
@@ -145,11 +145,9 @@ struct Dft<8, INV> {
     real2 b2 = cadd(v[2], v[6]), b6 = csub(v[2], v[6]);
     real2 b3 = cadd(v[3], v[7]), b7 = csub(v[3], v[7]);
     // b5 *= w8, b6 *= w8^2, b7 *= w8^3   (w8 = exp(-+ i pi/4))
-    b5 = INV ? make_real2(C * (b5.x - b5.y), C * (b5.x + b5.y))
-             : make_real2(C * (b5.x + b5.y), C * (b5.y - b5.x));
+    b5 = cscale(cadd(b5, rot90<INV>(b5)), C);
     b6 = rot90<INV>(b6);
-    b7 = INV ? make_real2(-C * (b7.x + b7.y), C * (b7.x - b7.y))
-             : make_real2(C * (b7.y - b7.x), -C * (b7.x + b7.y));
+    b7 = cscale(csub(rot90<INV>(b7), b7), C);
     real2 e[4] = {b0, b1, b2, b3};
     real2 o[4] = {b4, b5, b6, b7};
     Dft<4, INV>::run(e);

@@ -173,16 +173,79 @@ static __device__ __forceinline__ unsigned mul24(unsigned a, unsigned b) { retur
 #endif
 
 // ------------------------------------------------------------ small helpers --
+// Complex helpers.  In the float32 device build a complex number IS a two-wide operand (LPC_PK_COMPLEX): add / subtract
+// are one v_pk_add_f32, a product is v_pk_mul_f32 + v_pk_fma_f32 on (re, im) and the swapped pair -- written on v2f
+// so that the compiler keeps every value in its own aligned register pair instead of pairing unrelated scalars
+// (which cost the 540-point middle 815 register moves out of 3979 VALU instructions, profiles/r02_notes.md).
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(LPC_DOUBLE) && !defined(LPC_SIMT_EMU) && !defined(LPC_NO_PK_COMPLEX)
+#define LPC_PK_COMPLEX 1
+static __device__ __forceinline__ v2f c2v(real2 a) { return mk2(a.x, a.y); }
+static __device__ __forceinline__ real2 v2c(v2f a) { return make_real2(a.x, a.y); }
+static __device__ __forceinline__ v2f swap2(v2f a) { return __builtin_shufflevector(a, a, 1, 0); }
+#endif
 static __host__ __device__ __forceinline__ real2 cmul(real2 a, real2 b) {
+#ifdef LPC_PK_COMPLEX
+  const v2f A = c2v(a);
+  return v2c(fma2(swap2(A), mk2(-b.y, b.y), A * mk2(b.x, b.x)));
+#else
   return make_real2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+#endif
 }
 static __host__ __device__ __forceinline__ real2 cmul_conj(real2 a, real2 b) {  // a * conj(b)
+#ifdef LPC_PK_COMPLEX
+  const v2f A = c2v(a);
+  return v2c(fma2(swap2(A), mk2(b.y, -b.y), A * mk2(b.x, b.x)));
+#else
   return make_real2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y);
+#endif
 }
-static __host__ __device__ __forceinline__ real2 cadd(real2 a, real2 b) { return make_real2(a.x + b.x, a.y + b.y); }
-static __host__ __device__ __forceinline__ real2 csub(real2 a, real2 b) { return make_real2(a.x - b.x, a.y - b.y); }
+static __host__ __device__ __forceinline__ real2 cadd(real2 a, real2 b) {
+#ifdef LPC_PK_COMPLEX
+  return v2c(c2v(a) + c2v(b));
+#else
+  return make_real2(a.x + b.x, a.y + b.y);
+#endif
+}
+static __host__ __device__ __forceinline__ real2 csub(real2 a, real2 b) {
+#ifdef LPC_PK_COMPLEX
+  return v2c(c2v(a) - c2v(b));
+#else
+  return make_real2(a.x - b.x, a.y - b.y);
+#endif
+}
 static __host__ __device__ __forceinline__ real2 cconj(real2 a) { return make_real2(a.x, -a.y); }
-static __host__ __device__ __forceinline__ real2 cscale(real2 a, real s) { return make_real2(a.x * s, a.y * s); }
+static __host__ __device__ __forceinline__ real2 cscale(real2 a, real s) {
+#ifdef LPC_PK_COMPLEX
+  return v2c(c2v(a) * mk2(s, s));
+#else
+  return make_real2(a.x * s, a.y * s);
+#endif
+}
+// a * s + b (s real)
+static __host__ __device__ __forceinline__ real2 caxpy(real2 a, real s, real2 b) {
+#ifdef LPC_PK_COMPLEX
+  return v2c(fma2(c2v(a), mk2(s, s), c2v(b)));
+#else
+  return make_real2(a.x * s + b.x, a.y * s + b.y);
+#endif
+}
+// -i a = (a.y, -a.x)   /   +i a = (-a.y, a.x)
+static __host__ __device__ __forceinline__ real2 cmul_mi(real2 a) {
+#ifdef LPC_PK_COMPLEX
+  const v2f A = c2v(a);
+  return v2c(__builtin_shufflevector(A, -A, 1, 2));
+#else
+  return make_real2(a.y, -a.x);
+#endif
+}
+static __host__ __device__ __forceinline__ real2 cmul_pi(real2 a) {
+#ifdef LPC_PK_COMPLEX
+  const v2f A = c2v(a);
+  return v2c(__builtin_shufflevector(-A, A, 1, 2));
+#else
+  return make_real2(-a.y, a.x);
+#endif
+}
 
 // division of small non-negative ints by a plan-time constant: q = floor(n/d) for
 // n*d < 2^32 (all tile-local indices here are < 2^16).
