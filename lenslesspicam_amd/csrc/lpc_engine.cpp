@@ -237,6 +237,11 @@ static int setup_geometry(Engine* e) {
     if (e->N1 == 1 && e->T == 8 && e->planB.n == 540) e->static_mid = 540;
     if (e->N1 == 1 && e->T == 16 && c.algo == LPC_ALGO_ADMM && e->planB.n == 540) e->static_mid = 541;
     if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan960::matches(e->planW)) e->static_prow = 960;
+    // 960 = 8.8.5.3 on 256 threads leaves 136 lanes without a butterfly in the first stage, where every global load of
+    // the row kernels is issued; 128 threads x 8 points: forward rows 0.642 -> 0.576 ms, inverse 0.322 -> 0.312 ms at
+    // 64 frames, but 0.460 -> 0.470 ms per 5 iterations for ONE frame (profiles/r02_notes.md) -> batches only
+    e->prow_nt128 = e->static_prow == 960 && !std::getenv("LPC_PROW_NT256") &&
+                    ((long)e->P * g.Hp >= 8192 || std::getenv("LPC_PROW_NT128"));
     if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan2048::matches(e->planW)) e->static_prow = 2048;
   }
   // The half of the image-domain work that needs no neighbours IS fused by default where a compile-time row plan

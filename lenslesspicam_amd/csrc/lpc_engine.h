@@ -82,6 +82,7 @@ struct lpc_engine {
   bool static_sk = true;   // static-plan row kernels: LDS skew on (tuning knob LPC_ROWS_NOSKEW: 32 KiB tiles, 5 per CU)
   int static_passA = 0;    // pass-A length served by a compile-time plan (128 | 90 | 64, 16-column tiles), else 0
   int static_mid = 0;      // ADMM LDS-middle length served by a compile-time plan (48 with T = 16 | 540 with T = 8)
+  bool prow_nt128 = false; // 960-point paired rows on 128 threads x 8 points (every lane owns a first-stage butterfly): large batches
   int static_prow = 0;     // ADMM PAIRED-row length served by a compile-time plan (960 | 2048), else 0
   bool rows_r16 = false;   // 4096-point rows as 16.16.16 instead of 8.8.8.8
   int static_rows = 0;     // length of the half-row transform when a compile-time plan serves it (lpc_sfft.h), else 0
@@ -261,7 +262,7 @@ static inline int with_row_shape(const lpc_engine* e, F&& f) {
   if (e->static_rows == 4096 && e->rows_r16) return f(RowShape<RowPlan4096r16, 256, 16>{});
   if (e->static_rows == 4096) return f(RowShape<RowPlan4096, 256, 16>{});
   if (e->static_rows == 1920) return f(RowShape<RowPlan1920, 256, 8>{});
-  if (e->static_rows == 1024) return f(RowShape<RowPlan1024, 256, 4>{});
+  if (e->static_rows == 1024) return f(RowShape<RowPlan1024, 128, 8>{});   // 128 radix-8 butterflies in the fused first stage
   return fail("internal: no static row plan for this length");
 }
 

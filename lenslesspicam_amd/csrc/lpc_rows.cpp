@@ -114,6 +114,10 @@ int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc) {
                       LPC_ROW_SMEM_BYTES(P::n, true), g, sc, splan_arg<P>(e->planW), (const real*)e->Rsp,
                       (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->Y, SA, SB);
     };
+    if (e->static_prow == 960 && e->prow_nt128)
+      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<128, 8, true, SPlanArg<RowPlan960>>, dim3(g.Hp, e->P), 128,
+                      LPC_ROW_SMEM_BYTES(960, true), g, sc, splan_arg<RowPlan960>(e->planW), (const real*)e->Rsp,
+                      (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->Y, SA, SB);
     if (e->static_prow == 960) return go(RowPlan960{}, std::integral_constant<int, 4>{});
     if (e->static_prow == 2048) return go(RowPlan2048{}, std::integral_constant<int, 8>{});
     return fail("internal: no static paired-row plan");
@@ -198,6 +202,10 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout) {
   if (e->static_prow == 2048)
     return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<256, 8, true, false, SPlanArg<RowPlan2048>>, dim3(g.Hp, e->P), 256,
                     LPC_ROW_SMEM_BYTES(2048, true), g, splan_arg<RowPlan2048>(e->planW), (const real2*)SA, (const real2*)SB,
+                    Vout, HVout);
+  if (e->static_prow == 960 && e->prow_nt128)
+    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<128, 8, true, false, SPlanArg<RowPlan960>>, dim3(g.Hp, e->P), 128,
+                    LPC_ROW_SMEM_BYTES(960, true), g, splan_arg<RowPlan960>(e->planW), (const real2*)SA, (const real2*)SB,
                     Vout, HVout);
   if (e->static_prow == 960)
     return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<256, 4, true, false, SPlanArg<RowPlan960>>, dim3(g.Hp, e->P), 256,

@@ -444,6 +444,25 @@ def test_c4_sequential_middle_on_one_frame(backend, monkeypatch):
     assert "T = 16" in lpa.ADMM(torch.from_numpy(psf))._handle.plan_info()
 
 
+def test_c4_rows_on_128_threads(backend, monkeypatch):
+    """960-point paired rows of a large batch run on 128 threads x 8 points (every lane owns one radix-8 butterfly of
+    the fused first stage); LPC_PROW_NT128 forces that shape onto one frame.  Same plan, same arithmetic: the result
+    must be bitwise the one of the 256-thread kernels."""
+    rng = np.random.default_rng(5)
+    psf = torch.from_numpy(orc.synthetic_psf(1, 270, 480, 1, seed=1))
+    y = torch.from_numpy(rng.random((270, 480, 1), dtype=np.float32))
+    outs = []
+    for knob in ("LPC_PROW_NT256", "LPC_PROW_NT128"):
+        monkeypatch.setenv(knob, "1")
+        rec = lpa.ADMM(psf)
+        rec.set_data(y)
+        outs.append(rec.apply(n_iter=3, disp_iter=None, plot=False))
+        monkeypatch.delenv(knob)
+    assert torch.equal(outs[0], outs[1])
+    monkeypatch.setenv("LPC_PROW_NT128", "1")
+    _admm_fista_vs_oracle(270, 480, 1, (540, 960), n_admm=2, n_fista=1)
+
+
 @pytest.mark.parametrize("shape,padded", [((3072, 20, 1), (6144, 40)), ((1080, 20, 1), (2160, 40)), ((760, 20, 1), (1536, 40))],
                          ids=["passA128", "passA90", "passA64"])
 def test_pass_a_32_column_tiles(backend, monkeypatch, shape, padded):
