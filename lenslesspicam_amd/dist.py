@@ -79,3 +79,82 @@ def reconstruct_sharded(algo_cls, psf, frames, n_iter, group=None, solver=None, 
     """One-shot form of ``ShardedReconstructor``.  ``solver``: an existing ``algo_cls`` instance built from
     ``psf`` (skips handle creation, the PSF FFT and the workspace allocation)."""
     return ShardedReconstructor(algo_cls, psf, group=group, solver=solver, **algo_kwargs)(frames, n_iter)
+
+
+class PlaneShardedReconstructor:
+    """ONE frame split over the ranks by colour channel (every solver) and, for ADMM, also by depth plane
+    (optional: the 3 channels of C2 over 3 GPUs, the 16 x 3 planes of C5 over 8).
+
+    Why this is exact: no kernel of the path couples planes -- the FFTs, the TV stencil and every prox act inside one
+    (depth, channel) plane; the gradient-descent family takes its step size and its default start value per channel
+    ACROSS depth (gd.py:100-112), so it is split by channel only.  Each rank runs single-plane (gray) solvers for its
+    units one after the other, and one ``all_gather_into_tensor`` of the finished planes closes the frame: the
+    result equals the un-sharded ``algo_cls(psf).apply()`` bit for bit (tests/test_dist.py).
+
+    ``__call__(data, n_iter)``: ``data`` (H, W, C) or (1, H, W, C), same kind as ``psf``; returns (D, H, W, C) on
+    every rank.  Solvers (handle, PSF spectrum, workspace) are built once per unit and kept."""
+
+    def __init__(self, algo_cls, psf, group=None, **algo_kwargs):
+        from .admm import ADMM
+
+        self.group = group
+        self.algo_cls = algo_cls
+        self.kw = algo_kwargs
+        self.psf = psf
+        self.is_torch = isinstance(psf, torch.Tensor)
+        D, H, W, C = (int(v) for v in psf.shape)
+        self.shape = (D, H, W, C)
+        by_depth = issubclass(algo_cls, ADMM) and D > 1
+        # unit = (first depth plane, number of depth planes, channel)
+        self.units = [(d, 1, c) for d in range(D) for c in range(C)] if by_depth else [(0, D, c) for c in range(C)]
+        self._solvers = {}
+        self._recv = None
+
+    def _solver(self, u):
+        if u not in self._solvers:
+            d0, nd, c = self.units[u]
+            sub = self.psf[d0:d0 + nd, :, :, c:c + 1]
+            sub = sub.contiguous() if self.is_torch else np.ascontiguousarray(sub)
+            self._solvers[u] = self.algo_cls(sub, **self.kw)
+        return self._solvers[u]
+
+    def __call__(self, data, n_iter):
+        world, rank = _world(self.group)
+        D, H, W, C = self.shape
+        if data.ndim == 4:
+            assert data.shape[0] == 1, "one frame: (H, W, C) or (1, H, W, C)"
+            data = data[0]
+        assert tuple(data.shape) == (H, W, C), "data must match the PSF's (H, W, C)"
+        lo, hi = shard_bounds(len(self.units), world, rank)
+        nd = self.units[0][1]                      # depth planes per unit (the same for every unit)
+        planes, dev, tdtype = [], torch.device("cpu"), torch.float32
+        for u in range(lo, hi):
+            rec = self._solver(u)
+            dev, tdtype = rec._device, rec._tdtype
+            ch = self.units[u][2]
+            y = data[:, :, ch:ch + 1]
+            rec.set_data(y.contiguous() if self.is_torch else np.ascontiguousarray(y))
+            out = rec.apply(n_iter=n_iter, disp_iter=None, plot=False)          # (nd, H, W, 1)
+            out = out if self.is_torch else torch.from_numpy(out)
+            planes.append(out.reshape(nd, H, W).to(dev))
+        if world > 1:
+            if not planes:                         # more ranks than units: take part in the gather only
+                probe = self._solver(0)            # (device / dtype of the receive buffer)
+                dev, tdtype = probe._device, probe._tdtype
+            cap = -(-len(self.units) // world)
+            if self._recv is None:
+                self._recv = torch.empty((world * cap, nd, H, W), dtype=tdtype, device=dev)
+                self._send = torch.zeros((cap, nd, H, W), dtype=tdtype, device=dev)
+            for i, p in enumerate(planes):
+                self._send[i].copy_(p)
+            dist.all_gather_into_tensor(self._recv, self._send, group=self.group)    # the single collective
+            allp = [self._recv[r * cap + i] for r in range(world)
+                    for i in range(shard_bounds(len(self.units), world, r)[1] - shard_bounds(len(self.units), world, r)[0])]
+        else:
+            allp = planes
+        full = torch.empty((D, H, W, C), dtype=allp[0].dtype, device=allp[0].device)
+        for (d0, n, c), p in zip(self.units, allp):
+            full[d0:d0 + n, :, :, c] = p
+        if self.is_torch:
+            return full.to(self.psf.device)
+        return full.cpu().numpy()

@@ -69,6 +69,57 @@ def test_sharded_batch_world2_gloo(emu_lib, tmp_path):
     assert np.array_equal(a, b)
 
 
+def _plane_worker(rank, world, port, emu_path, out_dir):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LPC_EMU_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lenslesspicam_amd as lpa
+    from lenslesspicam_amd import _native, recon
+    from lenslesspicam_amd.dist import PlaneShardedReconstructor
+
+    lib = _native.Lib(emu_path)
+    recon.runtime = lambda dtype="float32": (lib, torch.device("cpu"))
+    rng = np.random.default_rng(1)
+    psf = rng.random((2, 12, 16, 3), dtype=np.float32) ** 4      # 2 depth planes x 3 channels
+    psf /= np.linalg.norm(psf.ravel())
+    y = rng.random((12, 16, 3), dtype=np.float32)
+    # ADMM: 6 (depth, channel) units over the ranks; FISTA / Nesterov: 3 channel units (step size and start value
+    # are taken per channel ACROSS depth, gd.py:100-112)
+    for cls, kw, n_units in ((lpa.ADMM, dict(tau=2e-6, mu2=1e-4), 6), (lpa.FISTA, {}, 3),
+                             (lpa.NesterovGradientDescent, {}, 3)):
+        sharded = PlaneShardedReconstructor(cls, psf, **kw)
+        assert len(sharded.units) == n_units
+        got = sharded(y, n_iter=5)
+        whole = cls(psf, **kw)
+        whole.set_data(y)
+        ref = whole.apply(n_iter=5, disp_iter=None, plot=False)
+        assert got.shape == ref.shape == (2, 12, 16, 3)
+        assert np.array_equal(got, ref), (rank, cls.__name__, float(np.abs(got - ref).max()))
+        again = sharded(y[None] * np.float32(0.5), n_iter=2)      # the solvers are kept; (1, H, W, C) accepted
+        whole.set_data(y * np.float32(0.5))
+        assert np.array_equal(again, whole.apply(n_iter=2, disp_iter=None, plot=False))
+    gray = psf[:1, :, :, :1].copy()                               # one unit, two ranks: rank 1 only gathers
+    one = PlaneShardedReconstructor(lpa.ADMM, torch.from_numpy(gray))(torch.from_numpy(y[:, :, :1].copy()), n_iter=3)
+    solo = lpa.ADMM(torch.from_numpy(gray))
+    solo.set_data(torch.from_numpy(y[:, :, :1].copy()))
+    assert isinstance(one, torch.Tensor) and torch.equal(one, solo.apply(n_iter=3, disp_iter=None, plot=False))
+    np.save(os.path.join(out_dir, f"plane_rank{rank}.npy"), got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_plane_sharded_single_frame_world2_gloo(emu_lib, tmp_path):
+    """SURVEY section 8e (optional row): ONE frame split by colour channel / depth plane over the ranks."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_plane_worker, args=(2, port, emu_lib.path, str(tmp_path)), nprocs=2, join=True)
+    assert np.array_equal(np.load(tmp_path / "plane_rank0.npy"), np.load(tmp_path / "plane_rank1.npy"))
+
+
 def test_shard_bounds_cover_everything():
     from lenslesspicam_amd.dist import shard_bounds
 
