@@ -3,15 +3,21 @@ Cache?): PYTHONPATH=. python tools/batch_scaling.py [H W]"""
 import sys
 import time
 
+import numpy as np
 import torch
 
 import lenslesspicam_amd as lpa
-from oracle import lensless_oracle as orc   # synthetic PSF only (tool, not product)
+
+
+def synthetic_psf(H, W, C, seed=1):
+    """caustic-like random pattern, unit l2 norm (timing input only)"""
+    p = np.random.default_rng(seed).random((1, H, W, C), dtype=np.float32) ** 8
+    return p / np.linalg.norm(p.ravel())
 
 
 def main():
     H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (270, 480)
-    psf = torch.from_numpy(orc.synthetic_psf(1, H, W, 3, seed=1)).cuda()
+    psf = torch.from_numpy(synthetic_psf(H, W, 3)).cuda()
     for B in (1, 2, 4, 8, 16, 32, 64, 128):
         rec = lpa.ADMM(psf)
         rec.set_data(torch.rand((B, 1, H, W, 3), device="cuda"))

@@ -3,10 +3,10 @@
 import sys
 import time
 
+import numpy as np
 import torch
 
 import lenslesspicam_amd as lpa
-from oracle import lensless_oracle as orc   # synthetic PSF only (tool, not product)
 
 
 def rate(cls, psf, y, n):
@@ -21,10 +21,16 @@ def rate(cls, psf, y, n):
     return n / (time.perf_counter() - t0)
 
 
+def synthetic_psf(H, W, C, seed=1):
+    """caustic-like random pattern, unit l2 norm (timing input only)"""
+    p = np.random.default_rng(seed).random((1, H, W, C), dtype=np.float32) ** 8
+    return p / np.linalg.norm(p.ravel())
+
+
 def main():
     H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3040, 4056)
     for C in (1, 3):
-        psf = torch.from_numpy(orc.synthetic_psf(1, H, W, C, seed=1)).cuda()
+        psf = torch.from_numpy(synthetic_psf(H, W, C)).cuda()
         y = torch.rand((1, H, W, C), device="cuda")
         for name, cls, n in (("ADMM", lpa.ADMM, 40), ("FISTA", lpa.FISTA, 60)):
             r = rate(cls, psf, y, n)
