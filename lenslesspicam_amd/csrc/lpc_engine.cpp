@@ -250,6 +250,8 @@ static int setup_geometry(Engine* e) {
   e->xhalf_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && g.Wp % 4 == 0 &&
                   ((e->rows_half && e->static_rows) || (!e->rows_half && e->static_prow)) &&
                   !e->fuse_rows && !std::getenv("LPC_NO_XHALF") && !std::getenv("LPC_K1_SCALAR");
+  // ... and outside the sensor window that half works from HV alone (AdmmScalars::xiw); LPC_XI_FULL = every pixel alike
+  e->xi_window = e->xhalf_rows && !std::getenv("LPC_XI_FULL");
   e->gd_fuse_fwd = c.algo >= LPC_ALGO_GD && e->rows_half && e->static_rows && !std::getenv("LPC_GD_NO_FUSE_FWD");
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
   const int ntc = (g.Wc + e->T - 1) / e->T;
@@ -368,6 +370,8 @@ static AdmmScalars admm_scalars(const Engine* e, const double cur[4]) {
   p.r_mu2p = (real)(1.0 / (double)p.mu2p); p.r_mu3p = (real)(1.0 / (double)p.mu3p);
   p.clamp_cur = e->vw_cur ? 1 : 0;
   p.clamp_old = e->vw_old ? 1 : 0;
+  p.xiw = e->xi_window ? 1 : 0;
+  p.xi_store = 1;              // admm_iterate clears it on all but the last iteration of a call
   return p;
 }
 
@@ -461,6 +465,7 @@ static int admm_iterate(Engine* e, int n_iter) {
     double par[4];
     admm_params(e, e->iters_done, par);
     AdmmScalars sc = admm_scalars(e, par);
+    sc.xi_store = (it + 1 == n_iter || !sc.xiw) ? 1 : 0;
     bool rows_done = false;
 #ifndef LPC_DOUBLE
     if (e->fuse_rows) {
@@ -1136,7 +1141,10 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
       // rho and writes eta0, eta1, rho, r_sp = 9R (SURVEY's 15R + R0 minus its X part: reads HV, X, xi, y, writes xi, X,
       // a); the row kernel reads r_sp (R) and xi, HV, HV_old, y (3R + R0), writes xi (R) and the two spectra (2S).
       case LPC_K_SPATIAL: b = e->fuse_rows ? 12.0 * R + R0 + 2.0 * S : (e->xhalf_rows ? 9.0 * R : 15.0 * R + R0); break;
-      case LPC_K_ROW_FWD: b = e->fuse_rows ? 0.0 : (e->xhalf_rows ? 5.0 * R + R0 + 2.0 * S : 2.0 * R + 2.0 * S); break;
+      // ... with xi confined to the sensor window (AdmmScalars::xiw) the row kernel reads r_sp, HV everywhere (2R) and
+      // xi, HV_old / writes xi only over the window (3 window-sized arrays per plane) and y: 2R + 3 Rw + R0 + 2S
+      case LPC_K_ROW_FWD: b = e->fuse_rows ? 0.0 : (e->xi_window ? 2.0 * R + 3.0 * eb * g.H * g.W * e->P + R0 + 2.0 * S
+                                  : e->xhalf_rows ? 5.0 * R + R0 + 2.0 * S : 2.0 * R + 2.0 * S); break;
       case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
       case LPC_K_COL_MID: b = 4.0 * S + Sc + eb * g.Hp * g.Wc; break;  // + H (complex) + |G| (real, one plane)
       case LPC_K_COL_A_INV: b = split ? 4.0 * S : 0.0; break;

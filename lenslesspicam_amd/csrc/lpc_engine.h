@@ -87,6 +87,7 @@ struct lpc_engine {
   bool rows_r16 = false;   // 4096-point rows as 16.16.16 instead of 8.8.8.8
   int static_rows = 0;     // length of the half-row transform when a compile-time plan serves it (lpc_sfft.h), else 0
   bool xhalf_rows = false; // ADMM: xi / a = mu1 X - xi computed by the forward row kernel (k_admm_rows_fused<.., TVHALF = false>)
+  bool xi_window = false;  // ... which then skips xi / HV_old outside the sensor window (AdmmScalars::xiw)
   bool fuse_rows = false;  // ADMM: the image-domain kernel is fused into the forward row pass (k_admm_rows_fused)
   bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (LPC_MID_LDS=1: off)
   bool rows_r2 = false; // row plans end in a radix-2 stage: fold it into the Hermitian (un)tangling

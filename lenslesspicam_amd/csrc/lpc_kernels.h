@@ -889,6 +889,13 @@ struct AdmmScalars {
   real m_in_p, m_out_p;  // X_divmat of the previous iteration (its X is recomputed, never stored)
   // correctly rounded reciprocals of the step sizes the kernels divide by (see div_by)
   real r_mu2, r_mu3, r_mu2p, r_mu3p;
+  // Outside the sensor window the data term has no measurement: X_divmat = 1/mu1 there (admm.py:193), so
+  //   X = xi/mu1 + HV,   a = mu1 X - xi = mu1 HV,   xi' = xi + mu1 (HV' - X) = mu1 (HV' - HV)
+  // -- neither `a` nor the next xi depends on the stored xi.  xiw: the X half of the forward rows works from HV alone
+  // outside the window (3/4 of the padded frame: no xi read, no HV_old read, no xi write); xi_store: this is the last
+  // iteration of the lpc_iterate() call, write xi = mu1p (HV - HV_old) there as well so that every read-out between
+  // calls (lpc_get_state, plug-and-play entries) finds the whole array valid.
+  int xiw, xi_store;
   // The reference clamps the image estimate IN PLACE whenever _form_image runs (admm.py:331-338: negative entries of
   // the sensor window become 0), and only the W-update ever sees that clamped copy (everything else works from the
   // cached Psi V / H V).  The clamp is a pure function of V, so no copy is kept: clamp_cur / clamp_old say that the
@@ -1256,7 +1263,10 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
   const int tid = threadIdx.x;
   const unsigned nblk = gridDim.x, bid = blockIdx.x;   // XCD-aware order (see k_admm_spatial)
   const unsigned qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-  const unsigned tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
+  // TVHALF: each XCD gets a contiguous band of rows (the halo rows are shared through ITS L2).  X half only: no row
+  // needs a neighbour, and rows inside the sensor window cost more than rows outside (AdmmScalars::xiw) -- bands would
+  // leave the XCDs that hold the window rows working while the others idle, so rows go round-robin over the XCDs
+  const unsigned tile = TVHALF ? (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx : bid;
   const int gr = (int)(tile >> 1), arr = (int)(tile & 1);
   const long pl = blockIdx.y;
   const long poff = pl * g.rplane;
@@ -1378,13 +1388,16 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
     const bool row_in = (gr >= g.sh) && (gr < g.sh + g.H);
     const float* y = Y + (long)dpl * g.uplane + (long)(gr - g.sh) * g.W;     // dereferenced only when row_in
     const bool y4 = ((g.sw | g.W) & 3) == 0;                                 // window and pitch allow float4 loads of y
-    struct QuadX { float4 hv, xi, ho; float ys[4]; bool ins[4]; };
+    struct QuadX { float4 hv, xi, ho; float ys[4]; bool ins[4]; bool skip; };
     auto load_quadx = [&](int q) {
       QuadX c;
       const int gc = 4 * q;
-      c.hv = ld4(HV + o_row + gc); c.xi = ld4(xi + o_row + gc);
-      c.ho = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (!p.first) c.ho = ld4(HVold + o_row + gc);
+      // the whole quad lies outside the sensor window: HV is all it needs (see AdmmScalars::xiw)
+      c.skip = p.xiw && !(row_in && gc + 4 > g.sw && gc < g.sw + g.W);
+      c.hv = ld4(HV + o_row + gc);
+      c.xi = c.ho = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!c.skip) c.xi = ld4(xi + o_row + gc);
+      if (!p.first && (!c.skip || p.xi_store)) c.ho = ld4(HVold + o_row + gc);
 #pragma unroll
       for (int i = 0; i < 4; ++i) { c.ys[i] = 0.f; c.ins[i] = false; }
       if (row_in) {
@@ -1421,6 +1434,11 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
       for (int i = 0; i < 4; ++i) {
         float xiv = xis[i];
         const float hv = hvs[i], yv = ys[i];
+        if (p.xiw && !ins[i]) {      // outside the window: a = mu1 HV, xi = mu1p (HV - HV_old) (stored on request only)
+          xin[i] = p.first ? 0.f : p.mu1p * (hv - hos[i]);
+          as[i] = p.mu1 * hv;
+          continue;
+        }
         if (!p.first) {
           const float xo = (ins[i] ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
           xiv = xiv + p.mu1p * (hv - xo);
@@ -1429,7 +1447,7 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
         xin[i] = xiv;
         as[i] = p.mu1 * xnew - xiv;
       }
-      st4(xi + o_row + gc, make_float4(xin[0], xin[1], xin[2], xin[3]));
+      if (!c.skip || p.xi_store) st4(xi + o_row + gc, make_float4(xin[0], xin[1], xin[2], xin[3]));
       s[lds_slot<SK>(2 * q)] = make_real2(as[0], as[1]);
       s[lds_slot<SK>(2 * q + 1)] = make_real2(as[2], as[3]);
     }
@@ -1463,8 +1481,12 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p
   auto src = [&](int i, int) {
     const long o = o_row + i;
     const bool inside = row_in && (i >= g.sw) && (i < g.sw + g.W);
-    const float yv = inside ? y[i - g.sw] : 0.f;
     const float hv = HV[o];
+    if (p.xiw && !inside) {        // outside the sensor window (see AdmmScalars::xiw)
+      if (p.xi_store) xi[o] = p.first ? 0.f : p.mu1p * (hv - HVold[o]);
+      return make_real2(Rsp[o], p.mu1 * hv);
+    }
+    const float yv = inside ? y[i - g.sw] : 0.f;
     float xiv = xi[o];
     if (!p.first) {
       const float xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * HVold[o] + yv);   // previous X

@@ -434,6 +434,48 @@ def test_other_baseline_shapes_static_plans(backend, monkeypatch, static, shape,
     assert ("[static" in info) == static, info        # the plan tables really matched (no silent run-time fallback)
 
 
+@pytest.mark.parametrize("shape", [(270, 480, 1), (3, 1014, 1)], ids=["paired960", "paired2048"])
+def test_xi_outside_the_sensor_window(backend, monkeypatch, shape):
+    """Outside the sensor window X_divmat = 1/mu1, so a = mu1 X - xi = mu1 HV and xi' = mu1 (HV' - HV): the X half
+    of the forward rows skips xi / HV_old there on all but the last iteration of a call (AdmmScalars::xiw).  Every
+    read-out between calls must still see the reference's xi and X on the WHOLE padded frame, multi-iteration calls
+    must equal single-iteration calls, and the image must stay on the full-xi path's (LPC_XI_FULL) to round-off."""
+    H, W, C = shape
+    rng = np.random.default_rng(8)
+    psf = orc.synthetic_psf(1, H, W, C, seed=8)
+    y = rng.random((H, W, C), dtype=np.float32)
+    o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
+    o.set_data(y)
+    o.reset()
+    for _ in range(4):
+        o.step()                                      # (no _form_image: it clamps V in place)
+
+    def run(steps):
+        rec = lpa.ADMM(torch.from_numpy(psf), tau=2e-6, mu2=1e-4)
+        assert "X half" in rec._handle.plan_info()
+        rec.set_data(torch.from_numpy(y))
+        rec.apply(n_iter=0, disp_iter=None, plot=False)
+        for n in steps:
+            rec._iterate(n)
+        return rec, np.asarray(rec._xi).copy(), np.asarray(rec._X).copy(), np.asarray(rec._image_est).copy()
+
+    rec, xi4, x4, v4 = run([4])                       # one call: three iterations never store xi outside the window
+    _, xi1, x1, v1 = run([1, 1, 1, 1])                # four calls: every iteration stores it
+    scale = float(np.abs(o.xi.numpy()).max())
+    assert scale > 0
+    assert np.abs(xi4 - o.xi.numpy()).max() <= 2e-5 * scale and np.abs(xi1 - o.xi.numpy()).max() <= 2e-5 * scale
+    assert rel(x4, o.X.numpy()) <= 5e-6 and rel(x1, o.X.numpy()) <= 5e-6
+    assert rel(v4, o.V.numpy()) <= 5e-6
+    assert np.array_equal(v4, v1) and np.array_equal(x4, x1) and np.array_equal(xi4, xi1)
+    sh, sw = (int(v) for v in rec._start_idx)
+    outside = np.ones(xi4.shape[1:3], bool)
+    outside[sh:sh + H, sw:sw + W] = False
+    assert np.abs(xi4[0][outside]).max() > 0          # the dual is alive out there, not just zeros
+    monkeypatch.setenv("LPC_XI_FULL", "1")
+    _, xif, xf, vf = run([4])
+    assert rel(vf, v4) <= 2e-6 and np.abs(xif - xi4).max() <= 2e-5 * scale
+
+
 def test_c4_sequential_middle_on_one_frame(backend, monkeypatch):
     """C4's fused ADMM middle takes the two spectra one after the other through a 16-column tile
     (k_cols_mid_admm_seq); the engine selects it for large batches only, LPC_MID_SEQ forces it onto one
