@@ -3,12 +3,15 @@
 
 // column pass A (only when split) over nplanes planes; inverse => conj twiddles before FFT
 int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1, int kid,
-                      bool crop_rows_only) {
+                      bool crop_rows_only, real sb_outside_scale) {
   if (e->N1 == 1) return 0;
   const PlaneGeom& g = e->g;
   ColPass cp = e->passA;
   cp.tw_mode = inverse ? 2 : 1;
   cp.zr0 = zr0; cp.zr1 = zr1;
+  if (!inverse && sb_outside_scale != (real)0.) {   // ADMM work spectra: planes [P, 2P) = SB, rows outside the window
+    cp.sc_plane0 = e->P; cp.sc_r0 = g.sh; cp.sc_r1 = g.sh + g.H; cp.sc = sb_outside_scale;
+  }
   if (inverse && crop_rows_only) {   // the row pass that follows reads spectrum rows (sh + u + Hp/2) mod Hp, u < H
     cp.need0 = (g.sh + g.Hp / 2) % g.Hp;
     cp.needn = g.H;
@@ -102,7 +105,10 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const bool split = e->N1 > 1;
-  if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, false, 0, g.Hp, LPC_K_COL_A_FWD));
+  // sc.skipa: the rows of SB outside the sensor window were not re-transformed, they still hold what the last inverse
+  // row pass consumed = rfft(HV row) / Wp; a = mu1 HV there
+  if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, false, 0, g.Hp, LPC_K_COL_A_FWD, false,
+                               sc.skipa ? sc.mu1 * (real)g.Wp : (real)0.));
   {
     ColPass cp = e->passB;
     const dim3 grid(cp.G * cp.ntile_c, e->P);

@@ -252,12 +252,14 @@ static int setup_geometry(Engine* e) {
                   !e->fuse_rows && !std::getenv("LPC_NO_XHALF") && !std::getenv("LPC_K1_SCALAR");
   // ... and outside the sensor window that half works from HV alone (AdmmScalars::xiw); LPC_XI_FULL = every pixel alike
   e->xi_window = e->xhalf_rows && !std::getenv("LPC_XI_FULL");
+  e->hv_skip = e->xi_window && e->rows_half && e->static_rows && e->N1 > 1 && !std::getenv("LPC_HV_FULL");
   e->gd_fuse_fwd = c.algo >= LPC_ALGO_GD && e->rows_half && e->static_rows && !std::getenv("LPC_GD_NO_FUSE_FWD");
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
   const int ntc = (g.Wc + e->T - 1) / e->T;
   ColPass& A = e->passA;
   A.N = e->N1; A.G = e->N2; A.istride = e->N2; A.gstride = 1; A.T = e->T; A.ntile_c = ntc;
   A.tw_mode = 0; A.zr0 = 0; A.zr1 = g.Hp; A.twH = e->twH; A.need0 = 0; A.needn = g.Hp;
+  A.sc_plane0 = INT_MAX; A.sc_r0 = 0; A.sc_r1 = g.Hp; A.sc = (real)1.;
   A.tdiv = make_fastdiv((unsigned)e->T); A.tcdiv = make_fastdiv((unsigned)ntc);
   ColPass& B = e->passB;
   B = A;
@@ -372,6 +374,7 @@ static AdmmScalars admm_scalars(const Engine* e, const double cur[4]) {
   p.clamp_old = e->vw_old ? 1 : 0;
   p.xiw = e->xi_window ? 1 : 0;
   p.xi_store = 1;              // admm_iterate clears it on all but the last iteration of a call
+  p.skipa = p.skiphv = 0;      // set by admm_iterate inside a call (AdmmScalars::skipa)
   return p;
 }
 
@@ -437,7 +440,7 @@ static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real
   else if (xhalf) LPC_OK(admm_rows_fwd_x(e, sc));
   else LPC_OK(admm_rows_fwd(e));
   LPC_OK(admm_cols(e, sc));
-  return admm_rows_inv(e, Vout, HVout);
+  return admm_rows_inv(e, Vout, HVout, sc.skiphv != 0);
 }
 
 
@@ -466,6 +469,12 @@ static int admm_iterate(Engine* e, int n_iter) {
     admm_params(e, e->iters_done, par);
     AdmmScalars sc = admm_scalars(e, par);
     sc.xi_store = (it + 1 == n_iter || !sc.xiw) ? 1 : 0;
+    // rows wholly outside the sensor window: from the second iteration of a call on, SB still holds their row spectra
+    // (nothing else touches the work spectrum inside this loop); the last iteration runs complete (it stores xi out
+    // there), and the last three write H V there: xi = mu1p (HV - HV_old) of the final X half and every read-out after
+    // the call need HV_{n-2}, HV_{n-1}, HV_n whole
+    sc.skipa = (e->hv_skip && it > 0 && !sc.xi_store) ? 1 : 0;
+    sc.skiphv = (e->hv_skip && it + 3 < n_iter) ? 1 : 0;
     bool rows_done = false;
 #ifndef LPC_DOUBLE
     if (e->fuse_rows) {
@@ -1131,6 +1140,7 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
   const double R0 = eb * g.H * g.W * e->Pdata;
   const double Sc = 2 * eb * g.Hp * g.Wc * e->Ppsf;   // spectral constants
   const bool split = e->N1 > 1;
+  const double fr = (double)g.H / (double)g.Hp;
   double b = 0.0;
   if (e->cfg.algo == LPC_ALGO_ADMM) {
     switch (kid) {
@@ -1143,12 +1153,15 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
       case LPC_K_SPATIAL: b = e->fuse_rows ? 12.0 * R + R0 + 2.0 * S : (e->xhalf_rows ? 9.0 * R : 15.0 * R + R0); break;
       // ... with xi confined to the sensor window (AdmmScalars::xiw) the row kernel reads r_sp, HV everywhere (2R) and
       // xi, HV_old / writes xi only over the window (3 window-sized arrays per plane) and y: 2R + 3 Rw + R0 + 2S
-      case LPC_K_ROW_FWD: b = e->fuse_rows ? 0.0 : (e->xi_window ? 2.0 * R + 3.0 * eb * g.H * g.W * e->P + R0 + 2.0 * S
+      // ... and with the H V row transforms skipped on rows wholly outside the window (AdmmScalars::skipa, steady state
+      // of a long call; fr = H / Hp): rows fwd (1 + fr) R + 3 Rw + R0 + (1 + fr) S, rows inv (1 + fr) (S + R)
+      case LPC_K_ROW_FWD: b = e->fuse_rows ? 0.0 : (e->hv_skip ? (1.0 + fr) * R + 3.0 * eb * g.H * g.W * e->P + R0 + (1.0 + fr) * S
+                                  : e->xi_window ? 2.0 * R + 3.0 * eb * g.H * g.W * e->P + R0 + 2.0 * S
                                   : e->xhalf_rows ? 5.0 * R + R0 + 2.0 * S : 2.0 * R + 2.0 * S); break;
       case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
       case LPC_K_COL_MID: b = 4.0 * S + Sc + eb * g.Hp * g.Wc; break;  // + H (complex) + |G| (real, one plane)
       case LPC_K_COL_A_INV: b = split ? 4.0 * S : 0.0; break;
-      case LPC_K_ROW_INV: b = 2.0 * S + 2.0 * R; break;
+      case LPC_K_ROW_INV: b = e->hv_skip ? (1.0 + fr) * (S + R) : 2.0 * S + 2.0 * R; break;
       default: return fail("bad kernel id");
     }
   } else if (e->cfg.algo >= LPC_ALGO_GD) {
@@ -1175,6 +1188,8 @@ int lpc_plan_info(lpc_handle e, char* buf, size_t n) {
     s += reg ? ", middle in registers" : (e->static_mid ? ", LDS middle [static]" : ", LDS middle");
     s += e->fuse_rows ? "; image-domain kernel fused into the forward rows"
                       : (e->xhalf_rows ? "; tiled TV / W kernel + X half inside the forward rows" : "; stand-alone image-domain kernel");
+    if (e->xi_window) s += e->hv_skip ? " (xi inside the sensor window only, H V row transforms skipped outside it)"
+                                      : " (xi inside the sensor window only)";
   }
   std::snprintf(buf, n, "%s", s.c_str());
   return 0;

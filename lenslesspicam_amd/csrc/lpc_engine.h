@@ -12,6 +12,7 @@
 #include "lpc.h"
 
 #include <algorithm>
+#include <climits>
 #include <string>
 #include <type_traits>
 #include <unordered_set>
@@ -88,6 +89,7 @@ struct lpc_engine {
   int static_rows = 0;     // length of the half-row transform when a compile-time plan serves it (lpc_sfft.h), else 0
   bool xhalf_rows = false; // ADMM: xi / a = mu1 X - xi computed by the forward row kernel (k_admm_rows_fused<.., TVHALF = false>)
   bool xi_window = false;  // ... which then skips xi / HV_old outside the sensor window (AdmmScalars::xiw)
+  bool hv_skip = false;    // ... and rows wholly outside it skip the H V row transforms in both directions (AdmmScalars::skipa)
   bool fuse_rows = false;  // ADMM: the image-domain kernel is fused into the forward row pass (k_admm_rows_fused)
   bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (LPC_MID_LDS=1: off)
   bool rows_r2 = false; // row plans end in a radix-2 stage: fold it into the Hermitian (un)tangling
@@ -273,13 +275,14 @@ int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int ki
 int rows_inv_single(Engine* e, const real2* S, const RealDst& dst, int nplanes, int kid);
 int admm_rows_fwd(Engine* e);                                   // e->Rsp, e->Aarr -> the two work spectra
 int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc);          // e->Rsp and (xi, HV, HV_old, y) -> the two work spectra
-int admm_rows_inv(Engine* e, real* Vout, real* HVout);          // the two work spectra -> V, H V
+int admm_rows_inv(Engine* e, real* Vout, real* HVout, bool skip_hv_outside = false);          // the two work spectra -> V, H V
 int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real* Vo);   // k_admm_rows_fused
 // lpc_cols.cpp
-int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1, int kid, bool crop_rows_only = false);
+int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1, int kid, bool crop_rows_only = false,
+               real sb_outside_scale = (real)0.);
 int cols_passB_fwd(Engine* e, real2* S, int nplanes, int zr0, int zr1);
 int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, int zr1, bool crop_rows_only = false);
-int admm_cols(Engine* e, const AdmmScalars& sc);                // [pass A] -> fused ADMM middle -> [inverse pass A]
+int admm_cols(Engine* e, const AdmmScalars& sc);   // sc.skipa: forward pass A rescales the kept rows of SB                // [pass A] -> fused ADMM middle -> [inverse pass A]
 // lpc_gd.cpp
 struct GdScalars;
 int gd_rows_mid(Engine* e);                                     // irfft rows -> residual -> rfft rows (S -> S2)

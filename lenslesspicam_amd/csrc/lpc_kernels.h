@@ -249,11 +249,14 @@ static __device__ __forceinline__ void tangle_half_load(real2* s, int M, const r
 template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                    const real2* LPC_RESTRICT SA, const real2* LPC_RESTRICT SB,
-                                                   real* LPC_RESTRICT A, real* LPC_RESTRICT B) {
+                                                   real* LPC_RESTRICT A, real* LPC_RESTRICT B, int skip_b_outside) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, row = blockIdx.x >> 1, arr = blockIdx.x & 1;
+  // block b runs on XCD b % 8: the array flips every fourth row so that each XCD transforms rows of both (the rows of
+  // B outside the sensor window may be skipped: with `arr = b & 1` only the odd XCDs would have less to do: 0.49 -> 0.47 ms, r02ak)
+  const int tid = threadIdx.x, row = blockIdx.x >> 1, arr = (blockIdx.x ^ (blockIdx.x >> 3)) & 1;
   const long pl = blockIdx.y;
+  if (arr == 1 && skip_b_outside && (row < g.sh || row >= g.sh + g.H)) return;   // AdmmScalars::skiphv
   tangle_half_load<NT, EMAX, SK>(s, g.Wp >> 1, twW, (arr ? SB : SA) + pl * g.cplane + (long)row * g.cpitch, tid);
   __syncthreads();
   real2* o2 = (real2*)((arr ? B : A) + pl * g.rplane + (long)row * g.rpitch);
@@ -432,6 +435,11 @@ struct ColPass {
   int need0, needn; // inverse only: rows r with ((r - need0) mod Hp) >= needn are never read again
                     // (they fall outside the crop window after ifftshift) and are not stored
   const real2* twH;  // exp(-2 pi i q / Hp), q in [0, Hp)
+  // forward pass A of the ADMM work spectra: planes >= sc_plane0 (the spectrum of `a`) are multiplied by `sc` on load
+  // in rows outside [sc_r0, sc_r1) -- rows whose forward row transform was skipped because it is mu1 * Wp times the
+  // row spectrum the last inverse row pass consumed (AdmmScalars::skipa).  sc_plane0 = INT_MAX: off.
+  int sc_plane0, sc_r0, sc_r1;
+  real sc;
   FastDiv tdiv;     // fast divide by T
   FastDiv tcdiv;    // fast divide by ntile_c
 };
@@ -453,6 +461,7 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
     real2 x = make_real2((real)0., (real)0.);
     const int row = row0 + i * cp.istride;
     if (c0 + c < g.Wc && (INV || (row >= cp.zr0 && row < cp.zr1))) x = base[i * rstep + c];
+    if (!INV && (int)blockIdx.y >= cp.sc_plane0 && (row < cp.sc_r0 || row >= cp.sc_r1)) x = cscale(x, cp.sc);
     return x;
   };
   // compile-time plans (short transforms): the plan's twiddles and this group's four-step twiddles
@@ -896,6 +905,13 @@ struct AdmmScalars {
   // iteration of the lpc_iterate() call, write xi = mu1p (HV - HV_old) there as well so that every read-out between
   // calls (lpc_get_state, plug-and-play entries) finds the whole array valid.
   int xiw, xi_store;
+  // Rows that lie outside the sensor window altogether carry a = mu1 HV, and HV of such a row is the (unnormalised)
+  // inverse row transform of the spectrum row SB[r] that the last inverse row pass read: rfft(a row) = mu1 Wp SB[r].
+  // skipa: the forward row blocks of `a` outside the window do nothing (SB[r] is still in place from the previous
+  // iteration of this call; forward pass A applies the factor, ColPass::sc); skiphv: the inverse row blocks of HV
+  // outside the window do nothing (no later iteration of this call reads those rows of HV -- the engine keeps the last
+  // three iterations of a call complete so that xi, X and HV read out whole).
+  int skipa, skiphv;
   // The reference clamps the image estimate IN PLACE whenever _form_image runs (admm.py:331-338: negative entries of
   // the sensor window become 0), and only the W-update ever sees that clamped copy (everything else works from the
   // cached Psi V / H V).  The clamp is a pure function of V, so no copy is kept: clamp_cur / clamp_old say that the
@@ -1267,12 +1283,16 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
   // needs a neighbour, and rows inside the sensor window cost more than rows outside (AdmmScalars::xiw) -- bands would
   // leave the XCDs that hold the window rows working while the others idle, so rows go round-robin over the XCDs
   const unsigned tile = TVHALF ? (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx : bid;
+  // (block b runs on XCD b % 8: the even XCDs transform the rows of r_sp, the odd ones form and transform the rows of
+  // `a` -- about twice the work per row, on half of the rows once those outside the sensor window are skipped.
+  // Flipping the pair every fourth row to mix both kinds on every XCD measured SLOWER: 0.47 -> 0.60 ms, r02ak)
   const int gr = (int)(tile >> 1), arr = (int)(tile & 1);
   const long pl = blockIdx.y;
   const long poff = pl * g.rplane;
   const long o_row = poff + (long)gr * g.rpitch;
   const int n4 = g.Wp >> 2;
   if constexpr (!TVHALF) {
+    if (arr == 1 && p.skipa && (gr < g.sh || gr >= g.sh + g.H)) return;   // AdmmScalars::skipa (uniform per block)
     if (arr == 0) {      // the stored row of r_sp: first stage fused into the fill, like k_rfwd_half
       const real2* a2 = (const real2*)(Vold + o_row);
       auto src = [&](int i, int) { return a2[i]; };

@@ -176,7 +176,7 @@ int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real
 }
 
 // ---- ADMM: the two work spectra -> V and H V (padded, no shift) ------------------------------------------------
-int admm_rows_inv(Engine* e, real* Vout, real* HVout) {
+int admm_rows_inv(Engine* e, real* Vout, real* HVout, bool skip_hv_outside) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
@@ -188,7 +188,7 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout) {
       constexpr bool sk = decltype(SKc)::value;
         return launch_k(e, LPC_K_ROW_INV, k_rinv_half<SH::nt, SH::em, sk, SPlanArg<typename SH::plan>>, dim3(2 * g.Hp, e->P), SH::nt,
                         LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, splan_arg<typename SH::plan>(e->planWh), e->planW.tw,
-                      (const real2*)SA, (const real2*)SB, Vout, HVout);
+                      (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
       });
     });
   if (e->rows_half)
@@ -197,7 +197,7 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout) {
       constexpr bool sk = decltype(SK)::value;
       return launch_k(e, LPC_K_ROW_INV, k_rinv_half<nt, em, sk>, dim3(2 * g.Hp, e->P), nt,
                       LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real2*)SA,
-                      (const real2*)SB, Vout, HVout);
+                      (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
     });
   if (e->static_prow == 2048)
     return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<256, 8, true, false, SPlanArg<RowPlan2048>>, dim3(g.Hp, e->P), 256,

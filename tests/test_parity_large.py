@@ -168,7 +168,13 @@ def test_c2_admm_zero_data_fixed_point_and_accounting(c2):
     rec._iterate(2)
     rec._iterate(2)                                           # 2 + 2 launches == 4: exact iteration accounting
     b = rec.get_image_estimate()[0]
-    assert torch.equal(a, b)
+    # (not bit-equal: inside ONE call the rows of H V outside the sensor window skip their row transforms,
+    # AdmmScalars::skipa -- same mathematics, different rounding; one iteration more or less is 4 decades away)
+    scale = float(a.abs().max())
+    assert float((a - b).abs().max()) <= 2e-6 * scale
+    rec.reset()
+    rec._iterate(3)
+    assert float((a - rec.get_image_estimate()[0]).abs().max()) >= 1e-3 * scale
     assert torch.isfinite(a).all() and float(a.min()) >= 0.0
 
 
