@@ -129,19 +129,20 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
       // another's loads and barriers -- 0.650 ms per launch at 64 frames against 0.84 ms for the two-stage 30.18
       // plan (184 registers, one workgroup per CU) and 0.95 ms for 6.6.5.3 (profiles/r02_notes.md section 4)
       constexpr int minw = sizeof(real) == 4 ? 4 : 1;
+      const real sbsc = sc.skipa ? sc.mu1 * (real)g.Wp : (real)0.;   // AdmmScalars::skipa: rows of SB kept from the last inverse rows
       static const bool twlds = getenv("LPC_NO_TW_LDS") == nullptr;
       if (twlds)
       LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<512, 18, SPlanArg<ColPlan540Seq>, 16, minw, true>,
                       dim3(cp.ntile_c, e->P), 512, (size_t)540 * 17 * sizeof(real2), g,
                       splan_arg<ColPlan540Seq>(e->planB), cp, SA, SB, (const real2*)e->Hs, (const real*)e->Gabs,
                       (const real2*)e->phr, (const real2*)e->phc, sc.mu1, sc.mu2, sc.mu3,
-                      (real)1.0 / ((real)g.Hp * (real)g.Wp)));
+                      (real)1.0 / ((real)g.Hp * (real)g.Wp), sbsc));
       else
       LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<512, 18, SPlanArg<ColPlan540Seq>, 16, minw>,
                       dim3(cp.ntile_c, e->P), 512, (size_t)540 * 16 * sizeof(real2), g,
                       splan_arg<ColPlan540Seq>(e->planB), cp, SA, SB, (const real2*)e->Hs, (const real*)e->Gabs,
                       (const real2*)e->phr, (const real2*)e->phc, sc.mu1, sc.mu2, sc.mu3,
-                      (real)1.0 / ((real)g.Hp * (real)g.Wp)));
+                      (real)1.0 / ((real)g.Hp * (real)g.Wp), sbsc));
     }
     else if (e->static_mid == 540) {   // C1 / C4: 540 points x 2 x 8 tile columns = 8640 points = 512 threads x 17
       LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<512, 18, SPlanArg<ColPlan540>, 16, true>, grid, 512,

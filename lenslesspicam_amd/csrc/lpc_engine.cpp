@@ -253,6 +253,9 @@ static int setup_geometry(Engine* e) {
   // ... and outside the sensor window that half works from HV alone (AdmmScalars::xiw); LPC_XI_FULL = every pixel alike
   e->xi_window = e->xhalf_rows && !std::getenv("LPC_XI_FULL");
   e->hv_skip = e->xi_window && e->rows_half && e->static_rows && e->N1 > 1 && !std::getenv("LPC_HV_FULL");
+  // paired 960-point rows of a large batch (C4): same skip, the rows of r_sp / V outside the window ride two per
+  // transform instead (k_rfwd_arrays_x / k_rinv_arrays) and the sequential fused middle rescales the kept rows of SB
+  e->prow_skip = e->xi_window && e->static_prow == 960 && e->static_mid == 541 && e->prow_nt128 && !std::getenv("LPC_HV_FULL");
   e->gd_fuse_fwd = c.algo >= LPC_ALGO_GD && e->rows_half && e->static_rows && !std::getenv("LPC_GD_NO_FUSE_FWD");
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
   const int ntc = (g.Wc + e->T - 1) / e->T;
@@ -473,8 +476,8 @@ static int admm_iterate(Engine* e, int n_iter) {
     // (nothing else touches the work spectrum inside this loop); the last iteration runs complete (it stores xi out
     // there), and the last three write H V there: xi = mu1p (HV - HV_old) of the final X half and every read-out after
     // the call need HV_{n-2}, HV_{n-1}, HV_n whole
-    sc.skipa = (e->hv_skip && it > 0 && !sc.xi_store) ? 1 : 0;
-    sc.skiphv = (e->hv_skip && it + 3 < n_iter) ? 1 : 0;
+    sc.skipa = ((e->hv_skip || e->prow_skip) && it > 0 && !sc.xi_store) ? 1 : 0;
+    sc.skiphv = ((e->hv_skip || e->prow_skip) && it + 3 < n_iter) ? 1 : 0;
     bool rows_done = false;
 #ifndef LPC_DOUBLE
     if (e->fuse_rows) {
@@ -1155,13 +1158,13 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
       // xi, HV_old / writes xi only over the window (3 window-sized arrays per plane) and y: 2R + 3 Rw + R0 + 2S
       // ... and with the H V row transforms skipped on rows wholly outside the window (AdmmScalars::skipa, steady state
       // of a long call; fr = H / Hp): rows fwd (1 + fr) R + 3 Rw + R0 + (1 + fr) S, rows inv (1 + fr) (S + R)
-      case LPC_K_ROW_FWD: b = e->fuse_rows ? 0.0 : (e->hv_skip ? (1.0 + fr) * R + 3.0 * eb * g.H * g.W * e->P + R0 + (1.0 + fr) * S
+      case LPC_K_ROW_FWD: b = e->fuse_rows ? 0.0 : ((e->hv_skip || e->prow_skip) ? (1.0 + fr) * R + 3.0 * eb * g.H * g.W * e->P + R0 + (1.0 + fr) * S
                                   : e->xi_window ? 2.0 * R + 3.0 * eb * g.H * g.W * e->P + R0 + 2.0 * S
                                   : e->xhalf_rows ? 5.0 * R + R0 + 2.0 * S : 2.0 * R + 2.0 * S); break;
       case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
       case LPC_K_COL_MID: b = 4.0 * S + Sc + eb * g.Hp * g.Wc; break;  // + H (complex) + |G| (real, one plane)
       case LPC_K_COL_A_INV: b = split ? 4.0 * S : 0.0; break;
-      case LPC_K_ROW_INV: b = e->hv_skip ? (1.0 + fr) * (S + R) : 2.0 * S + 2.0 * R; break;
+      case LPC_K_ROW_INV: b = (e->hv_skip || e->prow_skip) ? (1.0 + fr) * (S + R) : 2.0 * S + 2.0 * R; break;
       default: return fail("bad kernel id");
     }
   } else if (e->cfg.algo >= LPC_ALGO_GD) {
@@ -1188,7 +1191,7 @@ int lpc_plan_info(lpc_handle e, char* buf, size_t n) {
     s += reg ? ", middle in registers" : (e->static_mid ? ", LDS middle [static]" : ", LDS middle");
     s += e->fuse_rows ? "; image-domain kernel fused into the forward rows"
                       : (e->xhalf_rows ? "; tiled TV / W kernel + X half inside the forward rows" : "; stand-alone image-domain kernel");
-    if (e->xi_window) s += e->hv_skip ? " (xi inside the sensor window only, H V row transforms skipped outside it)"
+    if (e->xi_window) s += (e->hv_skip || e->prow_skip) ? " (xi inside the sensor window only, H V row transforms skipped outside it)"
                                       : " (xi inside the sensor window only)";
   }
   std::snprintf(buf, n, "%s", s.c_str());

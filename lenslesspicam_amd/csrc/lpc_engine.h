@@ -90,6 +90,7 @@ struct lpc_engine {
   bool xhalf_rows = false; // ADMM: xi / a = mu1 X - xi computed by the forward row kernel (k_admm_rows_fused<.., TVHALF = false>)
   bool xi_window = false;  // ... which then skips xi / HV_old outside the sensor window (AdmmScalars::xiw)
   bool hv_skip = false;    // ... and rows wholly outside it skip the H V row transforms in both directions (AdmmScalars::skipa)
+  bool prow_skip = false;  // ... the same for 960-point paired rows of a batch (rows outside the window two per transform)
   bool fuse_rows = false;  // ADMM: the image-domain kernel is fused into the forward row pass (k_admm_rows_fused)
   bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (LPC_MID_LDS=1: off)
   bool rows_r2 = false; // row plans end in a radix-2 stage: fold it into the Hermitian (un)tangling

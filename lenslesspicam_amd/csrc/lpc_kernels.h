@@ -318,23 +318,43 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows_half(PlaneGeom g, PL plan, con
 // ---- inverse, ADMM: spectra SA, SB -> real arrays A, B (no shift, padded) ---------------
 // R2: `plan` is the inverse-row plan whose FIRST stage is the radix-2 one (fused into the tangling); SK is
 // false in that case (the skew is not affine for ns = 2).
+// Rows outside the sensor window taken two at a time (paired-row kernels, AdmmScalars::skipa / skiphv): pair index q ->
+// first row; the rows above the window [0, sh) come first, then the rows below it [sh + H, Hp); an odd count leaves a
+// last pair whose second row is not valid.
+static __device__ __forceinline__ int outside_pair_row(const PlaneGeom& g, int q, bool& second_valid) {
+  const int n0 = g.sh, n1 = g.Hp - (g.sh + g.H), np0 = (n0 + 1) >> 1;
+  const bool below = q >= np0;
+  const int pi = below ? q - np0 : q;
+  second_valid = 2 * pi + 1 < (below ? n1 : n0);
+  return (below ? g.sh + g.H : 0) + 2 * pi;
+}
+static inline int outside_pair_count(const PlaneGeom& g) {
+  return ((g.sh + 1) >> 1) + ((g.Hp - (g.sh + g.H) + 1) >> 1);
+}
+
 template <int NT, int EMAX, bool SK, bool R2, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, PL plan,
                                                      const real2* LPC_RESTRICT SA,
                                                      const real2* LPC_RESTRICT SB,
-                                                     real* LPC_RESTRICT A, real* LPC_RESTRICT B) {
+                                                     real* LPC_RESTRICT A, real* LPC_RESTRICT B, int window_only) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, row = blockIdx.x;
+  const int tid = threadIdx.x;
   const long pl = blockIdx.y;
+  // window_only (AdmmScalars::skiphv; grid.x = H + outside_pair_count): blocks [0, H) = the rows of the sensor window,
+  // both arrays; the others = two rows of A (= V) outside the window per transform, B (= H V) is not produced there
+  const bool pairs = window_only && (int)blockIdx.x >= g.H;
+  bool vb = true;
+  const int row = !window_only ? (int)blockIdx.x
+                               : (pairs ? outside_pair_row(g, (int)blockIdx.x - g.H, vb) : g.sh + (int)blockIdx.x);
   const real2* ia = SA + pl * g.cplane + (long)row * g.cpitch;
-  const real2* ib = SB + pl * g.cplane + (long)row * g.cpitch;
-  if (R2) tangle_r2_load<NT>(s, g.Wp, ia, ib, true, tid);
-  else tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, ia, ib, true, tid);
+  const real2* ib = pairs ? ia + g.cpitch : SB + pl * g.cplane + (long)row * g.cpitch;
+  if (R2) tangle_r2_load<NT>(s, g.Wp, ia, ib, vb, tid);
+  else tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, ia, ib, vb, tid);
   __syncthreads();
   real* a = A + pl * g.rplane + (long)row * g.rpitch;
-  real* b = B + pl * g.rplane + (long)row * g.rpitch;
-  auto out = [&](int i, int, real2 v) { a[i] = v.x; b[i] = v.y; };
+  real* b = pairs ? a + g.rpitch : B + pl * g.rplane + (long)row * g.rpitch;
+  auto out = [&](int i, int, real2 v) { a[i] = v.x; if (vb) b[i] = v.y; };
   if constexpr (is_static_plan<PL>::value)
     fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
   else
@@ -461,7 +481,8 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
     real2 x = make_real2((real)0., (real)0.);
     const int row = row0 + i * cp.istride;
     if (c0 + c < g.Wc && (INV || (row >= cp.zr0 && row < cp.zr1))) x = base[i * rstep + c];
-    if (!INV && (int)blockIdx.y >= cp.sc_plane0 && (row < cp.sc_r0 || row >= cp.sc_r1)) x = cscale(x, cp.sc);
+    if (!INV && (int)blockIdx.y >= cp.sc_plane0)      // uniform per block; one compare, one select, one product per element
+      x = cscale(x, (unsigned)(row - cp.sc_r0) >= (unsigned)(cp.sc_r1 - cp.sc_r0) ? cp.sc : (real)1.);
     return x;
   };
   // compile-time plans (short transforms): the plan's twiddles and this group's four-step twiddles
@@ -816,7 +837,7 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
                                                            real2* LPC_RESTRICT SB, const real2* LPC_RESTRICT Hs,
                                                            const real* LPC_RESTRICT Gabs, const real2* LPC_RESTRICT phr,
                                                            const real2* LPC_RESTRICT phc, real mu1, real mu2, real mu3,
-                                                           real rscale) {
+                                                           real rscale, real sb_outside_scale) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
@@ -829,7 +850,13 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   const real* rb = Gabs + c0;
   const long rstep = g.cpitch;
   const real2 zero = make_real2((real)0., (real)0.);
-  auto inB = [&](int i, int j) { return (c0 + j < g.Wc) ? bb[i * rstep + j] : zero; };
+  // sb_outside_scale != 0 (AdmmScalars::skipa): the rows of SB outside the sensor window were not re-transformed; they
+  // hold rfft(H V row) / Wp from the last inverse row pass, and a = mu1 H V there
+  const real sb_k = sb_outside_scale != (real)0. ? sb_outside_scale : (real)1.;
+  auto inB = [&](int i, int j) {
+    const real2 x = (c0 + j < g.Wc) ? bb[i * rstep + j] : zero;
+    return cscale(x, (unsigned)(i - g.sh) >= (unsigned)g.H ? sb_k : (real)1.);   // one compare, one select, one product
+  };
   auto inA = [&](int i, int j) { return (c0 + j < g.Wc) ? ba[i * rstep + j] : zero; };
   // the twiddle table moves into LDS behind the tile (lpc_sfft.h twiddles_to_lds)
   if (TWLDS) plan = twiddles_to_lds<NT>(plan, s + NELEM, tid);
@@ -1492,8 +1519,23 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p
                                                        real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, row = blockIdx.x;
+  const int tid = threadIdx.x;
   const long pl = blockIdx.y;
+  // p.skipa (grid.x = H + outside_pair_count): blocks [0, H) = the rows of the sensor window as below; the others
+  // transform two rows of r_sp outside the window at once -- `a` = mu1 HV needs no transform there, SB keeps the row
+  // spectra the last inverse row pass read and the fused middle rescales them (AdmmScalars::skipa)
+  if (p.skipa && (int)blockIdx.x >= g.H) {
+    bool v1;
+    const int r0 = outside_pair_row(g, (int)blockIdx.x - g.H, v1);
+    const float* ra = Rsp + pl * g.rplane + (long)r0 * g.rpitch;
+    const float* rb = ra + g.rpitch;
+    auto two = [&](int i, int) { return make_real2(ra[i], v1 ? rb[i] : 0.f); };
+    fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, two, LdsNatural{});
+    real2* o0 = SA + pl * g.cplane + (long)r0 * g.cpitch;
+    untangle_store<NT, SK>(s, g.Wp, g.Wc, o0, o0 + g.cpitch, v1, tid);
+    return;
+  }
+  const int row = p.skipa ? g.sh + (int)blockIdx.x : (int)blockIdx.x;
   const long o_row = pl * g.rplane + (long)row * g.rpitch;
   const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
   const bool row_in = (row >= g.sh) && (row < g.sh + g.H);

@@ -107,15 +107,17 @@ int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc) {
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   if (!e->rows_half) {     // paired rows (static_prow): 960 = 256 threads x 4, 2048 = 256 x 8
+    // sc.skipa: the window rows as usual + the rows of r_sp outside it two per transform (k_rfwd_arrays_x)
+    const int xrows = sc.skipa ? g.H + outside_pair_count(g) : g.Hp;
     auto go = [&](auto plan_tag, auto em_tag) {
       using P = decltype(plan_tag);
       constexpr int em = decltype(em_tag)::value;
-      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<256, em, true, SPlanArg<P>>, dim3(g.Hp, e->P), 256,
+      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<256, em, true, SPlanArg<P>>, dim3(xrows, e->P), 256,
                       LPC_ROW_SMEM_BYTES(P::n, true), g, sc, splan_arg<P>(e->planW), (const real*)e->Rsp,
                       (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->Y, SA, SB);
     };
     if (e->static_prow == 960 && e->prow_nt128)
-      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<128, 8, true, SPlanArg<RowPlan960>>, dim3(g.Hp, e->P), 128,
+      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<128, 8, true, SPlanArg<RowPlan960>>, dim3(xrows, e->P), 128,
                       LPC_ROW_SMEM_BYTES(960, true), g, sc, splan_arg<RowPlan960>(e->planW), (const real*)e->Rsp,
                       (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->Y, SA, SB);
     if (e->static_prow == 960) return go(RowPlan960{}, std::integral_constant<int, 4>{});
@@ -178,6 +180,9 @@ int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real
 // ---- ADMM: the two work spectra -> V and H V (padded, no shift) ------------------------------------------------
 int admm_rows_inv(Engine* e, real* Vout, real* HVout, bool skip_hv_outside) {
   const PlaneGeom& g = e->g;
+  // paired rows, skip_hv_outside: the window rows as usual + the rows of V outside it two per transform (k_rinv_arrays)
+  const int wo = (skip_hv_outside && !e->rows_half) ? 1 : 0;
+  const int irows = wo ? g.H + outside_pair_count(g) : g.Hp;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
@@ -200,21 +205,21 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout, bool skip_hv_outside) {
                       (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
     });
   if (e->static_prow == 2048)
-    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<256, 8, true, false, SPlanArg<RowPlan2048>>, dim3(g.Hp, e->P), 256,
+    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<256, 8, true, false, SPlanArg<RowPlan2048>>, dim3(irows, e->P), 256,
                     LPC_ROW_SMEM_BYTES(2048, true), g, splan_arg<RowPlan2048>(e->planW), (const real2*)SA, (const real2*)SB,
-                    Vout, HVout);
+                    Vout, HVout, wo);
   if (e->static_prow == 960 && e->prow_nt128)
-    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<128, 8, true, false, SPlanArg<RowPlan960>>, dim3(g.Hp, e->P), 128,
+    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<128, 8, true, false, SPlanArg<RowPlan960>>, dim3(irows, e->P), 128,
                     LPC_ROW_SMEM_BYTES(960, true), g, splan_arg<RowPlan960>(e->planW), (const real2*)SA, (const real2*)SB,
-                    Vout, HVout);
+                    Vout, HVout, wo);
   if (e->static_prow == 960)
-    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<256, 4, true, false, SPlanArg<RowPlan960>>, dim3(g.Hp, e->P), 256,
+    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<256, 4, true, false, SPlanArg<RowPlan960>>, dim3(irows, e->P), 256,
                     LPC_ROW_SMEM_BYTES(960, true), g, splan_arg<RowPlan960>(e->planW), (const real2*)SA, (const real2*)SB,
-                    Vout, HVout);
+                    Vout, HVout, wo);
   return dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
     constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
     constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
-    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em, sk, r2>, dim3(g.Hp, e->P), nt,
-                    LPC_ROW_SMEM_BYTES(g.Wp, sk), g, pinv, (const real2*)SA, (const real2*)SB, Vout, HVout);
+    return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<nt, em, sk, r2>, dim3(irows, e->P), nt,
+                    LPC_ROW_SMEM_BYTES(g.Wp, sk), g, pinv, (const real2*)SA, (const real2*)SB, Vout, HVout, wo);
   });
 }

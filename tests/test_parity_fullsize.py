@@ -137,12 +137,15 @@ def test_c4_batch64_vs_oracle_and_singles(c4_inputs):
     # batch ran: the engine picks the sequential 16-column middle for large batches only, LPC_MID_SEQ selects it for one
     # frame too.  The default single-frame plan (two spectra side by side, 8 columns each) is another instruction
     # stream for the same arithmetic: equal to float32 round-off.
+    # (LPC_PROW_NT128: the batch's 128-thread row kernels, which also skip the H V row transforms outside the window)
     os.environ["LPC_MID_SEQ"] = "1"
+    os.environ["LPC_PROW_NT128"] = "1"
     try:
         single = lpa.ADMM(psf_d)
     finally:
-        del os.environ["LPC_MID_SEQ"]
+        del os.environ["LPC_MID_SEQ"], os.environ["LPC_PROW_NT128"]
     assert "T = 16" in single._handle.plan_info() and "T = 16" in rec._handle.plan_info()
+    assert "row transforms skipped" in single._handle.plan_info() and "row transforms skipped" in rec._handle.plan_info()
     for b in range(64):
         single.set_data(frames_d[b])
         assert torch.equal(single.apply(n_iter=20, disp_iter=None), full[b]), b

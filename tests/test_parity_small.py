@@ -476,15 +476,25 @@ def test_xi_outside_the_sensor_window(backend, monkeypatch, shape):
     assert rel(vf, v4) <= 2e-6 and np.abs(xif - xi4).max() <= 2e-5 * scale
 
 
-def test_hv_rows_outside_the_sensor_window_are_skipped(backend, monkeypatch):
+@pytest.mark.parametrize("kind", ["half_rows_split_columns", "paired_rows_c4"])
+def test_hv_rows_outside_the_sensor_window_are_skipped(backend, monkeypatch, kind):
     """Wide frames on compile-time plans with a column split: rows wholly outside the sensor window carry a = mu1 HV,
     whose row spectrum is mu1 Wp times the spectrum row the last inverse row pass read -- inside a call neither their
     forward nor their inverse H V row transform runs (AdmmScalars::skipa / skiphv); the last three iterations run
     complete.  Read-outs (V, HV, xi, X on the WHOLE padded frame) must match the float64 oracle after calls of every
     length around those boundaries, and continuations (reset=False) must too."""
-    H, W, C = 12, 1014, 1           # 24 x 2048 padded: half rows of 1024 points (compile-time plan), columns split
-    monkeypatch.setenv("LPC_ROWS_HALF", "1")
-    monkeypatch.setenv("LPC_TILE_BUDGET", "256")
+    if kind == "paired_rows_c4":
+        # C4's shape for ONE frame: 960-point paired rows (the rows of r_sp / V outside the window ride two per
+        # transform: 135 rows above and below = 67 pairs + one single each), sequential 540-point middle rescaling SB
+        H, W, C = 270, 480, 1
+        monkeypatch.setenv("LPC_MID_SEQ", "1")
+        monkeypatch.setenv("LPC_PROW_NT128", "1")
+        runs = ([2], [5], [4, 1, 5])
+    else:
+        H, W, C = 12, 1014, 1       # 24 x 2048 padded: half rows of 1024 points (compile-time plan), columns split
+        monkeypatch.setenv("LPC_ROWS_HALF", "1")
+        monkeypatch.setenv("LPC_TILE_BUDGET", "256")
+        runs = ([2], [4], [5], [9], [6, 1, 5])
     rng = np.random.default_rng(11)
     psf = orc.synthetic_psf(1, H, W, C, seed=11)
     y = rng.random((H, W, C), dtype=np.float32)
@@ -508,16 +518,16 @@ def test_hv_rows_outside_the_sensor_window_are_skipped(backend, monkeypatch):
             rec._iterate(n)
         return rec
 
-    for steps in ([2], [4], [5], [9], [6, 1, 5]):
+    for steps in runs:
         rec, o = engine(steps), oracle(sum(steps))
         for attr, ref, tol in (("_image_est", o.V, 1e-5), ("_forward_out", o.HV, 1e-5), ("_X", o.X, 1e-5)):
             assert rel(np.asarray(getattr(rec, attr)), ref.numpy()) <= tol, (steps, attr)
         scale = float(np.abs(o.xi.numpy()).max())
         assert np.abs(np.asarray(rec._xi) - o.xi.numpy()).max() <= 5e-5 * scale, steps
     monkeypatch.setenv("LPC_HV_FULL", "1")
-    full = engine([9])
+    full = engine([6])
     monkeypatch.delenv("LPC_HV_FULL")
-    assert rel(np.asarray(engine([9])._image_est), np.asarray(full._image_est)) <= 2e-6
+    assert rel(np.asarray(engine([6])._image_est), np.asarray(full._image_est)) <= 2e-6
 
 
 def test_c4_sequential_middle_on_one_frame(backend, monkeypatch):
