@@ -254,9 +254,19 @@ __global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, PL plan, const re
   real2* s = (real2*)smem;
   // block b runs on XCD b % 8: the array flips every fourth row so that each XCD transforms rows of both (the rows of
   // B outside the sensor window may be skipped: with `arr = b & 1` only the odd XCDs would have less to do: 0.49 -> 0.47 ms, r02ak)
-  const int tid = threadIdx.x, row = blockIdx.x >> 1, arr = (blockIdx.x ^ (blockIdx.x >> 3)) & 1;
+  const int tid = threadIdx.x;
+  int row = blockIdx.x >> 1, arr = (blockIdx.x ^ (blockIdx.x >> 3)) & 1;
   const long pl = blockIdx.y;
-  if (arr == 1 && skip_b_outside && (row < g.sh || row >= g.sh + g.H)) return;   // AdmmScalars::skiphv
+  // AdmmScalars::skiphv: grid.x = 2 H + (Hp - H) -- both arrays on the rows of the sensor window, then A (= V) alone on
+  // the rows above and below it (no empty workgroups: each would still claim its LDS and a launch slot)
+  if (skip_b_outside) {
+    if ((int)blockIdx.x < 2 * g.H) row += g.sh;
+    else {
+      const int q = (int)blockIdx.x - 2 * g.H;
+      row = q < g.sh ? q : q + g.H;
+      arr = 0;
+    }
+  }
   tangle_half_load<NT, EMAX, SK>(s, g.Wp >> 1, twW, (arr ? SB : SA) + pl * g.cplane + (long)row * g.cpitch, tid);
   __syncthreads();
   real2* o2 = (real2*)((arr ? B : A) + pl * g.rplane + (long)row * g.rpitch);
@@ -481,8 +491,8 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
     real2 x = make_real2((real)0., (real)0.);
     const int row = row0 + i * cp.istride;
     if (c0 + c < g.Wc && (INV || (row >= cp.zr0 && row < cp.zr1))) x = base[i * rstep + c];
-    if (!INV && (int)blockIdx.y >= cp.sc_plane0)      // uniform per block; one compare, one select, one product per element
-      x = cscale(x, (unsigned)(row - cp.sc_r0) >= (unsigned)(cp.sc_r1 - cp.sc_r0) ? cp.sc : (real)1.);
+    // (a select + an unconditional product instead of this branch measured slower: pass A 0.47 -> 0.50 ms, r02am)
+    if (!INV && (int)blockIdx.y >= cp.sc_plane0 && (row < cp.sc_r0 || row >= cp.sc_r1)) x = cscale(x, cp.sc);
     return x;
   };
   // compile-time plans (short transforms): the plan's twiddles and this group's four-step twiddles
@@ -1313,6 +1323,8 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
   // (block b runs on XCD b % 8: the even XCDs transform the rows of r_sp, the odd ones form and transform the rows of
   // `a` -- about twice the work per row, on half of the rows once those outside the sensor window are skipped.
   // Flipping the pair every fourth row to mix both kinds on every XCD measured SLOWER: 0.47 -> 0.60 ms, r02ak)
+  // (a compact grid without the empty blocks of skipped `a` rows, two light blocks per heavy one on every XCD, measured
+  // the same: 0.498 / 0.480 vs 0.499 / 0.481 ms, r02an)
   const int gr = (int)(tile >> 1), arr = (int)(tile & 1);
   const long pl = blockIdx.y;
   const long poff = pl * g.rplane;

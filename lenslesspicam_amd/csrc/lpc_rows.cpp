@@ -183,6 +183,7 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout, bool skip_hv_outside) {
   // paired rows, skip_hv_outside: the window rows as usual + the rows of V outside it two per transform (k_rinv_arrays)
   const int wo = (skip_hv_outside && !e->rows_half) ? 1 : 0;
   const int irows = wo ? g.H + outside_pair_count(g) : g.Hp;
+  const int hrows = skip_hv_outside ? g.Hp + g.H : 2 * g.Hp;      // half-length rows: k_rinv_half
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
@@ -191,7 +192,7 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout, bool skip_hv_outside) {
       using SH = decltype(SHc);
       return with_sk(e->static_sk, [&](auto SKc) {
       constexpr bool sk = decltype(SKc)::value;
-        return launch_k(e, LPC_K_ROW_INV, k_rinv_half<SH::nt, SH::em, sk, SPlanArg<typename SH::plan>>, dim3(2 * g.Hp, e->P), SH::nt,
+        return launch_k(e, LPC_K_ROW_INV, k_rinv_half<SH::nt, SH::em, sk, SPlanArg<typename SH::plan>>, dim3(hrows, e->P), SH::nt,
                         LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, splan_arg<typename SH::plan>(e->planWh), e->planW.tw,
                       (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
       });
@@ -200,7 +201,7 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout, bool skip_hv_outside) {
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
       constexpr bool sk = decltype(SK)::value;
-      return launch_k(e, LPC_K_ROW_INV, k_rinv_half<nt, em, sk>, dim3(2 * g.Hp, e->P), nt,
+      return launch_k(e, LPC_K_ROW_INV, k_rinv_half<nt, em, sk>, dim3(hrows, e->P), nt,
                       LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real2*)SA,
                       (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
     });
