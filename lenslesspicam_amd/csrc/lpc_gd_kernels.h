@@ -69,11 +69,16 @@ struct GdScalars {
 // One element of the three _update()s as a function of values (x = iterate, pp = the auxiliary state, gr = gradient):
 // returns the value to store in X (the point the next iteration's forward model is evaluated at) and sets aux_out to
 // the value AUX takes where the variant writes it (gd_aux_access says whether it reads / writes AUX at all).
+// KIND >= 0: the variant is known at compile time (the half-row kernels branch on p.kind ONCE and run a straight-line
+// body: with the uniform branches inside every element the loads of x and of the auxiliary state could not be issued
+// ahead of one another -- 5 700 static SALU instructions in the update kernel); KIND < 0: read p.kind.
+template <int KIND = -1>
 static __device__ __forceinline__ real gd_update_val(real x, real pp, real gr, real al, const GdScalars& p,
                                                       real& aux_out) {
+  const int kind = KIND >= 0 ? KIND : p.kind;
   aux_out = pp;
   if (p.split) {   // everything up to `self._form_image()` of the three _update()s; k_gd_post finishes
-    if (p.kind == 1) {
+    if (kind == 1) {
       const real pn = p.mu * pp - al * gr;
       aux_out = pn;
       return x + (p.negmu * pp + p.onepmu * pn);
@@ -82,8 +87,8 @@ static __device__ __forceinline__ real gd_update_val(real x, real pp, real gr, r
     aux_out = xs;              // stored only when kind == 2 && first: x_k aliases the iterate before the first projection
     return xs;
   }
-  if (p.kind == 0) return rmax(x - al * gr, (real)0.);   // gd.py:132-134
-  if (p.kind == 1) {                                      // gd.py:183-188
+  if (kind == 0) return rmax(x - al * gr, (real)0.);   // gd.py:132-134
+  if (kind == 1) {                                      // gd.py:183-188
     const real pn = p.mu * pp - al * gr;
     const real xn = x + (p.negmu * pp + p.onepmu * pn);
     aux_out = pn;
@@ -95,31 +100,35 @@ static __device__ __forceinline__ real gd_update_val(real x, real pp, real gr, r
   aux_out = xk;
   return xk + p.coef * (xk - xp);
 }
+template <int KIND = -1>
 static __device__ __forceinline__ void gd_aux_access(const GdScalars& p, bool& rd, bool& wr) {
-  rd = p.kind == 1 || (p.kind == 2 && !p.split && !p.first);
-  wr = p.kind == 1 || (p.kind == 2 && (!p.split || p.first));
+  const int kind = KIND >= 0 ? KIND : p.kind;
+  rd = kind == 1 || (kind == 2 && !p.split && !p.first);
+  wr = kind == 1 || (kind == 2 && (!p.split || p.first));
 }
+template <int KIND = -1>
 static __device__ __forceinline__ real gd_update_one(real* LPC_RESTRICT X, real* LPC_RESTRICT AUX, long o,
                                                       real gr, real al, const GdScalars& p) {
   bool rd, wr;
-  gd_aux_access(p, rd, wr);
+  gd_aux_access<KIND>(p, rd, wr);
   real an;
-  const real xs = gd_update_val(X[o], rd ? AUX[o] : (real)0., gr, al, p, an);
+  const real xs = gd_update_val<KIND>(X[o], rd ? AUX[o] : (real)0., gr, al, p, an);
   if (wr) AUX[o] = an;
   X[o] = xs;
   return xs;
 }
 // two neighbouring columns at once (o even: 8-byte accesses; the half-row kernels use it when the window offset,
 // the frame width and Wp / 2 are all even, so that gradient samples 2i and 2i + 1 are one aligned pair of x)
+template <int KIND = -1>
 static __device__ __forceinline__ real2 gd_update_pair(real* LPC_RESTRICT X, real* LPC_RESTRICT AUX, long o,
                                                         real2 gr, real al, const GdScalars& p) {
   bool rd, wr;
-  gd_aux_access(p, rd, wr);
+  gd_aux_access<KIND>(p, rd, wr);
   const real2 x = *(const real2*)(X + o);
   const real2 pp = rd ? *(const real2*)(AUX + o) : make_real2((real)0., (real)0.);
   real2 an, xs;
-  xs.x = gd_update_val(x.x, pp.x, gr.x, al, p, an.x);
-  xs.y = gd_update_val(x.y, pp.y, gr.y, al, p, an.y);
+  xs.x = gd_update_val<KIND>(x.x, pp.x, gr.x, al, p, an.x);
+  xs.y = gd_update_val<KIND>(x.y, pp.y, gr.y, al, p, an.y);
   if (wr) *(real2*)(AUX + o) = an;
   *(real2*)(X + o) = xs;
   return xs;
@@ -214,17 +223,23 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update_half(PlaneGeom g, PL plan
   const real al = alpha[pl % g.C];
   const long base = pl * g.uplane + (long)u * g.W;
   const bool pair = ((g.sw | g.W | hw) & 1) == 0;
-  auto upd = [&](int i, int, real2 z) {     // gradient samples 2i, 2i+1 -> shift + crop -> fused update
-    const int c0 = shifted_col(2 * i, hw, g.sw, g.Wp);
-    if (pair) {
-      if (c0 < g.W) gd_update_pair(X, AUX, base + c0, z, al, p);
-      return;
-    }
-    if (c0 < g.W) gd_update_one(X, AUX, base + c0, z.x, al, p);
-    const int c1 = shifted_col(2 * i + 1, hw, g.sw, g.Wp);
-    if (c1 < g.W) gd_update_one(X, AUX, base + c1, z.y, al, p);
+  auto run = [&](auto kind_tag) {           // one branch on the variant, then a straight-line body (gd_update_val)
+    constexpr int KIND = decltype(kind_tag)::value;
+    auto upd = [&](int i, int, real2 z) {   // gradient samples 2i, 2i+1 -> shift + crop -> fused update
+      const int c0 = shifted_col(2 * i, hw, g.sw, g.Wp);
+      if (pair) {
+        if (c0 < g.W) gd_update_pair<KIND>(X, AUX, base + c0, z, al, p);
+        return;
+      }
+      if (c0 < g.W) gd_update_one<KIND>(X, AUX, base + c0, z.x, al, p);
+      const int c1 = shifted_col(2 * i + 1, hw, g.sw, g.Wp);
+      if (c1 < g.W) gd_update_one<KIND>(X, AUX, base + c1, z.y, al, p);
+    };
+    fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, upd);
   };
-  fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, upd);
+  if (p.kind == 2) run(std::integral_constant<int, 2>{});
+  else if (p.kind == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
 }
 
 // ---- the same update with the NEXT iteration's forward rows fused behind it -------------------------------------
@@ -251,24 +266,30 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update_fwd_half(PlaneGeom g, PL 
   // (m in window) ? updated x[m - sw] : 0, where x[c] takes gradient sample (m + Wp/2) mod Wp
   const real al = alpha[pl % g.C];
   const long base = pl * g.uplane + (long)u * g.W;
-  auto sample = [&](int m) {
-    const int c = m - g.sw;
-    if (c < 0 || c >= g.W) return (real)0.;
-    const int q = wrap_add(m, hw, g.Wp);
-    const real2 z = s[lds_slot<SK>(q >> 1)];
-    return gd_update_one(X, AUX, base + c, (q & 1) ? z.y : z.x, al, p);
-  };
   const bool pair = ((g.sw | g.W | hw) & 1) == 0;
-  auto newrow = [&](int i, int) {
-    if (pair) {
-      const int c = 2 * i - g.sw;
-      if (c < 0 || c >= g.W) return make_real2((real)0., (real)0.);
-      const real2 z = s[lds_slot<SK>(wrap_add(2 * i, hw, g.Wp) >> 1)];
-      return gd_update_pair(X, AUX, base + c, z, al, p);
-    }
-    return make_real2(sample(2 * i), sample(2 * i + 1));
+  auto run = [&](auto kind_tag) {           // one branch on the variant, then a straight-line body (gd_update_val)
+    constexpr int KIND = decltype(kind_tag)::value;
+    auto sample = [&](int m) {
+      const int c = m - g.sw;
+      if (c < 0 || c >= g.W) return (real)0.;
+      const int q = wrap_add(m, hw, g.Wp);
+      const real2 z = s[lds_slot<SK>(q >> 1)];
+      return gd_update_one<KIND>(X, AUX, base + c, (q & 1) ? z.y : z.x, al, p);
+    };
+    auto newrow = [&](int i, int) {
+      if (pair) {
+        const int c = 2 * i - g.sw;
+        if (c < 0 || c >= g.W) return make_real2((real)0., (real)0.);
+        const real2 z = s[lds_slot<SK>(wrap_add(2 * i, hw, g.Wp) >> 1)];
+        return gd_update_pair<KIND>(X, AUX, base + c, z, al, p);
+      }
+      return make_real2(sample(2 * i), sample(2 * i + 1));
+    };
+    fft_tile<NT, EMAX, false, SK, true, true>(s, plan, 1, make_fastdiv_dev1(), tid, newrow, LdsNatural{});
   };
-  fft_tile<NT, EMAX, false, SK, true, true>(s, plan, 1, make_fastdiv_dev1(), tid, newrow, LdsNatural{});
+  if (p.kind == 2) run(std::integral_constant<int, 2>{});
+  else if (p.kind == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
   untangle_half_store<NT, SK>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
 }
 
