@@ -530,6 +530,33 @@ def test_hv_rows_outside_the_sensor_window_are_skipped(backend, monkeypatch, kin
     assert rel(np.asarray(engine([6])._image_est), np.asarray(full._image_est)) <= 2e-6
 
 
+def test_window_structure_with_a_per_iteration_schedule(backend, monkeypatch):
+    """Unrolled ADMM changes mu1 from one iteration to the next: outside the sensor window a = mu1_k HV uses THIS
+    iteration's step size and the stored xi = mu1_{k-1} (HV - HV_old) the previous one's.  The window-aware launch plan
+    must agree with the plan that keeps xi and H V whole (LPC_XI_FULL, LPC_HV_FULL), for a batch of two frames."""
+    H, W, C, n_iter = 12, 1014, 1, 7
+    monkeypatch.setenv("LPC_ROWS_HALF", "1")
+    monkeypatch.setenv("LPC_TILE_BUDGET", "256")
+    rng = np.random.default_rng(17)
+    psf = torch.from_numpy(orc.synthetic_psf(1, H, W, C, seed=17))
+    batch = torch.from_numpy(rng.random((2, 1, H, W, C), dtype=np.float32))
+    sched = dict(mu1=1e-6 * (1 + 0.3 * np.arange(n_iter)), mu2=1e-4 * (1 + 0.1 * np.arange(n_iter)),
+                 mu3=4e-5 * (1 + 0.2 * np.arange(n_iter)), tau=2e-6 * np.ones(n_iter))
+
+    def run():
+        net = lpa.UnrolledADMM(psf, n_iter=n_iter)
+        net.set_parameters(**sched)
+        return net.forward(batch), net._handle.plan_info()
+
+    out, info = run()
+    assert "H V row transforms skipped" in info, info
+    monkeypatch.setenv("LPC_XI_FULL", "1")
+    monkeypatch.setenv("LPC_HV_FULL", "1")
+    ref, info_full = run()
+    assert "xi inside the sensor window" not in info_full
+    assert float(ref.abs().max()) > 0 and rel(out, ref) <= 2e-6
+
+
 def test_c4_sequential_middle_on_one_frame(backend, monkeypatch):
     """C4's fused ADMM middle takes the two spectra one after the other through a 16-column tile
     (k_cols_mid_admm_seq); the engine selects it for large batches only, LPC_MID_SEQ forces it onto one
