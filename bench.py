@@ -123,7 +123,7 @@ def run_c4(args, rank, world, dev, dist):
         elapsed = float(t.item())
     assert out.shape == (B, 1, H, W, C)
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "ADMM frame-iterations/sec, batch of 64 frames 270x480x3, 20 iters (BASELINE config 4)",
             "value": round(B * n_iter * args.steps / elapsed, 1), "unit": "frame-iterations/s", "n_gpus": world,
             "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -131,7 +131,7 @@ def run_c4(args, rank, world, dev, dist):
             "config": {"workload": "C4: 64 frames 270x480x3, ADMM-TV 20 iterations, frames block-sharded over the "
                                    "ranks, one all-gather per step (solver built once, outside the timed region)",
                        "frames_per_gpu": -(-B // world)},
-        }), flush=True)
+        })
     if dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -218,7 +218,23 @@ def other_configs(dev):
     return out
 
 
+_JSON_OUT = None
+
+
+def emit(obj):
+    """The ONE JSON line of the contract, on the process's real stdout."""
+    out = _JSON_OUT if _JSON_OUT is not None else sys.stdout
+    print(json.dumps(obj), file=out, flush=True)
+
+
 def main():
+    global _JSON_OUT
+    # stdout must carry exactly one line.  RCCL prints a start-up banner ("RCCL version : ...", 5 lines) from C on file
+    # descriptor 1 when the process group initialises: keep the real stdout aside for the JSON line and point
+    # descriptor 1 at stderr for everything else.
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -483,7 +499,7 @@ def main():
         log("other configs done")
 
     if rank == 0:
-        print(json.dumps(result), flush=True)
+        emit(result)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
