@@ -6,7 +6,7 @@
 //                   evaluation / preparation kernels
 //   lpc_rows.cpp    every row-pass launch (real <-> half-spectrum transforms, incl. the fused ADMM rows)
 //   lpc_cols.cpp    every column-pass launch (pass A, the fused middles)
-//   lpc_gd.cpp      the gradient-descent family's fused row kernels
+//   lpc_gd.cpp, lpc_gd_update.cpp, lpc_gd_update_fwd.cpp   the gradient-descent family's fused row kernels
 #pragma once
 #include "lpc_kernels.h"
 #include "lpc.h"
@@ -284,7 +284,7 @@ int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1,
 int cols_passB_fwd(Engine* e, real2* S, int nplanes, int zr0, int zr1);
 int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, int zr1, bool crop_rows_only = false);
 int admm_cols(Engine* e, const AdmmScalars& sc);   // sc.skipa: forward pass A rescales the kept rows of SB                // [pass A] -> fused ADMM middle -> [inverse pass A]
-// lpc_gd.cpp
+// lpc_gd.cpp, lpc_gd_update.cpp, lpc_gd_update_fwd.cpp (one kernel family each)
 struct GdScalars;
 int gd_rows_mid(Engine* e);                                     // irfft rows -> residual -> rfft rows (S -> S2)
 int gd_rows_update(Engine* e, const GdScalars& sc, const real* alpha);   // irfft rows -> fused projected update
