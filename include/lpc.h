@@ -66,12 +66,40 @@ typedef struct lpc_config {
   double lip_fact;         /* GD family step factor              gd.py:67,107-112             */
   double nesterov_mu, nesterov_p; /* gd.py:153,178-181                                         */
   double fista_tk;         /* gd.py:200,227-233                                               */
+  const char* options;     /* NULL, or "key=value,key=value": launch-plan choices (below).  Read  */
+                           /* by lpc_create only; the string is not kept.                         */
 } lpc_config;
+
+/* Launch-plan options (lpc_config.options; the environment variable LPC_OPTIONS, same syntax, supplies process-wide
+ * defaults that a handle's own string overrides).  None changes a result beyond float round-off; none is needed in
+ * production -- they exist so that tests and A/B measurements can select a launch plan without touching the process
+ * environment.  lpc_plan_info() reports the plan a handle ended up with.
+ *   no_static=1        run-time FFT plans only (no plan module);  no_static_cols=1: ... for the column passes only
+ *   jit=0              never compile a plan module: use what is on disk (default 1: a frame shape whose module is
+ *                      missing is compiled with hipcc on first use, ~3 s, and kept in <libdir>/modules or ~/.cache)
+ *   jit_min_points=N   padded frames with fewer than N points keep the run-time plans (default 65536)
+ *   module_dir=PATH    first place modules are looked for / written;  compiler=PATH  the hipcc to use
+ *   rows_half=0|1      paired rows / one real row per half-length transform (default: by width)
+ *   col_t=N tile_budget=N split_n2=N passa_t=N     column tiling: image columns per tile, LDS points per tile, forced
+ *                      length of the fused middle transform, columns per pass-A tile
+ *   mid_seq=0|1 mid_lds=1 prow_nt128=0|1            ADMM single-pass middle one spectrum at a time / side by side; no
+ *                      register-resident middles; short paired rows on 128 threads (defaults: by batch size)
+ *   xi_full=1 hv_full=1 no_xhalf=1 k1_scalar=1      ADMM without the sensor-window structure of xi / of the H V row
+ *                      transforms; with the stand-alone image-domain kernel; ... in its scalar-lane form
+ *   no_r2=1 no_skew=1 gd_no_fuse_fwd=1              run-time row plans without the folded radix-2 stage / the LDS skew;
+ *                      gradient-descent update without the next iteration's forward rows
+ * An unknown key makes lpc_create fail. */
 
 /* ---- life cycle ------------------------------------------------------------------ */
 /* replaces the constructors (recon.py:203-329, admm.py:35-135, gd.py:67-92) minus the PSF */
 int lpc_create(const lpc_config* cfg, lpc_handle* out);
 int lpc_destroy(lpc_handle h);
+/* Plan modules.  The compile-time-plan kernels of one frame shape live in a small shared object next to the library
+ * (lenslesspicam_amd/csrc/lpc_plan.h); lpc_create loads it, compiling it first when missing.  lpc_plan_module reports
+ * the key of the module lpc_create(cfg) would use ("" = none: run-time plans) and, with build != 0, compiles it now if
+ * it is not on disk -- no device needed, so a build step can pre-build the shapes it knows (build.py does, for
+ * BASELINE.json's).  key_buf may be NULL. */
+int lpc_plan_module(const lpc_config* cfg, int build, char* key_buf, size_t n);
 const char* lpc_last_error(void);
 const char* lpc_backend(void);        /* "hip-gfx950" for the product library */
 const char* lpc_real_name(void);      /* "float32" or "float64": the arithmetic type of this build */

@@ -23,6 +23,25 @@ K_SPATIAL, K_ROW_FWD, K_COL_A_FWD, K_COL_MID, K_COL_A_INV, K_ROW_INV, K_COUNT = 
 KERNEL_NAMES = ["spatial", "row_fwd", "col_a_fwd", "col_mid", "col_a_inv", "row_inv"]
 
 
+# Launch-plan options every new handle starts from (include/lpc.h, lpc_config.options); an explicit ``options=`` /
+# ``engine_options=`` argument overrides entry by entry.  Empty in production; the test-suite patches it to select a
+# launch plan for solvers that shared helpers construct.
+DEFAULT_OPTIONS: dict = {}
+
+
+def _options_dict(opts) -> dict:
+    if not opts:
+        return {}
+    if isinstance(opts, dict):
+        return dict(opts)
+    out = {}
+    for tok in str(opts).replace(";", ",").replace(" ", ",").split(","):
+        if tok:
+            k, _, v = tok.partition("=")
+            out[k] = v if v != "" else 1
+    return out
+
+
 class Config(C.Structure):
     _fields_ = [
         ("algo", C.c_int),
@@ -41,6 +60,7 @@ class Config(C.Structure):
         ("nesterov_mu", C.c_double),
         ("nesterov_p", C.c_double),
         ("fista_tk", C.c_double),
+        ("options", C.c_char_p),
     ]
 
 
@@ -72,6 +92,7 @@ class Lib:
         sig = {
             "lpc_create": [C.POINTER(Config), C.POINTER(vp)],
             "lpc_destroy": [vp],
+            "lpc_plan_module": [C.POINTER(Config), C.c_int, C.c_char_p, C.c_size_t],
             "lpc_padded_shape": [vp, ip, ip, ip, ip],
             "lpc_set_psf": [vp, fp, vp],
             "lpc_convolve": [vp, fp, fp, C.c_int, C.c_int, C.c_int, vp],
@@ -134,14 +155,30 @@ class Lib:
     def resize_aa(self, in_ptr, n, H, W, Cn, Hout, Wout, out_ptr, stream=0):
         self.check(self.dll.lpc_resize_aa(in_ptr, int(n), int(H), int(W), int(Cn), int(Hout), int(Wout), out_ptr, stream))
 
-    def create(self, **kw) -> "Handle":
+    @staticmethod
+    def _config(kw) -> Config:
         cfg = Config()
         defaults = dict(algo=ALGO_ADMM, height=0, width=0, channels=3, depth=1, batch=1, norm=0, pad=1,
                         mu1=1e-6, mu2=1e-5, mu3=4e-5, tau=1e-4, lip_fact=1.8, nesterov_mu=0.9,
-                        nesterov_p=0.0, fista_tk=1.0)
+                        nesterov_p=0.0, fista_tk=1.0, options=None)
         defaults.update(kw)
+        opts = {**DEFAULT_OPTIONS, **_options_dict(defaults["options"])}    # {"hv_full": 1} -> "hv_full=1"
+        opts = ",".join(f"{k}={int(v) if isinstance(v, bool) else v}" for k, v in opts.items())
+        defaults["options"] = opts.encode() if opts else None
         for k, v in defaults.items():
             setattr(cfg, k, v)
+        return cfg
+
+    def plan_module(self, build=False, **kw) -> str:
+        """Key of the plan module ``create(**kw)`` would use ('' = run-time plans); ``build``: compile it if missing.
+        Needs no device (lpc_plan_module)."""
+        cfg = self._config(kw)
+        buf = C.create_string_buffer(512)
+        self.check(self.dll.lpc_plan_module(C.byref(cfg), int(bool(build)), buf, 512))
+        return buf.value.decode()
+
+    def create(self, **kw) -> "Handle":
+        cfg = self._config(kw)
         h = C.c_void_p()
         self.check(self.dll.lpc_create(C.byref(cfg), C.byref(h)))
         return Handle(self, h, cfg)

@@ -1,13 +1,20 @@
-"""Builds the product library in-tree: hipcc, gfx950 only.  (No JIT cache: the .so must travel
+"""Builds the product library in-tree: hipcc, gfx950 only.  (No JIT cache outside the tree: the .so files must travel
 with the source snapshot to the GPU box.)
 
 The engine is split into translation units (csrc/lpc_engine.h) so that the device compiler works on them in
-parallel: every ``csrc/*.cpp`` is compiled to an object file per flavour (float32, and float64 with
-``-DLPC_DOUBLE``), all jobs side by side, then linked into ``_lib/liblpc.so`` / ``_lib/liblpc_f64.so``.
-No relocatable device code is needed: a kernel is always launched from the unit that instantiates it."""
+parallel: every ``csrc/*.cpp`` except ``lpc_module.cpp`` is compiled to an object file per flavour (float32, and
+float64 with ``-DLPC_DOUBLE``), all jobs side by side, then linked into ``_lib/liblpc.so`` / ``_lib/liblpc_f64.so``.
+No relocatable device code is needed: a kernel is always launched from the unit that instantiates it.
+
+``lpc_module.cpp`` is the source of the PLAN MODULES (csrc/lpc_plan.h): the compile-time-plan kernels of one frame
+shape, one small shared object per shape under ``_lib/modules/``.  The library compiles a missing module itself on
+first use (csrc/lpc_jit.cpp); ``build_modules()`` asks it to do that now -- no GPU needed -- for the shapes of
+BASELINE.json's configurations, so that a fresh GPU box starts with them on disk."""
+import hashlib
 import os
 import shutil
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
@@ -15,14 +22,25 @@ CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "_lib", "liblpc.so")            # float32
 OUT_F64 = os.path.join(HERE, "_lib", "liblpc_f64.so")    # same translation units with -DLPC_DOUBLE
 OBJ = os.path.join(HERE, "_lib", "obj")
+MODULES = os.path.join(HERE, "_lib", "modules")
 
 
 def units():
-    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".cpp")]
+    return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".cpp") and f != "lpc_module.cpp"]
 
 
 def sources():
     return [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC))] + [os.path.join(ROOT, "include", "lpc.h")]
+
+
+def fingerprint():
+    """names the sources a library was built from: a plan module is only ever loaded by the library it was built for"""
+    h = hashlib.sha1()
+    for f in sources():
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(os.environ.get("LPC_EXTRA_DEFS", "").encode())
+    return h.hexdigest()[:12]
 
 
 def is_stale():
@@ -35,10 +53,14 @@ def build_hip(force=False, verbose=True):
         return OUT
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     os.makedirs(OBJ, exist_ok=True)
+    fp = fingerprint()
     base = [hipcc, "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-x", "hip",
-            "-I", os.path.join(ROOT, "include"), "-I", CSRC]
+            "-I", os.path.join(ROOT, "include"), "-I", CSRC, f'-DLPC_SRC_FP="{fp}"']
     extra_defs = os.environ.get("LPC_EXTRA_DEFS", "").split()    # e.g. -DLPC_DEBUG_KNOBS for timing experiments
     flavours = (("f32", OUT, extra_defs), ("f64", OUT_F64, ["-DLPC_DOUBLE"] + extra_defs))
+    for stale in os.listdir(OBJ):                                 # objects of units that no longer exist
+        if stale.rsplit(".", 2)[0] + ".cpp" not in {os.path.basename(u) for u in units()}:
+            os.remove(os.path.join(OBJ, stale))
     jobs = []
     for tag, _, extra in flavours:
         for src in units():
@@ -52,12 +74,46 @@ def build_hip(force=False, verbose=True):
             raise subprocess.CalledProcessError(pr.returncode, cmd)
     for tag, out, _ in flavours:
         objs = [os.path.join(OBJ, f"{os.path.basename(src)[:-4]}.{tag}.o") for src in units()]
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC"] + objs + ["-o", out]
+        # the soname lets a plan module's DT_NEEDED entry resolve to the copy of the library already in the process
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", f"-Wl,-soname,{os.path.basename(out)}"] + objs + \
+              ["-o", out, "-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    if os.path.isdir(MODULES):                               # modules of other sources are dead weight in the snapshot
+        for f in os.listdir(MODULES):
+            if f.startswith("lpcmod_") and f"_{fp}_" not in f:
+                os.remove(os.path.join(MODULES, f))
     return OUT
+
+
+# frame shapes whose plan modules are pre-built: BASELINE.json's configurations C1-C5 and the
+# profile/*.py frame.  (algo: 1 ADMM, 4 FISTA -- the gradient-descent family and the bare operator share one module)
+PREBUILT = [
+    dict(algo=1, height=3040, width=4056, channels=3), dict(algo=4, height=3040, width=4056, channels=3),   # C2, C3
+    dict(algo=1, height=270, width=480, channels=3), dict(algo=4, height=270, width=480, channels=3),       # C1
+    dict(algo=1, height=270, width=480, channels=3, batch=64),                                               # C4
+    dict(algo=1, height=270, width=480, channels=3, batch=8),                                                # C4 / 8 GPUs
+    dict(algo=1, height=1080, width=1920, channels=3, depth=16), dict(algo=4, height=1080, width=1920, channels=3),  # C5
+    dict(algo=1, height=760, width=1014, channels=1), dict(algo=4, height=760, width=1014, channels=1),     # profile/*.py
+]
+PREBUILT_F64 = [dict(algo=1, height=3040, width=4056, channels=3), dict(algo=4, height=3040, width=4056, channels=3)]
+
+
+def build_modules(verbose=True):
+    """Compiles the plan modules of PREBUILT that are not on disk yet (in parallel; ~3 s of hipcc each)."""
+    from . import _native
+
+    os.makedirs(MODULES, exist_ok=True)
+    jobs = [(_native.Lib(OUT), kw) for kw in PREBUILT] + [(_native.Lib(OUT_F64), kw) for kw in PREBUILT_F64]
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:      # ctypes releases the GIL
+        keys = list(pool.map(lambda j: j[0].plan_module(build=True, **j[1]), jobs))
+    if verbose:
+        for (lib, kw), key in zip(jobs, keys):
+            print(f"plan module {lib.real} {kw}: {key or '(run-time plans)'}", flush=True)
+    return keys
 
 
 if __name__ == "__main__":
     build_hip(force=True)
+    build_modules()

@@ -16,33 +16,8 @@ int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1,
     cp.need0 = (g.sh + g.Hp / 2) % g.Hp;
     cp.needn = g.H;
   }
+  if (e->mod && e->mod->cols_passA) return e->mod->cols_passA(e, &cp, S, nplanes, inverse ? 1 : 0, kid);
   const dim3 grid(cp.G * cp.ntile_c, nplanes);
-  // compile-time plans: 32 columns per tile (512 threads: 128 x 32 = 512 x 8 points, 90 x 32 <= 512 x 6, 64 x 32 = 512 x 4),
-  // or 16 (256 threads) when the engine kept the narrow tile (narrow frames, tuning knobs)
-  auto static_passA = [&](auto plan_tag) {
-    using P = decltype(plan_tag);
-    const SPlanArg<P> pa = splan_arg<P>(e->planA);
-    static const bool twl = getenv("LPC_NO_TW_LDS") == nullptr;   // plan + four-step twiddles staged in LDS
-    if (cp.T == 32) {
-      const size_t smem = (size_t)P::n * (32 + (twl ? 2 : 0)) * sizeof(real2);
-      if (twl) {
-        if (inverse) return launch_k(e, kid, k_cols<512, 8, true, SPlanArg<P>, 32, true>, grid, 512, smem, g, pa, cp, S);
-        return launch_k(e, kid, k_cols<512, 8, false, SPlanArg<P>, 32, true>, grid, 512, smem, g, pa, cp, S);
-      }
-      if (inverse) return launch_k(e, kid, k_cols<512, 8, true, SPlanArg<P>, 32>, grid, 512, smem, g, pa, cp, S);
-      return launch_k(e, kid, k_cols<512, 8, false, SPlanArg<P>, 32>, grid, 512, smem, g, pa, cp, S);
-    }
-    const size_t smem = (size_t)P::n * (16 + (twl ? 2 : 0)) * sizeof(real2);
-    if (twl) {
-      if (inverse) return launch_k(e, kid, k_cols<256, 8, true, SPlanArg<P>, 16, true>, grid, 256, smem, g, pa, cp, S);
-      return launch_k(e, kid, k_cols<256, 8, false, SPlanArg<P>, 16, true>, grid, 256, smem, g, pa, cp, S);
-    }
-    if (inverse) return launch_k(e, kid, k_cols<256, 8, true, SPlanArg<P>, 16>, grid, 256, smem, g, pa, cp, S);
-    return launch_k(e, kid, k_cols<256, 8, false, SPlanArg<P>, 16>, grid, 256, smem, g, pa, cp, S);
-  };
-  if (e->static_passA == 128) return static_passA(ColPlan128{});
-  if (e->static_passA == 90) return static_passA(ColPlan90{});
-  if (e->static_passA == 64) return static_passA(ColPlan64{});
   return dispatch_cfg(cp.N * cp.T, [&](auto NT, auto EM) {
     constexpr int nt = decltype(NT)::value, em = decltype(EM)::value;
     const size_t smem = (size_t)cp.N * cp.T * sizeof(real2);
@@ -124,44 +99,8 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
     // (profiles/r01b_notes.md): 24 points 0.89 ms and 32 points 0.83 ms beat the LDS middle (0.99 / 0.92 ms) but
     // need a 256- / 192-point pass A that costs more than it saves; 48 points is 1.62 ms (AGPR traffic).
     if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_admm_reg<8, 3>)); }
-    else if (e->static_mid == 541) {   // C1 / C4, one spectrum at a time: 540 points x 16 columns = 512 threads x 17
-      // three stages 6.10.9 inside a 128-register budget: TWO workgroups per CU (2 x 69 KiB of LDS) overlap one
-      // another's loads and barriers -- 0.650 ms per launch at 64 frames against 0.84 ms for the two-stage 30.18
-      // plan (184 registers, one workgroup per CU) and 0.95 ms for 6.6.5.3 (profiles/r02_notes.md section 4)
-      constexpr int minw = sizeof(real) == 4 ? 4 : 1;
-      const real sbsc = sc.skipa ? sc.mu1 * (real)g.Wp : (real)0.;   // AdmmScalars::skipa: rows of SB kept from the last inverse rows
-      static const bool twlds = getenv("LPC_NO_TW_LDS") == nullptr;
-      if (twlds)
-      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<512, 18, SPlanArg<ColPlan540Seq>, 16, minw, true>,
-                      dim3(cp.ntile_c, e->P), 512, (size_t)540 * 17 * sizeof(real2), g,
-                      splan_arg<ColPlan540Seq>(e->planB), cp, SA, SB, (const real2*)e->Hs, (const real*)e->Gabs,
-                      (const real2*)e->phr, (const real2*)e->phc, sc.mu1, sc.mu2, sc.mu3,
-                      (real)1.0 / ((real)g.Hp * (real)g.Wp), sbsc));
-      else
-      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<512, 18, SPlanArg<ColPlan540Seq>, 16, minw>,
-                      dim3(cp.ntile_c, e->P), 512, (size_t)540 * 16 * sizeof(real2), g,
-                      splan_arg<ColPlan540Seq>(e->planB), cp, SA, SB, (const real2*)e->Hs, (const real*)e->Gabs,
-                      (const real2*)e->phr, (const real2*)e->phc, sc.mu1, sc.mu2, sc.mu3,
-                      (real)1.0 / ((real)g.Hp * (real)g.Wp), sbsc));
-    }
-    else if (e->static_mid == 540) {   // C1 / C4: 540 points x 2 x 8 tile columns = 8640 points = 512 threads x 17
-      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<512, 18, SPlanArg<ColPlan540>, 16, true>, grid, 512,
-                      (size_t)540 * 17 * sizeof(real2), g, splan_arg<ColPlan540>(e->planB), cp, SA, SB,
-                      (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2,
-                      sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
-    }
-    else if (e->static_mid == 48) {   // 48-point middle, 2 x 16 tile columns: 1536 points = 256 threads x 6
-      static const bool twl = getenv("LPC_NO_TW_LDS") == nullptr;
-      if (twl)
-      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<256, 8, SPlanArg<ColPlan48>, 32, true>, grid, 256,
-                      (size_t)48 * 33 * sizeof(real2), g, splan_arg<ColPlan48>(e->planB), cp, SA, SB,
-                      (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2,
-                      sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
-      else
-      LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<256, 8, SPlanArg<ColPlan48>, 32>, grid, 256,
-                      (size_t)48 * 32 * sizeof(real2), g, splan_arg<ColPlan48>(e->planB), cp, SA, SB,
-                      (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2,
-                      sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
+    else if (e->mod && e->mod->admm_mid) {   // compile-time plan in LDS: both spectra side by side, or one at a time
+      LPC_OK(e->mod->admm_mid(e, &cp, &sc, (sc.skipa && !split) ? sc.mu1 * (real)g.Wp : (real)0.));
     }
     else if (cp.N * cp.T * 2 > 8192 && cp.N * cp.T * 2 <= 9216) {
       // just above 8192 points (C1 / C4: 540 rows x 8 columns x 2 arrays = 8640): 512 threads x 18 points keeps
@@ -169,14 +108,14 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
       // at every barrier (C4: middle 1.435 -> 1.331 ms, 17.5k -> 18.0k frame-it/s)
       LPC_OK(launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<512, 18>, grid, 512, (size_t)cp.N * cp.T * 2 * sizeof(real2),
                       g, e->planB, cp, SA, SB, (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr,
-                      (const real2*)e->phc, t2, sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp)));
+                      (const real2*)e->phc, t2, sc.mu1, sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp), (real)0.));
     } else
     LPC_OK(dispatch_cfg(cp.N * cp.T * 2, [&](auto NTc, auto EM) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
       return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<nt, em>, grid, nt,
                       (size_t)cp.N * cp.T * 2 * sizeof(real2), g, e->planB, cp, SA, SB, (const real2*)e->Hs,
                       (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2, sc.mu1, sc.mu2,
-                      sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp));
+                      sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp), (real)0.);
     }));
   }
   if (split) LPC_OK(cols_passA(e, e->S, 2 * e->P, true, 0, g.Hp, LPC_K_COL_A_INV));

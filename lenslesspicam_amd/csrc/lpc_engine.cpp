@@ -64,7 +64,7 @@ static int plan_from_radices(Engine* e, Fft1dPlan& p, int n, const std::vector<i
     if (nb % 8 != 0) p.skew_ok = 0;
     if (!(p.ns[st] % 8 == 0 || (p.ns[st] == 1 && p.radix[st] % 8 == 0))) p.skew_ok = 0;
   }
-  if (std::getenv("LPC_NO_SKEW")) p.skew_ok = 0;
+  if (e->opt.no_skew) p.skew_ok = 0;
   // diagnostic only (results are garbage): no butterflies at all, every pass degenerates to "tile in, tile out"
   // through LDS -- times the memory access pattern of the passes alone (profiles/r01b_notes.md)
 #ifdef LPC_DEBUG_KNOBS   // never in the product build: the results are garbage by construction
@@ -76,23 +76,13 @@ static int plan_from_radices(Engine* e, Fft1dPlan& p, int n, const std::vector<i
   return 0;
 }
 
-static int build_plan(Engine* e, Fft1dPlan& p, int n) {
-  p.n = n;
-  p.nst = 0;
+// radices of a length-n transform (5-smooth): few, fat stages -- the number of radix-6 stages (each pairs a 2 with a 3)
+// that minimises the stage count; ties keep more radix-8 stages.  8s first (the twiddle-free first stage should be fat).
+static bool plan_radices(int n, std::vector<int>& rad) {
+  rad.clear();
   int r = n, a = 0, b3 = 0;
   while (r % 2 == 0) { r /= 2; ++a; }
   while (r % 3 == 0) { r /= 3; ++b3; }
-  std::vector<int> rad;
-  // few, fat stages: choose the number of radix-6 stages (each pairs a 2 with a 3) that minimises the
-  // stage count; ties keep more radix-8 stages.  8s first (the twiddle-free first stage should be fat).
-  static int max_radix = -1;
-  if (max_radix < 0) {
-    const char* env = std::getenv("LPC_MAX_RADIX");  // 16 needs a -DLPC_ENABLE_R16 build
-    max_radix = env ? atoi(env) : 8;
-#ifndef LPC_ENABLE_R16
-    max_radix = 8;
-#endif
-  }
   int c5 = 0;
   { int t = r; while (t % 5 == 0) { t /= 5; ++c5; } }
   int best_k6 = 0, best_cnt = 1 << 30;
@@ -101,32 +91,44 @@ static int build_plan(Engine* e, Fft1dPlan& p, int n) {
     const int cnt = k6 + a2 / 3 + (a2 % 3 ? 1 : 0) + (b3 - k6) + c5;
     if (cnt < best_cnt) { best_cnt = cnt; best_k6 = k6; }
   }
-  if (max_radix >= 16) {
-    best_k6 = (a % 4 == 1 && b3 > 0) ? 1 : 0;
-    for (int i = 0; i < (a - best_k6) / 4; ++i) rad.push_back(16);
-    a = (a - best_k6) % 4;
-  } else {
-    a -= best_k6;
-    for (int i = 0; i < a / 3; ++i) rad.push_back(8);
-    a %= 3;
-  }
+  a -= best_k6;
+  for (int i = 0; i < a / 3; ++i) rad.push_back(8);
+  a %= 3;
   for (int i = 0; i < best_k6; ++i) rad.push_back(6);
   b3 -= best_k6;
   if (a == 2) rad.push_back(4);
   if (a == 1) rad.push_back(2);
   while (r % 5 == 0) { r /= 5; rad.push_back(5); }
   for (int i = 0; i < b3; ++i) rad.push_back(3);
-  if (r != 1) return fail("length " + std::to_string(n) + " is not 5-smooth");
+  return r == 1;
+}
+
+static int build_plan(Engine* e, Fft1dPlan& p, int n) {
+  p.n = n;
+  p.nst = 0;
+  std::vector<int> rad;
+  if (!plan_radices(n, rad)) return fail("length " + std::to_string(n) + " is not 5-smooth");
   return plan_from_radices(e, p, n, rad);
 }
 
+// same rule as plan_from_radices(): the i + i/8 LDS skew stays affine in every stage
+static bool radices_skew_ok(int n, const std::vector<int>& rad) {
+  int ns = 1;
+  for (int r : rad) {
+    if ((n / r) % 8 != 0) return false;
+    if (!(ns % 8 == 0 || (ns == 1 && r % 8 == 0))) return false;
+    ns *= r;
+  }
+  return true;
+}
+
 // choose the column split Hp = N1*N2 and the tile width
-static void choose_split(int Hp, int Wc, int* N1, int* N2, int* T, bool prefer24 = false) {
+static void choose_split(const EngineOpts& opt, int Hp, int Wc, int* N1, int* N2, int* T, bool prefer24 = false) {
   int t = 16;
-  if (const char* env = std::getenv("LPC_COL_T")) t = std::max(1, atoi(env));  // tuning knob
+  if (opt.col_t > 0) t = opt.col_t;  // option col_t
   while (t > 1 && t / 2 >= Wc) t /= 2;  // tiny images: do not waste lanes on empty columns
   int budget = kMaxTilePoints;          // points per LDS tile, worst case two arrays (ADMM middle)
-  if (const char* env = std::getenv("LPC_TILE_BUDGET")) budget = std::max(64, atoi(env));  // test knob
+  if (opt.tile_budget > 0) budget = std::max(64, opt.tile_budget);  // option tile_budget (tests)
   for (int tt = t; tt >= (t >= 8 ? 8 : t); tt /= 2) {
     if ((long)Hp * 2 * tt <= budget) { *N1 = 1; *N2 = Hp; *T = tt; return; }
     if (tt == 1) break;
@@ -145,8 +147,8 @@ static void choose_split(int Hp, int Wc, int* N1, int* N2, int* T, bool prefer24
   if (prefer24 && Hp % 24 == 0 && Hp / 24 <= 128 && Hp / 24 >= 2 && (long)(Hp / 24) * t <= budget / 2) {
     best2 = 24; best1 = Hp / 24;
   }
-  if (const char* env = std::getenv("LPC_SPLIT_N2")) {  // tuning knob: force the length of the fused middle transform
-    const int n2 = atoi(env);
+  if (opt.split_n2 > 0) {  // option split_n2: force the length of the fused middle transform
+    const int n2 = opt.split_n2;
     if (n2 > 0 && Hp % n2 == 0 && (long)n2 * 2 * t <= budget && (long)(Hp / n2) * t <= budget) { best2 = n2; best1 = Hp / n2; }
   }
   *N1 = best1; *N2 = best2; *T = t;
@@ -155,7 +157,137 @@ static void choose_split(int Hp, int Wc, int* N1, int* N2, int* T, bool prefer24
 // stored row p = k1*N2 + k2  <->  frequency k = k1 + N1*k2
 static inline int stored_row_freq(const Engine* e, int p) { return (p / e->N2) + e->N1 * (p % e->N2); }
 
-static int setup_geometry(Engine* e) {
+// ---- the launch plan: everything that is decided once per handle, no device work -----------------------------------
+static void set_static_fft(StaticFft& f, int n, const std::vector<int>& rad, int T, int nt, int em) {
+  f = StaticFft{};
+  if ((int)rad.size() > LPC_SPEC_MAX_ST) return;    // (cannot happen for n <= 16384 with these radices: leaves n == 0)
+  f.n = n; f.nst = (int)rad.size();
+  for (int i = 0; i < f.nst; ++i) f.rad[i] = rad[(size_t)i];
+  f.T = T; f.nt = nt; f.em = em;
+}
+static inline int round_up64(int v) { return (v + 63) / 64 * 64; }
+
+// `allow_static`: choose compile-time plans (-> e->spec, served by a plan module) wherever the kernels exist; false: the
+// run-time plans of the core library alone.  Sets N1, N2, T, rows_half and the spec; touches nothing on the device.
+static void choose_plan(Engine* e, bool allow_static) {
+  const lpc_config& c = e->cfg;
+  const PlaneGeom& g = e->g;
+  const EngineOpts& o = e->opt;
+  const bool admm = c.algo == LPC_ALGO_ADMM, f32 = sizeof(real) == 4;
+  e->spec = PlanSpec{};
+  e->spec.family = admm ? LPC_FAM_ADMM : LPC_FAM_GD;
+  e->spec.f64 = f32 ? 0 : 1;
+  e->mid_reg = !o.mid_lds;
+  // (a 24-point register middle for ADMM in float32 only: 2 x 24 complex128 values do not fit a lane's registers)
+  choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, (!admm || f32) && e->mid_reg);
+  const bool st_cols = allow_static && !o.no_static_cols;
+  // Single-pass ADMM columns whose two-spectra tile allows only 8 image columns (DiffuserCam-sized frames, 540 padded
+  // rows): the fused middle takes the two spectra one after the other through a 16-column tile (k_cols_mid_admm_seq)
+  // ... when the batch is large enough to fill the chip with half as many workgroups (measured, profiles/r02_notes.md:
+  // 64 frames 1.20 -> 0.96 ms per launch; ONE frame 0.032 -> 0.042 ms: 93 workgroups for 256 CUs)
+  bool seq = false;
+  if (admm && f32 && st_cols && e->N1 == 1 && e->T == 8 && g.Wc > 8 && (long)g.Hp * 16 <= kMaxTilePoints &&
+      o.col_t == 0 && o.mid_seq != 0 && ((long)e->P * ((g.Wc + 15) / 16) >= 512 || o.mid_seq == 1)) {
+    seq = true;
+    e->T = 16;
+  }
+  // Row passes: one real row per half-length complex transform (k_r*_half kernels) once the
+  // paired tile is so large that fewer than 5 workgroups fit a CU's 160 KiB of LDS.  Measured (r01b_notes.md):
+  // 8192 columns +3 % it/s, 3840 columns (C5) +1.8 %; 960 columns (C4) -5 %: the short transforms leave most
+  // of a 256-thread group idle.
+  // The gradient-descent family switches earlier (its irfft -> residual -> rfft kernel runs two transforms per
+  // workgroup): 2048 columns FISTA +6.8 %, ADMM -1 %.
+  const bool half_ok = g.Wp % 2 == 0 && g.Wp >= 4;
+  const bool wide = admm ? 5 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024 : g.Wp >= 2048;
+  e->rows_half = half_ok && wide;
+  if (o.rows_half == 0) e->rows_half = false;
+  if (o.rows_half == 1 && half_ok) e->rows_half = true;
+  if (!allow_static) return;
+
+  PlanSpec& sp = e->spec;
+  std::vector<int> rad;
+  // the X half of the image-domain work moves into the forward rows when the stencil half can run as the tiled
+  // 16-byte-lane kernel (k_admm_spatial_v4<.., XHALF = false>): float32, padded width a multiple of 4
+  const bool xhalf = admm && f32 && g.Wp % 4 == 0 && !o.no_xhalf && !o.k1_scalar;
+  // ---- rows
+  if (e->rows_half) {
+    const int n = g.Wp / 2;
+    plan_radices(n, rad);
+    if (n == 4096) rad = {16, 16, 16};   // one butterfly per thread and stage, one LDS round trip fewer than 8.8.8.8
+                                          // (same-box A/B, profiles/r02_notes.md: inverse rows 0.518 -> 0.487 ms)
+    const int nt = std::min(1024, std::max(64, round_up64(n / rad[0])));   // every lane owns a first-stage butterfly
+    set_static_fft(sp.row, n, rad, 1, nt, (n + nt - 1) / nt);
+    if (sp.row.n && sp.row.em <= 16) {
+      sp.row_kind = LPC_ROWS_HALF;
+      sp.row_sk = radices_skew_ok(n, rad) && !o.no_skew;
+      sp.row_x = xhalf;
+    }
+  } else if (admm) {    // paired rows: ADMM's own kernels only (set-up transforms keep the run-time plan)
+    const int n = g.Wp;
+    plan_radices(n, rad);
+    // no folded radix-2 stage on compile-time plans: 8 ... 2 -> 4 ... 4
+    if (rad.size() >= 2 && rad.back() == 2) {
+      for (size_t i = rad.size() - 1; i-- > 0;)
+        if (rad[i] == 8) { rad[i] = 4; rad.back() = 4; std::stable_sort(rad.begin(), rad.end(), [](int a, int b) { return (a == 8) > (b == 8); }); break; }
+    }
+    int nt = std::min(1024, std::max(64, round_up64(n / rad[0])));
+    // short rows (960 = 8.8.5.3: 120 first-stage butterflies): 128 threads x 8 points for batches, where every lane
+    // then owns a butterfly of the stage that issues the global loads (forward rows 0.642 -> 0.576 ms at 64 frames);
+    // ONE frame is faster on 256 x 4 (0.460 vs 0.470 ms per 5 iterations, profiles/r02_notes.md)
+    if (nt < 256 && n >= 512) {
+      const bool batch = (long)e->P * g.Hp >= 8192;
+      if (o.prow_nt128 == 0 || (o.prow_nt128 < 0 && !batch)) nt = 256;
+    }
+    set_static_fft(sp.row, n, rad, 1, nt, (n + nt - 1) / nt);
+    if (sp.row.n && sp.row.em <= 16) {
+      sp.row_kind = LPC_ROWS_PAIRED;
+      sp.row_sk = radices_skew_ok(n, rad) && !o.no_skew;
+      sp.row_x = xhalf;
+    }
+  }
+  // ---- pass A of a split column transform: 32 columns per tile (256-byte row segments at its long row stride) while
+  // the fused middle keeps 16 -- the two passes tile the columns independently.  Same-box A/B at 12 MP with T = 32 for
+  // both (profiles/r02_notes.md): pass A 0.578 / 0.575 -> 0.530 / 0.510 ms, the middle 0.655 -> 0.71 ms.
+  if (st_cols && e->N1 > 1) {
+    int T = e->T;
+    if (e->T == 16 && g.Wc >= 256 && o.col_t == 0) T = 32;
+    if (o.passa_t > 0) T = o.passa_t;
+    while (T > 1 && (long)e->N1 * T > kMaxTilePoints) T /= 2;
+    plan_radices(e->N1, rad);
+    const int pts = e->N1 * T;
+    int nt = T >= 32 ? 512 : 256;
+    while (nt < 1024 && (pts + nt - 1) / nt > 16) nt *= 2;
+    set_static_fft(sp.passA, e->N1, rad, T, nt, (pts + nt - 1) / nt);
+    if (sp.passA.em > 16) sp.passA = StaticFft{};
+  }
+  // ---- ADMM's fused middle in LDS (a 24-point pass B lives in registers: k_cols_mid_admm_reg, core library)
+  const bool reg_mid = e->N1 > 1 && e->mid_reg && f32 && e->N2 == 24;
+  if (admm && st_cols && !reg_mid) {
+    const int n = e->N2, T = e->T;
+    plan_radices(n, rad);
+    // 540 = 30.18 side by side (two fat register butterflies, one LDS trip; 184 registers, one workgroup per CU);
+    // one spectrum at a time: 6.10.9 inside a 128-register budget = TWO workgroups per CU overlapping one another's
+    // loads and barriers -- 0.650 ms per launch at 64 frames against 0.84 ms for 30.18 and 0.95 ms for 6.6.5.3
+    if (n == 540) rad = seq ? std::vector<int>{6, 10, 9} : std::vector<int>{30, 18};
+    const int pts = n * (seq ? T : 2 * T);
+    const int nt = pts <= 4096 ? 256 : (pts <= 9216 ? 512 : 1024);
+    set_static_fft(sp.mid, n, rad, T, nt, (pts + nt - 1) / nt);
+    if (sp.mid.n && sp.mid.em <= 18) {
+      sp.mid_kind = seq ? LPC_MID_SEQ : LPC_MID_PAIR;
+      if (seq) {   // waves per SIMD the register allocation must allow: as many workgroups as the LDS holds
+        const size_t lds = (size_t)n * (T + 1) * sizeof(real2);
+        const int wgs = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
+        sp.mid_minw = std::min(8, std::max(1, wgs * nt / 256));
+      }
+    } else {
+      sp.mid = StaticFft{};
+    }
+  }
+  if (seq && sp.mid_kind != LPC_MID_SEQ) e->T = 8;   // (no module kernel for it after all: back to the two-spectra tile)
+}
+
+// frame geometry (rfft_convolve.py:110-117) and the launch plan -- no device work (also serves lpc_plan_module)
+static int setup_shape(Engine* e, bool* want_static_out) {
   const lpc_config& c = e->cfg;
   PlaneGeom& g = e->g;
   g.H = c.height; g.W = c.width;
@@ -176,87 +308,47 @@ static int setup_geometry(Engine* e) {
   e->Pdata = c.batch * c.channels;
   if (g.Wp > kMaxTilePoints)
     return fail("padded width " + std::to_string(g.Wp) + " > " + std::to_string(kMaxTilePoints) + " is not supported");
-  // (ADMM in float32 only: 2 x 24 complex128 values do not fit a lane's registers)
-  choose_split(g.Hp, g.Wc, &e->N1, &e->N2, &e->T,
-               (c.algo != LPC_ALGO_ADMM || sizeof(real) == 4) && !std::getenv("LPC_MID_LDS"));
-  // DiffuserCam-sized ADMM frames (540 padded rows, single-pass columns): the fused middle takes the two spectra one
-  // after the other through a 16-column tile (k_cols_mid_admm_seq) instead of 2 x 8 columns side by side
-  // ... when the batch is large enough to fill the chip with the half as many workgroups (measured, profiles/r02_notes.md:
-  // 64 frames 1.20 -> 0.96 ms per launch; ONE frame 0.032 -> 0.042 ms: 93 workgroups for 256 CUs)
-  if (c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && e->N1 == 1 && g.Hp == 540 && e->T == 8 && g.Wc > 8 &&
-      ((long)e->P * ((g.Wc + 15) / 16) >= 512 || std::getenv("LPC_MID_SEQ")) && !std::getenv("LPC_MID_PAIR") && !std::getenv("LPC_NO_STATIC") && !std::getenv("LPC_NO_STATIC_COLS") &&
-      !std::getenv("LPC_COL_T"))
-    e->T = 16;
+  // compile-time plans live in a plan module (lpc_plan.h): look for it, build it if allowed, else run-time plans
+  const bool want_static = !e->opt.no_static && (long)g.Hp * g.Wp >= e->opt.jit_min_points;
+  choose_plan(e, want_static);
+  *want_static_out = want_static;
+  return 0;
+}
+
+static int setup_geometry(Engine* e) {
+  bool want_static = false;
+  LPC_OK(setup_shape(e, &want_static));
+  const lpc_config& c = e->cfg;
+  const PlaneGeom& g = e->g;
+  e->mod = nullptr;
+  if (!want_static) e->mod_note = e->opt.no_static ? "no_static" : "small frame";
+  else if (e->spec.any()) {
+    e->mod = get_plan_module(e->spec, e->opt, e->opt.jit != 0, &e->mod_note);
+    if (!e->mod) choose_plan(e, false);
+  }
+  if (!e->mod) e->spec = PlanSpec{};
+  const bool admm = c.algo == LPC_ALGO_ADMM;
   LPC_OK(build_plan(e, e->planW, g.Wp));
-  e->rows_r2 = e->planW.nst >= 2 && e->planW.radix[e->planW.nst - 1] == 2 && !std::getenv("LPC_NO_R2");
+  e->rows_r2 = e->planW.nst >= 2 && e->planW.radix[e->planW.nst - 1] == 2 && !e->opt.no_r2;
   if (e->rows_r2) {
     std::vector<int> rad{2};
     for (int st = 0; st + 1 < e->planW.nst; ++st) rad.push_back(e->planW.radix[st]);
     LPC_OK(plan_from_radices(e, e->planWi, g.Wp, rad));
     e->planWi.skew_ok = 0;
   }
-  e->mid_reg = !std::getenv("LPC_MID_LDS");
-  // Row passes: one real row per half-length complex transform (k_r*_half kernels) once the
-  // paired tile is so large that fewer than 5 workgroups fit a CU's 160 KiB of LDS.  Measured (r01b_notes.md):
-  // 8192 columns +3 % it/s, 3840 columns (C5) +1.8 %; 960 columns (C4) -5 %: the short transforms leave most
-  // of a 256-thread group idle.
-  const bool half_ok = g.Wp % 2 == 0 && g.Wp >= 4;
-  // The gradient-descent family switches earlier (its irfft -> residual -> rfft kernel runs two transforms per
-  // workgroup): 2048 columns FISTA +6.8 %, ADMM -1 %.
-  const bool wide = c.algo == LPC_ALGO_ADMM ? 5 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024 : g.Wp >= 2048;
-  e->rows_half = half_ok && wide && !std::getenv("LPC_ROWS_PAIRED");
-  if (half_ok && std::getenv("LPC_ROWS_HALF")) e->rows_half = true;   // test knob: small frames too
   if (e->rows_half) LPC_OK(build_plan(e, e->planWh, g.Wp / 2));
-  if (e->rows_half && e->planWh.skew_ok && !std::getenv("LPC_NO_STATIC")) {
-    if (RowPlan4096::matches(e->planWh)) e->static_rows = 4096;
-    if (RowPlan1920::matches(e->planWh)) e->static_rows = 1920;
-    if (RowPlan1024::matches(e->planWh)) e->static_rows = 1024;
-  }
-
-  // float4 lanes and half-length rows: r_sp and a are computed by the row workgroups themselves (float32 build)
-  // ... an OPTION (LPC_FUSE_ROWS=1), not the default: it removes 4R of traffic and one launch per iteration, but its
-  // image-domain half runs at the row kernel's occupancy (4 workgroups per CU, LDS-bound) instead of the tiled kernel's
-  // 7.  Measured on one box with compile-time plans everywhere (profiles/r02_notes.md): 12 MP fused 2.01 ms vs
-  // stand-alone 1.51 + 0.45 ms (229.7 vs 236.3 it/s); 1080p x 16 planes 5.85 vs 4.31 + 1.52 ms.  (With the run-time
-  // plans of round 1 the forward rows took 0.61 ms and fusion won, 202 vs 196 it/s.)
-  e->fuse_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && e->rows_half && g.Wp % 4 == 0 &&
-                 std::getenv("LPC_FUSE_ROWS") && !std::getenv("LPC_K1_SCALAR");
-
   LPC_OK(build_plan(e, e->planB, e->N2));
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
-  e->static_sk = !std::getenv("LPC_ROWS_NOSKEW");
-  // 4096-point rows as 16.16.16: one radix-16 butterfly per thread and stage, one LDS round trip fewer than 8.8.8.8
-  // (same-box A/B, profiles/r02_notes.md: inverse rows 0.518 -> 0.487 ms, FISTA 412 -> 417 it/s); LPC_ROWS_R8 = the old plan
-  e->rows_r16 = std::getenv("LPC_ROWS_R8") == nullptr;
-  if (!std::getenv("LPC_NO_STATIC") && !std::getenv("LPC_NO_STATIC_COLS")) {
-    if (e->N1 > 1 && e->T == 16 && ColPlan128::matches(e->planA)) e->static_passA = 128;
-    if (e->N1 > 1 && e->T == 16 && ColPlan90::matches(e->planA)) e->static_passA = 90;
-    if (e->N1 > 1 && e->T == 16 && ColPlan64::matches(e->planA)) e->static_passA = 64;
-    if (e->N1 > 1 && e->T == 16 && ColPlan48::matches(e->planB)) e->static_mid = 48;
-    // (540: the static plan is 30.18, not build_plan()'s 6.6.5.3 -- only the length and the twiddle table are shared)
-    if (e->N1 == 1 && e->T == 8 && e->planB.n == 540) e->static_mid = 540;
-    if (e->N1 == 1 && e->T == 16 && c.algo == LPC_ALGO_ADMM && e->planB.n == 540) e->static_mid = 541;
-    if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan960::matches(e->planW)) e->static_prow = 960;
-    // 960 = 8.8.5.3 on 256 threads leaves 136 lanes without a butterfly in the first stage, where every global load of
-    // the row kernels is issued; 128 threads x 8 points: forward rows 0.642 -> 0.576 ms, inverse 0.322 -> 0.312 ms at
-    // 64 frames, but 0.460 -> 0.470 ms per 5 iterations for ONE frame (profiles/r02_notes.md) -> batches only
-    e->prow_nt128 = e->static_prow == 960 && !std::getenv("LPC_PROW_NT256") &&
-                    ((long)e->P * g.Hp >= 8192 || std::getenv("LPC_PROW_NT128"));
-    if (!e->rows_half && !e->rows_r2 && e->planW.skew_ok && RowPlan2048::matches(e->planW)) e->static_prow = 2048;
-  }
-  // The half of the image-domain work that needs no neighbours IS fused by default where a compile-time row plan
-  // exists: the forward row blocks of `a` compute xi' and a = mu1 X - xi' from xi, HV, HV_old, y themselves (-2R per
-  // iteration), the tiled kernel keeps the stencil half at its own occupancy.  LPC_NO_XHALF = the full stand-alone kernel.
-  e->xhalf_rows = c.algo == LPC_ALGO_ADMM && sizeof(real) == 4 && g.Wp % 4 == 0 &&
-                  ((e->rows_half && e->static_rows) || (!e->rows_half && e->static_prow)) &&
-                  !e->fuse_rows && !std::getenv("LPC_NO_XHALF") && !std::getenv("LPC_K1_SCALAR");
-  // ... and outside the sensor window that half works from HV alone (AdmmScalars::xiw); LPC_XI_FULL = every pixel alike
-  e->xi_window = e->xhalf_rows && !std::getenv("LPC_XI_FULL");
-  e->hv_skip = e->xi_window && e->rows_half && e->static_rows && e->N1 > 1 && !std::getenv("LPC_HV_FULL");
-  // paired 960-point rows of a large batch (C4): same skip, the rows of r_sp / V outside the window ride two per
-  // transform instead (k_rfwd_arrays_x / k_rinv_arrays) and the sequential fused middle rescales the kept rows of SB
-  e->prow_skip = e->xi_window && e->static_prow == 960 && e->static_mid == 541 && e->prow_nt128 && !std::getenv("LPC_HV_FULL");
-  e->gd_fuse_fwd = c.algo >= LPC_ALGO_GD && e->rows_half && e->static_rows && !std::getenv("LPC_GD_NO_FUSE_FWD");
+  // The half of the image-domain work that needs no neighbours rides in the module's forward row kernel: the blocks of
+  // `a` compute xi' and a = mu1 X - xi' from xi, HV, HV_old, y themselves (-2R per iteration), the tiled kernel keeps
+  // the stencil half at its own occupancy (option no_xhalf: the full stand-alone kernel) ...
+  e->xhalf_rows = admm && e->mod && e->mod->admm_rows_fwd_x;
+  // ... outside the sensor window that half works from HV alone (AdmmScalars::xiw; option xi_full: every pixel alike) ...
+  e->xi_window = e->xhalf_rows && !e->opt.xi_full;
+  // ... and rows wholly outside it skip the H V row transforms in both directions: the kept rows of SB are rescaled by
+  // forward pass A (any plan) or, for single-pass columns, by the module's fused middle (option hv_full: off)
+  e->hv_skip = e->xi_window && !e->opt.hv_full && e->mod->admm_rows_inv && (e->N1 > 1 || e->mod->admm_mid);
+  e->gd_fuse_fwd = c.algo >= LPC_ALGO_GD && e->mod && e->mod->gd_rows_update_fwd && !e->opt.gd_no_fuse_fwd;
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
   const int ntc = (g.Wc + e->T - 1) / e->T;
   ColPass& A = e->passA;
@@ -267,14 +359,10 @@ static int setup_geometry(Engine* e) {
   ColPass& B = e->passB;
   B = A;
   B.N = e->N2; B.G = e->N1; B.istride = 1; B.gstride = e->N2;
-  // Pass A on a compile-time plan takes 32 columns per tile (256-byte row segments at its long row stride) while the
-  // fused middle keeps 16: the two passes tile the columns independently.  Same-box A/B at 12 MP with T = 32 for both
-  // (profiles/r02_notes.md): pass A 0.578 / 0.575 -> 0.530 / 0.510 ms, the middle 0.655 -> 0.71 ms.
-  if (e->static_passA && e->T == 16 && (g.Wc >= 256 || std::getenv("LPC_PASSA_T32")) && !std::getenv("LPC_COL_T") &&
-      !std::getenv("LPC_PASSA_T16")) {
-    A.T = 32;
-    A.ntile_c = (g.Wc + 31) / 32;
-    A.tdiv = make_fastdiv(32u);
+  if (e->spec.passA.n) {       // the module's pass A tiles the columns on its own (choose_plan)
+    A.T = e->spec.passA.T;
+    A.ntile_c = (g.Wc + A.T - 1) / A.T;
+    A.tdiv = make_fastdiv((unsigned)A.T);
     A.tcdiv = make_fastdiv((unsigned)A.ntile_c);
   }
   // ifftshift phases: out[i] = in[(i + n/2) mod n]  <=>  multiply bin k by exp(+2 pi i k (n/2) / n)
@@ -437,10 +525,8 @@ static int admm_reset(Engine* e) {
 
 // (r_sp, a) in e->Rsp / e->Aarr  ->  Vout = irfft2(R_div (rfft2 r_sp + s H* rfft2 a)),  HVout = H Vout:
 // forward rows, [pass A], fused middle, [inverse pass A], inverse rows
-static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real* HVout, bool rows_done = false,
-                              bool xhalf = false) {
-  if (rows_done) {}                            // k_admm_rows_fused has already written the row spectra
-  else if (xhalf) LPC_OK(admm_rows_fwd_x(e, sc));
+static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real* HVout, bool xhalf = false) {
+  if (xhalf) LPC_OK(admm_rows_fwd_x(e, sc));
   else LPC_OK(admm_rows_fwd(e));
   LPC_OK(admm_cols(e, sc));
   return admm_rows_inv(e, Vout, HVout, sc.skiphv != 0);
@@ -454,8 +540,7 @@ static int admm_iterate(Engine* e, int n_iter) {
   const unsigned tiles_x = (g.Wp + TW - 1) / TW, tiles_y = (g.Hp + TH - 1) / TH;
   const dim3 k1_grid(tiles_x * tiles_y, e->P, 1);
   // 16-byte-lane kernel whenever the padded width allows aligned float4 rows (every BASELINE size does)
-  static int force_scalar = -1;
-  if (force_scalar < 0) force_scalar = std::getenv("LPC_K1_SCALAR") ? 1 : 0;
+  const bool force_scalar = e->opt.k1_scalar != 0;
 #ifdef LPC_DOUBLE
   const bool vec4 = false;  // the 16-byte-lane kernel is float-only
 #else
@@ -481,14 +566,10 @@ static int admm_iterate(Engine* e, int n_iter) {
     // (nothing else touches the work spectrum inside this loop); the last iteration runs complete (it stores xi out
     // there), and the last three write H V there: xi = mu1p (HV - HV_old) of the final X half and every read-out after
     // the call need HV_{n-2}, HV_{n-1}, HV_n whole
-    sc.skipa = ((e->hv_skip || e->prow_skip) && it > 0 && !sc.xi_store) ? 1 : 0;
-    sc.skiphv = ((e->hv_skip || e->prow_skip) && it + 3 < n_iter) ? 1 : 0;
-    bool rows_done = false;
+    sc.skipa = (e->hv_skip && it > 0 && !sc.xi_store) ? 1 : 0;
+    sc.skiphv = (e->hv_skip && it + 3 < n_iter) ? 1 : 0;
 #ifndef LPC_DOUBLE
-    if (e->fuse_rows) {
-      LPC_OK(admm_rows_fused(e, sc, (const real*)Vc, (const real*)Vo));
-      rows_done = true;
-    } else if (vec4 && e->xhalf_rows)
+    if (vec4 && e->xhalf_rows)
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4X, NT, false>, k1_grid4x, NT, k1_smem4x, g, sc, (const real*)Vc,
                       (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
                       (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
@@ -510,7 +591,7 @@ static int admm_iterate(Engine* e, int n_iter) {
     e->first = false;
     // (hcur still names the CURRENT H V here: the X half inside the forward rows reads HVb[hcur] and HVb[hcur ^ 1]
     // before the inverse rows of this same step overwrite HVb[hcur ^ 1] -- stream order)
-    LPC_OK(admm_spectral_step(e, sc, Vo, e->HVb[e->hcur ^ 1], rows_done, vec4 && e->xhalf_rows && !rows_done));
+    LPC_OK(admm_spectral_step(e, sc, Vo, e->HVb[e->hcur ^ 1], vec4 && e->xhalf_rows));
     e->vcur ^= 1;  // Vo now holds the new image estimate
     e->hcur ^= 1;  // ... and the other H V buffer its forward model
     for (int k = 0; k < 4; ++k) e->last_par[k] = par[k];
@@ -541,6 +622,12 @@ int lpc_create(const lpc_config* cfg, lpc_handle* out) {
     return fail("no HIP device: the engine has no CPU path");
   Engine* e = new Engine();
   e->cfg = *cfg;
+  e->cfg.options = nullptr;            // (the caller's string is not kept)
+  {   // process-wide defaults from the environment first, then the handle's own
+    std::string err = parse_engine_opts(std::getenv("LPC_OPTIONS"), e->opt);
+    if (err.empty()) err = parse_engine_opts(cfg->options, e->opt);
+    if (!err.empty()) { delete e; return fail("lpc_create: " + err); }
+  }
   e->tk = cfg->fista_tk; e->nest_mu = cfg->nesterov_mu; e->nest_p = cfg->nesterov_p;
   int rc = setup_geometry(e);
   const PlaneGeom& g = e->g;
@@ -561,6 +648,26 @@ int lpc_create(const lpc_config* cfg, lpc_handle* out) {
     return rc;
   }
   *out = e;
+  return 0;
+}
+
+// the plan module lpc_create(cfg) would use: its key, and (build != 0) compile it now if it is not on disk.  No device
+// needed: build.py pre-builds the modules of BASELINE.json's shapes with it in the GPU-less build container.
+int lpc_plan_module(const lpc_config* cfg, int build, char* key_buf, size_t n) {
+  if (!cfg) return fail("lpc_plan_module: null config");
+  if (cfg->height < 1 || cfg->width < 1 || cfg->depth < 1 || cfg->batch < 1) return fail("lpc_plan_module: bad size");
+  Engine tmp;
+  tmp.cfg = *cfg;
+  std::string err = parse_engine_opts(std::getenv("LPC_OPTIONS"), tmp.opt);
+  if (err.empty()) err = parse_engine_opts(cfg->options, tmp.opt);
+  if (!err.empty()) return fail("lpc_plan_module: " + err);
+  bool want_static = false;
+  LPC_OK(setup_shape(&tmp, &want_static));
+  const bool any = want_static && tmp.spec.any();
+  if (key_buf && n) std::snprintf(key_buf, n, "%s", any ? plan_spec_key(tmp.spec).c_str() : "");
+  if (!any || !build) return 0;
+  std::string path;
+  if (build_plan_module(tmp.spec, tmp.opt, &path) != 0) return fail(path);
   return 0;
 }
 
@@ -1158,18 +1265,18 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
       // X half in the forward rows (default with compile-time row plans): the tiled kernel reads V, V_old, eta0, eta1,
       // rho and writes eta0, eta1, rho, r_sp = 9R (SURVEY's 15R + R0 minus its X part: reads HV, X, xi, y, writes xi, X,
       // a); the row kernel reads r_sp (R) and xi, HV, HV_old, y (3R + R0), writes xi (R) and the two spectra (2S).
-      case LPC_K_SPATIAL: b = e->fuse_rows ? 12.0 * R + R0 + 2.0 * S : (e->xhalf_rows ? 9.0 * R : 15.0 * R + R0); break;
+      case LPC_K_SPATIAL: b = e->xhalf_rows ? 9.0 * R : 15.0 * R + R0; break;
       // ... with xi confined to the sensor window (AdmmScalars::xiw) the row kernel reads r_sp, HV everywhere (2R) and
       // xi, HV_old / writes xi only over the window (3 window-sized arrays per plane) and y: 2R + 3 Rw + R0 + 2S
       // ... and with the H V row transforms skipped on rows wholly outside the window (AdmmScalars::skipa, steady state
       // of a long call; fr = H / Hp): rows fwd (1 + fr) R + 3 Rw + R0 + (1 + fr) S, rows inv (1 + fr) (S + R)
-      case LPC_K_ROW_FWD: b = e->fuse_rows ? 0.0 : ((e->hv_skip || e->prow_skip) ? (1.0 + fr) * R + 3.0 * eb * g.H * g.W * e->P + R0 + (1.0 + fr) * S
+      case LPC_K_ROW_FWD: b = (e->hv_skip ? (1.0 + fr) * R + 3.0 * eb * g.H * g.W * e->P + R0 + (1.0 + fr) * S
                                   : e->xi_window ? 2.0 * R + 3.0 * eb * g.H * g.W * e->P + R0 + 2.0 * S
                                   : e->xhalf_rows ? 5.0 * R + R0 + 2.0 * S : 2.0 * R + 2.0 * S); break;
       case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
       case LPC_K_COL_MID: b = 4.0 * S + Sc + eb * g.Hp * g.Wc; break;  // + H (complex) + |G| (real, one plane)
       case LPC_K_COL_A_INV: b = split ? 4.0 * S : 0.0; break;
-      case LPC_K_ROW_INV: b = (e->hv_skip || e->prow_skip) ? (1.0 + fr) * (S + R) : 2.0 * S + 2.0 * R; break;
+      case LPC_K_ROW_INV: b = e->hv_skip ? (1.0 + fr) * (S + R) : 2.0 * S + 2.0 * R; break;
       default: return fail("bad kernel id");
     }
   } else if (e->cfg.algo >= LPC_ALGO_GD) {
@@ -1184,21 +1291,29 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
 int lpc_plan_info(lpc_handle e, char* buf, size_t n) {
   if (!e || !buf || n == 0) return fail("null argument");
   const PlaneGeom& g = e->g;
+  const PlanSpec& sp = e->spec;
+  auto radstr = [](const StaticFft& f) {
+    std::string r;
+    for (int i = 0; i < f.nst; ++i) r += (i ? "." : "") + std::to_string(f.rad[i]);
+    return r;
+  };
   std::string s = "padded " + std::to_string(g.Hp) + "x" + std::to_string(g.Wp);
   s += e->rows_half ? "; rows: half-length " + std::to_string(g.Wp / 2) : "; rows: paired " + std::to_string(g.Wp);
-  if (e->rows_half && e->static_rows) s += e->static_rows == 4096 && e->rows_r16 ? " [static 16.16.16]" : " [static]";
-  if (!e->rows_half && e->static_prow && e->cfg.algo == LPC_ALGO_ADMM) s += " [static]";
+  const bool rows_static = e->mod && sp.row_kind && (e->rows_half || e->cfg.algo == LPC_ALGO_ADMM);
+  if (rows_static) s += " [static " + radstr(sp.row) + ", " + std::to_string(sp.row.nt) + " threads]";
   s += "; columns: " + (e->N1 > 1 ? std::to_string(e->N1) + " x " + std::to_string(e->N2) + " split" : std::string("single pass ") + std::to_string(e->N2));
   s += ", T = " + std::to_string(e->T);
-  if (e->static_passA) s += ", pass A [static]";
+  if (e->mod && sp.passA.n) s += ", pass A [static " + radstr(sp.passA) + ", T = " + std::to_string(sp.passA.T) + "]";
   if (e->cfg.algo == LPC_ALGO_ADMM) {
     const bool reg = e->N1 > 1 && e->mid_reg && sizeof(real) == 4 && e->N2 == 24;
-    s += reg ? ", middle in registers" : (e->static_mid ? ", LDS middle [static]" : ", LDS middle");
-    s += e->fuse_rows ? "; image-domain kernel fused into the forward rows"
-                      : (e->xhalf_rows ? "; tiled TV / W kernel + X half inside the forward rows" : "; stand-alone image-domain kernel");
-    if (e->xi_window) s += (e->hv_skip || e->prow_skip) ? " (xi inside the sensor window only, H V row transforms skipped outside it)"
+    s += reg ? ", middle in registers"
+             : (e->mod && sp.mid_kind ? ", LDS middle [static " + radstr(sp.mid) + (sp.mid_kind == LPC_MID_SEQ ? ", one spectrum at a time]" : "]")
+                                      : ", LDS middle");
+    s += e->xhalf_rows ? "; tiled TV / W kernel + X half inside the forward rows" : "; stand-alone image-domain kernel";
+    if (e->xi_window) s += e->hv_skip ? " (xi inside the sensor window only, H V row transforms skipped outside it)"
                                       : " (xi inside the sensor window only)";
   }
+  s += e->mod ? "; plan module " + plan_spec_key(sp) : "; run-time plans (" + e->mod_note + ")";
   std::snprintf(buf, n, "%s", s.c_str());
   return 0;
 }

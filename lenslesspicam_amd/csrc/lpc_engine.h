@@ -7,9 +7,16 @@
 //   lpc_rows.cpp    every row-pass launch (real <-> half-spectrum transforms, incl. the fused ADMM rows)
 //   lpc_cols.cpp    every column-pass launch (pass A, the fused middles)
 //   lpc_gd.cpp, lpc_gd_update.cpp, lpc_gd_update_fwd.cpp   the gradient-descent family's fused row kernels
+//   lpc_jit.cpp     plan modules: find / compile / load (lpc_plan.h)
+//   lpc_module.cpp  NOT part of the library: the source of a plan module (compile-time-plan kernels of one frame shape)
 #pragma once
 #include "lpc_kernels.h"
 #include "lpc.h"
+#include "lpc_plan.h"
+
+#ifndef LPC_SRC_FP
+#define LPC_SRC_FP "dev"     // fingerprint of the sources (build.py): a module must be built from the same ones
+#endif
 
 #include <algorithm>
 #include <climits>
@@ -80,18 +87,13 @@ struct lpc_engine {
   Fft1dPlan planWi{};   // inverse-row plan with the radix-2 stage FIRST (rows_r2 only)
   Fft1dPlan planWh{};   // length Wp/2: ADMM rows, one real row per half-length transform (rows_half)
   bool rows_half = false;
-  bool static_sk = true;   // static-plan row kernels: LDS skew on (tuning knob LPC_ROWS_NOSKEW: 32 KiB tiles, 5 per CU)
-  int static_passA = 0;    // pass-A length served by a compile-time plan (128 | 90 | 64, 16-column tiles), else 0
-  int static_mid = 0;      // ADMM LDS-middle length served by a compile-time plan (48 with T = 16 | 540 with T = 8)
-  bool prow_nt128 = false; // 960-point paired rows on 128 threads x 8 points (every lane owns a first-stage butterfly): large batches
-  int static_prow = 0;     // ADMM PAIRED-row length served by a compile-time plan (960 | 2048), else 0
-  bool rows_r16 = false;   // 4096-point rows as 16.16.16 instead of 8.8.8.8
-  int static_rows = 0;     // length of the half-row transform when a compile-time plan serves it (lpc_sfft.h), else 0
-  bool xhalf_rows = false; // ADMM: xi / a = mu1 X - xi computed by the forward row kernel (k_admm_rows_fused<.., TVHALF = false>)
+  EngineOpts opt;          // lpc_config::options
+  PlanSpec spec;           // the compile-time-plan kernels this handle runs (lpc_plan.h) ...
+  const struct LpcModule* mod = nullptr;   // ... and the loaded plan module that holds them (null: run-time plans only)
+  std::string mod_note;    // why there is no module, for lpc_plan_info
+  bool xhalf_rows = false; // ADMM: xi / a = mu1 X - xi computed by the forward row kernel of the module
   bool xi_window = false;  // ... which then skips xi / HV_old outside the sensor window (AdmmScalars::xiw)
   bool hv_skip = false;    // ... and rows wholly outside it skip the H V row transforms in both directions (AdmmScalars::skipa)
-  bool prow_skip = false;  // ... the same for 960-point paired rows of a batch (rows outside the window two per transform)
-  bool fuse_rows = false;  // ADMM: the image-domain kernel is fused into the forward row pass (k_admm_rows_fused)
   bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (LPC_MID_LDS=1: off)
   bool rows_r2 = false; // row plans end in a radix-2 stage: fold it into the Hermitian (un)tangling
   ColPass passA{}, passB{};
@@ -232,43 +234,24 @@ static inline RealDst dst_cropped(const Engine* e, real* base) {
   return d;
 }
 
-// static-plan shapes (lpc_sfft.h).  4096 = 8.8.8.8: the half-row transform of 8192-column padded frames (12 MP)
-typedef SPlan<8, 8, 8, 8> RowPlan4096;
-typedef SPlanArg<RowPlan4096> RowArg4096;
-typedef SPlan<16, 16, 16> RowPlan4096r16;   // the same length in three radix-16 stages (one butterfly per thread and stage)
-// 12 MP's column split 6144 = 128 x 48 with 16-column tiles: pass A 128 = 8.8.2, fused middle 48 = 8.6
-typedef SPlan<8, 8, 2> ColPlan128;
-typedef SPlan<8, 6> ColPlan48;
-// 1080 x 1920 frames: 2160 = 90 x 24, pass A 90 = 6.5.3 (the 24-point middle lives in registers)
-typedef SPlan<6, 5, 3> ColPlan90;
-// DiffuserCam-sized frames (270 x 480 -> 540 x 960): single-pass 540-point columns = 30.18 over 2 x 8 tile columns,
-// paired rows of 960 = 8.8.5.3
-typedef SPlan<30, 18> ColPlan540;          // two fat register butterflies (lpc_fft.h); build_plan() makes 6.6.5.3
-typedef SPlan<6, 10, 9> ColPlan540Seq;     // one-spectrum-at-a-time middle: small butterflies, two workgroups per CU
-typedef SPlan<8, 8, 5, 3> RowPlan960;
-// 760 x 1014 frames (1536 x 2048 padded, 1536 = 64 x 24): pass A 64 = 8.8, ADMM's paired rows 2048 = 8.8.8.4
-typedef SPlan<8, 8> ColPlan64;
-typedef SPlan<8, 8, 8, 4> RowPlan2048;
-typedef SPlan<8, 8, 6, 5> RowPlan1920;      // half rows of 3840-column padded frames (1080 x 1920)
-typedef SPlan<8, 8, 8, 2> RowPlan1024;      // half rows of 2048-column padded frames (760 x 1014, the profile/*.py frame)
-// workgroup shape per static row plan: NT threads x EM points (the same table as dispatch_cfg)
-template <class P, int NT_, int EM_>
-struct RowShape { using plan = P; static constexpr int nt = NT_, em = EM_; };
-template <class F>
-static inline int with_row_shape(const lpc_engine* e, F&& f);
-template <class F>
-static inline int with_sk(bool sk, F&& f) {
-  return sk ? f(std::integral_constant<bool, true>{}) : f(std::integral_constant<bool, false>{});
-}
-
-template <class F>
-static inline int with_row_shape(const lpc_engine* e, F&& f) {
-  if (e->static_rows == 4096 && e->rows_r16) return f(RowShape<RowPlan4096r16, 256, 16>{});
-  if (e->static_rows == 4096) return f(RowShape<RowPlan4096, 256, 16>{});
-  if (e->static_rows == 1920) return f(RowShape<RowPlan1920, 256, 8>{});
-  if (e->static_rows == 1024) return f(RowShape<RowPlan1024, 128, 8>{});   // 128 radix-8 butterflies in the fused first stage
-  return fail("internal: no static row plan for this length");
-}
+// ---- plan module: launchers of the compile-time-plan kernels of one frame shape (lpc_module.cpp) -------------------
+// An entry is null when the module does not hold that kernel; the core then launches its run-time-plan kernel.
+struct GdScalars;
+struct LpcModule {
+  int (*rows_fwd_single)(Engine*, const RealSrc*, real2* S, int nplanes, int kid);
+  int (*rows_inv_single)(Engine*, const real2* S, const RealDst*, int nplanes, int kid);
+  int (*admm_rows_fwd)(Engine*);
+  int (*admm_rows_fwd_x)(Engine*, const AdmmScalars*);
+  int (*admm_rows_inv)(Engine*, real* Vout, real* HVout, int skip_hv_outside);
+  int (*gd_rows_mid)(Engine*);
+  int (*gd_rows_update)(Engine*, const GdScalars*, const real* alpha);
+  int (*gd_rows_update_fwd)(Engine*, const GdScalars*, const real* alpha);
+  int (*cols_passA)(Engine*, const ColPass*, real2* S, int nplanes, int inverse, int kid);
+  int (*admm_mid)(Engine*, const ColPass*, const AdmmScalars*, real sb_outside_scale);
+};
+// lpc_jit.cpp: the module of `spec` -- from the process cache, from disk, or (allow_compile) compiled now; null + `why`
+const LpcModule* get_plan_module(const PlanSpec& spec, const EngineOpts& opt, bool allow_compile, std::string* why);
+int build_plan_module(const PlanSpec& spec, const EngineOpts& opt, std::string* path_or_error);   // compile only (no load)
 
 // ---- host functions that cross translation units ------------------------------------------------------------
 // lpc_rows.cpp
@@ -285,7 +268,6 @@ int cols_passB_fwd(Engine* e, real2* S, int nplanes, int zr0, int zr1);
 int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, int zr1, bool crop_rows_only = false);
 int admm_cols(Engine* e, const AdmmScalars& sc);   // sc.skipa: forward pass A rescales the kept rows of SB                // [pass A] -> fused ADMM middle -> [inverse pass A]
 // lpc_gd.cpp, lpc_gd_update.cpp, lpc_gd_update_fwd.cpp (one kernel family each)
-struct GdScalars;
 int gd_rows_mid(Engine* e);                                     // irfft rows -> residual -> rfft rows (S -> S2)
 int gd_rows_update(Engine* e, const GdScalars& sc, const real* alpha);   // irfft rows -> fused projected update
 int gd_rows_update_fwd(Engine* e, const GdScalars& sc, const real* alpha);   // ... -> next iteration's forward rows (S)

@@ -6,16 +6,7 @@
 int gd_rows_mid(Engine* e) {
   const PlaneGeom& g = e->g;
   const int nblk = (g.H + 1) / 2;
-  if (e->rows_half && e->static_rows)
-    return with_row_shape(e, [&](auto SHc) {
-      using SH = decltype(SHc);
-      return with_sk(e->static_sk, [&](auto SKc) {
-      constexpr bool sk = decltype(SKc)::value;
-        return launch_k(e, LPC_K_ROW_INV, k_rinv_gd_mid_half<SH::nt, SH::em, sk, SPlanArg<typename SH::plan>>, dim3(g.H, e->P), SH::nt,
-                        LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, splan_arg<typename SH::plan>(e->planWh), e->planW.tw,
-                      (const real2*)e->S, e->S2, (const real*)e->Y);
-      });
-    });
+  if (e->mod && e->mod->gd_rows_mid) return e->mod->gd_rows_mid(e);
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;

@@ -8,16 +8,7 @@ int gd_rows_update(Engine* e, const GdScalars& sc, const real* alpha) {
   const PlaneGeom& g = e->g;
   const int nblk = (g.H + 1) / 2;
   const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
-  if (e->rows_half && e->static_rows)
-    return with_row_shape(e, [&](auto SHc) {
-      using SH = decltype(SHc);
-      return with_sk(e->static_sk, [&](auto SKc) {
-      constexpr bool sk = decltype(SKc)::value;
-        return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update_half<SH::nt, SH::em, sk, SPlanArg<typename SH::plan>>, dim3(g.H, e->P), SH::nt,
-                        LPC_ROW_SMEM_BYTES(SH::plan::n, sk), g, splan_arg<typename SH::plan>(e->planWh), e->planW.tw,
-                      (const real2*)e->S2, e->gx, e->gaux, alpha, sc);
-      });
-    });
+  if (e->mod && e->mod->gd_rows_update) return e->mod->gd_rows_update(e, &sc, alpha);
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
       constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
@@ -32,4 +23,10 @@ int gd_rows_update(Engine* e, const GdScalars& sc, const real* alpha) {
     return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update<nt, em, sk, r2>, dim3(nblk, e->P), nt,
                     LPC_ROW_SMEM_BYTES(g.Wp, sk), g, pinv, (const real2*)e->S2, e->gx, e->gaux, alpha, sc);
   });
+}
+
+// the same + the forward row transform of the updated rows (e->S2 -> x, e->S): compile-time half-row plans only
+int gd_rows_update_fwd(Engine* e, const GdScalars& sc, const real* alpha) {
+  if (e->mod && e->mod->gd_rows_update_fwd) return e->mod->gd_rows_update_fwd(e, &sc, alpha);
+  return fail("internal: the update kernel with fused forward rows lives in the plan module");
 }

@@ -764,7 +764,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
                                                        const real2* LPC_RESTRICT phr,
                                                        const real2* LPC_RESTRICT phc,
                                                        FastDiv t2div, real mu1, real mu2, real mu3,
-                                                       real rscale) {
+                                                       real rscale, real sb_outside_scale) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
@@ -793,9 +793,13 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
       if (c0 + j < g.Wc) { h[k] = hb[i * rstep + j]; rd[k] = rb[i * rstep + j]; }   // rd: |G| for now
     }
   }
+  // sb_outside_scale != 0 (AdmmScalars::skipa, single-pass columns only): the rows of SB outside the sensor window were
+  // not re-transformed; they hold rfft(H V row) / Wp from the last inverse row pass, and a = mu1 H V there
+  const real sb_k = sb_outside_scale != (real)0. ? sb_outside_scale : (real)1.;
   auto in = [&](int i, int c) {
     const int j = c < T ? c : c - T;
-    return (c0 + j < g.Wc) ? (c < T ? ba : bb)[i * rstep + j] : make_real2((real)0., (real)0.);
+    const real2 x = (c0 + j < g.Wc) ? (c < T ? ba : bb)[i * rstep + j] : make_real2((real)0., (real)0.);
+    return cscale(x, (c >= T && (unsigned)(i - g.sh) >= (unsigned)g.H) ? sb_k : (real)1.);
   };
   if constexpr (is_static_plan<PL>::value && TWLDS) plan = twiddles_to_lds<NT>(plan, s + PL::n * SBT2, tid);
   if constexpr (is_static_plan<PL>::value)

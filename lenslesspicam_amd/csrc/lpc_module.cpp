@@ -1,0 +1,181 @@
+// lpc_module.cpp -- ONE plan module: the compile-time-plan instantiations (lpc_sfft.h) of the hot-loop kernels for one
+// frame shape, plus their launchers.  Compiled on its own into <libdir>/modules/lpcmod_<key>.so with the -D flags of
+// plan_spec_defines() (lpc_plan.h): by build.py for BASELINE.json's shapes, by lpc_create() itself (lpc_jit.cpp) for any
+// other shape on first use.  The core library loads it with dlopen and calls the launchers through the LpcModule table;
+// a launcher is the static branch of the core's own launch code (lpc_rows.cpp / lpc_cols.cpp / lpc_gd.cpp) with every
+// plan choice turned into a constant.  Nothing here is shape-specific source: the shape arrives as macros.
+#include "lpc_engine.h"
+#include "lpc_gd_kernels.h"
+
+#ifndef LPC_MOD_FAMILY
+#error "lpc_module.cpp is compiled with the flags of plan_spec_defines() (lpc_plan.h)"
+#endif
+
+// ============================================================================== rows ==
+#if LPC_MOD_ROW_KIND != 0
+typedef SPlan<LPC_MOD_ROW_RAD> RowP;
+typedef SPlanArg<RowP> RowPA;
+static constexpr int RNT = LPC_MOD_ROW_NT, REM = LPC_MOD_ROW_EM;
+static constexpr bool RSK = LPC_MOD_ROW_SK != 0;
+static_assert(!RSK || RowP::skew_ok(), "this row plan does not keep the LDS skew affine");
+static const size_t kRowSmem = LPC_ROW_SMEM_BYTES(RowP::n, RSK);
+#endif
+
+#if LPC_MOD_ROW_KIND == LPC_ROWS_HALF
+static RowPA row_arg(const Engine* e) { return splan_arg<RowP>(e->planWh); }
+
+static int m_rows_fwd_single(Engine* e, const RealSrc* src, real2* S, int nplanes, int kid) {
+  return launch_k(e, kid, k_rfwd_rows_half<RNT, REM, RSK, RowPA>, dim3(src->nrows, nplanes), RNT, kRowSmem, e->g,
+                  row_arg(e), e->planW.tw, *src, S);
+}
+static int m_rows_inv_single(Engine* e, const real2* S, const RealDst* dst, int nplanes, int kid) {
+  return launch_k(e, kid, k_rinv_rows_half<RNT, REM, RSK, RowPA>, dim3(dst->nrows, nplanes), RNT, kRowSmem, e->g,
+                  row_arg(e), e->planW.tw, S, *dst);
+}
+#if LPC_MOD_FAMILY == LPC_FAM_ADMM
+static int m_admm_rows_fwd(Engine* e) {
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_half<RNT, REM, RSK, RowPA>, dim3(2 * g.Hp, e->P), RNT, kRowSmem, g,
+                  row_arg(e), e->planW.tw, (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
+}
+static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outside) {
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  const int hrows = skip_hv_outside ? g.Hp + g.H : 2 * g.Hp;
+  return launch_k(e, LPC_K_ROW_INV, k_rinv_half<RNT, REM, RSK, RowPA>, dim3(hrows, e->P), RNT, kRowSmem, g, row_arg(e),
+                  e->planW.tw, (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
+}
+#if LPC_MOD_ROW_X
+static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  return launch_k(e, LPC_K_ROW_FWD, k_admm_rows_fused<RNT, REM, RSK, 1, 1, RowPA, false>, dim3(2 * g.Hp, e->P), RNT,
+                  kRowSmem, g, *sc, row_arg(e), (const real2*)e->planW.tw, (const real*)nullptr, (const real*)e->Rsp,
+                  (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)nullptr,
+                  (const real*)nullptr, (real*)nullptr, (real*)nullptr, (real*)nullptr, (const real*)e->Y, SA, SB);
+}
+#endif
+#else   // gradient-descent family
+static int m_gd_rows_mid(Engine* e) {
+  const PlaneGeom& g = e->g;
+  return launch_k(e, LPC_K_ROW_INV, k_rinv_gd_mid_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem, g,
+                  row_arg(e), e->planW.tw, (const real2*)e->S, e->S2, (const real*)e->Y);
+}
+static int m_gd_rows_update(Engine* e, const GdScalars* sc, const real* alpha) {
+  const PlaneGeom& g = e->g;
+  return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem, g,
+                  row_arg(e), e->planW.tw, (const real2*)e->S2, e->gx, e->gaux, alpha, *sc);
+}
+static int m_gd_rows_update_fwd(Engine* e, const GdScalars* sc, const real* alpha) {
+  const PlaneGeom& g = e->g;
+  return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update_fwd_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem, g,
+                  row_arg(e), e->planW.tw, (const real2*)e->S2, e->S, e->gx, e->gaux, alpha, *sc);
+}
+#endif
+#endif   // half rows
+
+#if LPC_MOD_ROW_KIND == LPC_ROWS_PAIRED   // ADMM only: two real rows per complex transform of length Wp
+static RowPA row_arg(const Engine* e) { return splan_arg<RowP>(e->planW); }
+
+static int m_admm_rows_fwd(Engine* e) {
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<RNT, REM, RSK, false, RowPA>, dim3(g.Hp, e->P), RNT, kRowSmem, g,
+                  row_arg(e), (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
+}
+static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outside) {
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  const int irows = skip_hv_outside ? g.H + outside_pair_count(g) : g.Hp;
+  return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<RNT, REM, RSK, false, RowPA>, dim3(irows, e->P), RNT, kRowSmem, g,
+                  row_arg(e), (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
+}
+#if LPC_MOD_ROW_X
+static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  // sc->skipa: the window rows as usual + the rows of r_sp outside it two per transform
+  const int xrows = sc->skipa ? g.H + outside_pair_count(g) : g.Hp;
+  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA>, dim3(xrows, e->P), RNT, kRowSmem, g, *sc,
+                  row_arg(e), (const real*)e->Rsp, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1],
+                  e->xi, (const real*)e->Y, SA, SB);
+}
+#endif
+#endif   // paired rows
+
+// ============================================================================ pass A ==
+#if LPC_MOD_PASSA
+typedef SPlan<LPC_MOD_PASSA_RAD> PassAP;
+typedef SPlanArg<PassAP> PassAPA;
+// cp: the engine's pass-A descriptor with this call's mode, zero rows and scale already set (cols_passA)
+static int m_cols_passA(Engine* e, const ColPass* cp, real2* S, int nplanes, int inverse, int kid) {
+  constexpr int NT = LPC_MOD_PASSA_NT, EM = LPC_MOD_PASSA_EM, T = LPC_MOD_PASSA_T;
+  const dim3 grid(cp->G * cp->ntile_c, nplanes);
+  const size_t smem = (size_t)PassAP::n * (T + 2) * sizeof(real2);   // tile + the plan's and the four-step twiddles
+  const PassAPA pa = splan_arg<PassAP>(e->planA);
+  if (inverse) return launch_k(e, kid, k_cols<NT, EM, true, PassAPA, T, true>, grid, NT, smem, e->g, pa, *cp, S);
+  return launch_k(e, kid, k_cols<NT, EM, false, PassAPA, T, true>, grid, NT, smem, e->g, pa, *cp, S);
+}
+#endif
+
+// ============================================================ ADMM fused middle (LDS) ==
+#if LPC_MOD_MID_KIND != 0
+typedef SPlan<LPC_MOD_MID_RAD> MidP;
+typedef SPlanArg<MidP> MidPA;
+static int m_admm_mid(Engine* e, const ColPass* cp, const AdmmScalars* sc, real sb_outside_scale) {
+  constexpr int NT = LPC_MOD_MID_NT, EM = LPC_MOD_MID_EM, T = LPC_MOD_MID_T;
+  const PlaneGeom& g = e->g;
+  real2* SA = e->S;
+  real2* SB = e->S + (size_t)e->P * g.cplane;
+  const MidPA pa = splan_arg<MidP>(e->planB);
+  const real rscale = (real)1.0 / ((real)g.Hp * (real)g.Wp);
+#if LPC_MOD_MID_KIND == LPC_MID_SEQ     // single-pass columns, one spectrum at a time through T columns
+  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, true>,
+                  dim3(cp->G * cp->ntile_c, e->P), NT, (size_t)MidP::n * (T + 1) * sizeof(real2), g, pa, *cp, SA, SB,
+                  (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, sc->mu1,
+                  sc->mu2, sc->mu3, rscale, sb_outside_scale);
+#else                                   // both spectra side by side: [N][2 T]
+  const FastDiv t2 = make_fastdiv((unsigned)(2 * T));
+  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<NT, EM, MidPA, 2 * T, true>, dim3(cp->G * cp->ntile_c, e->P), NT,
+                  (size_t)MidP::n * (2 * T + 1) * sizeof(real2), g, pa, *cp, SA, SB, (const real2*)e->Hs,
+                  (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2, sc->mu1, sc->mu2, sc->mu3,
+                  rscale, sb_outside_scale);
+#endif
+}
+#endif
+
+// ================================================================================ table ==
+extern "C" int lpc_module_init(LpcModule* m, size_t engine_size, const char* src_fp) {
+  if (!m || engine_size != sizeof(Engine) || !src_fp || std::strcmp(src_fp, LPC_SRC_FP) != 0) return 1;
+  std::memset((void*)m, 0, sizeof(*m));
+#if LPC_MOD_ROW_KIND == LPC_ROWS_HALF
+  m->rows_fwd_single = m_rows_fwd_single;
+  m->rows_inv_single = m_rows_inv_single;
+#endif
+#if LPC_MOD_ROW_KIND != 0 && LPC_MOD_FAMILY == LPC_FAM_ADMM
+  m->admm_rows_fwd = m_admm_rows_fwd;
+  m->admm_rows_inv = m_admm_rows_inv;
+#if LPC_MOD_ROW_X
+  m->admm_rows_fwd_x = m_admm_rows_fwd_x;
+#endif
+#endif
+#if LPC_MOD_ROW_KIND == LPC_ROWS_HALF && LPC_MOD_FAMILY == LPC_FAM_GD
+  m->gd_rows_mid = m_gd_rows_mid;
+  m->gd_rows_update = m_gd_rows_update;
+  m->gd_rows_update_fwd = m_gd_rows_update_fwd;
+#endif
+#if LPC_MOD_PASSA
+  m->cols_passA = m_cols_passA;
+#endif
+#if LPC_MOD_MID_KIND != 0
+  m->admm_mid = m_admm_mid;
+#endif
+  return 0;
+}

@@ -92,6 +92,9 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
         self._psf_shape = np.array(psf.shape)
         self._pad = pad
         self._norm = kwargs.get("norm", "ortho")
+        # launch-plan options of the native engine (include/lpc.h, lpc_config.options): a dict or "k=v,k=v" string --
+        # additive to the reference's keywords, which swallow unknown ones anyway (recon.py:203-213)
+        self._engine_options = kwargs.get("engine_options", None)
         self._handle = None
         self._handle_batch = None
         self._data = None
@@ -119,7 +122,8 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
     def _new_handle(self, batch):
         D, H, W, C = (int(v) for v in self._psf_dev.shape)
         return self._lib.create(algo=self._ALGO, height=H, width=W, channels=C, depth=D, batch=int(batch),
-                                norm=_native.NORM[self._norm], pad=int(bool(self._pad)), **self._config())
+                                norm=_native.NORM[self._norm], pad=int(bool(self._pad)), options=self._engine_options,
+                                **self._config())
 
     def _ensure_handle(self, batch):
         if self._handle_batch != batch:

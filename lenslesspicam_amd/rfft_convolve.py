@@ -28,6 +28,7 @@ class RealFFTConvolve2D(_Boundary):
         self.norm = norm
         self.dtype = self._tdtype if self.is_torch else (np.float64 if self._real == "float64" else np.float32)
         self.pad = pad
+        self._engine_options = kwargs.get("engine_options", None)    # launch-plan options (include/lpc.h)
         self._handle = None
         self._handle_batch = 0
         self.set_psf(psf)
@@ -55,7 +56,8 @@ class RealFFTConvolve2D(_Boundary):
         if self._handle is not None:
             self._handle.close()
         self._handle = self._lib.create(algo=_native.ALGO_CONV, height=H, width=W, channels=C, depth=D,
-                                        batch=int(batch), norm=_native.NORM[self.norm], pad=int(bool(self.pad)))
+                                        batch=int(batch), norm=_native.NORM[self.norm], pad=int(bool(self.pad)),
+                                        options=self._engine_options)
         self._handle_batch = int(batch)
         self._handle.set_psf(self._psf_dev.data_ptr(), self._stream())
 

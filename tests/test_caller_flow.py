@@ -203,9 +203,11 @@ def test_momentum_override_survives_batch_change(backend):
         assert rel(got[b], o.apply(5, reset=False)) <= 5e-6
 
 
-def test_apply_display_loop_golden_fused_rows(backend, monkeypatch, tmp_path):
-    """The same vectors through the 12-MP code path (half-length rows with the image-domain kernel fused into them):
-    the clamped copies of the estimate that the W-update sees after a read-out travel through k_admm_rows_fused."""
-    monkeypatch.setenv("LPC_ROWS_HALF", "1")
-    monkeypatch.setenv("LPC_FUSE_ROWS", "1")
+def test_apply_display_loop_golden_plan_module(backend, monkeypatch, tmp_path):
+    """The same vectors through the 12-MP code path (half-length rows from a plan module, the X half of the
+    image-domain work inside the forward rows): the clamped copies of the estimate that the W-update sees after a
+    read-out travel through the tiled TV / W kernel, the xi window structure through the read-outs in between."""
+    from lenslesspicam_amd import _native
+
+    monkeypatch.setattr(_native, "DEFAULT_OPTIONS", {"rows_half": 1, "jit_min_points": 0})
     test_apply_display_loop_golden(backend, tmp_path)

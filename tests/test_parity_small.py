@@ -23,6 +23,15 @@ from oracle import lensless_oracle as orc
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
 
 
+def engine_opts(monkeypatch, **kw):
+    """Launch-plan options (include/lpc.h, lpc_config.options) for every solver built during this test: the package's
+    default-options table is patched, the process environment is never touched."""
+    from lenslesspicam_amd import _native
+
+    new = {**_native.DEFAULT_OPTIONS, **kw}
+    monkeypatch.setattr(_native, "DEFAULT_OPTIONS", {k: v for k, v in new.items() if v is not None})
+
+
 def rel(a, b):
     if isinstance(a, torch.Tensor):
         a = a.detach().cpu().numpy()
@@ -289,9 +298,9 @@ def test_forced_four_step_column_split(backend, monkeypatch, h, hp, n2):
     tuning knobs force them on ~100-row padded frames so that the CPU suite executes those kernels too:
     every pass-B length that has a register-resident middle (48, 40, 36, 32, 30, 24) and one that takes the
     LDS middle (12)."""
-    monkeypatch.setenv("LPC_TILE_BUDGET", "512")
-    monkeypatch.setenv("LPC_COL_T", "4")
-    monkeypatch.setenv("LPC_SPLIT_N2", str(n2))
+    engine_opts(monkeypatch, tile_budget=512)
+    engine_opts(monkeypatch, col_t=4)
+    engine_opts(monkeypatch, split_n2=int(n2))
     psf = orc.synthetic_psf(1, h, 20, 3, seed=8)
     y = np.random.default_rng(8).random((h, 20, 3), dtype=np.float32)
     rec = lpa.ADMM(torch.from_numpy(psf), tau=2e-6, mu2=1e-4)
@@ -310,18 +319,15 @@ def test_forced_four_step_column_split(backend, monkeypatch, h, hp, n2):
     assert rel(conv.deconvolve(x), of.conv.deconvolve(x)) <= 2e-6
 
 
-@pytest.mark.parametrize("fused", [True, False], ids=["fused", "unfused"])
+@pytest.mark.parametrize("static", [False, True], ids=["runtime_plan", "plan_module"])
 @pytest.mark.parametrize("name", ["admm_24x32x3_tv", "admm_47x29x3_tv", "admm_24x32x3_init_bg", "admm_24x32x3_default"])
-def test_admm_half_length_row_kernels(backend, monkeypatch, name, fused):
-    """ADMM's row passes switch to one real row per half-length complex transform for wide frames only;
-    LPC_ROWS_HALF forces them on the golden-vector sizes (row transforms of 32 and 30 points, the second one without
-    the LDS skew): same trajectory checks as the regular golden test.  `fused`: the image-domain kernel computes the
-    rows of r_sp and a inside the forward row workgroups (k_admm_rows_fused, opt-in with LPC_FUSE_ROWS: measured slower
-    than the stand-alone pair once the rows run on compile-time plans); otherwise the stand-alone kernels
-    (k_admm_spatial_v4 + k_rfwd_half), the 12-MP default."""
-    monkeypatch.setenv("LPC_ROWS_HALF", "1")
-    if fused:
-        monkeypatch.setenv("LPC_FUSE_ROWS", "1")
+def test_admm_half_length_row_kernels(backend, monkeypatch, name, static):
+    """ADMM's row passes switch to one real row per half-length complex transform for wide frames only; the option
+    rows_half=1 forces them on the golden-vector sizes (row transforms of 32 and 30 points, the second one without the
+    LDS skew): same trajectory checks as the regular golden test.  `static`: the same frames through a plan module
+    compiled for them (jit_min_points=0) -- 47x29 pads to 60 columns, not a multiple of 4, so its module keeps the
+    stand-alone image-domain kernel; 24x32 runs the X half inside the forward rows."""
+    engine_opts(monkeypatch, rows_half=1, jit_min_points=0 if static else None)
     test_admm_matches_reference_golden(backend, name)
 
 
@@ -331,28 +337,25 @@ def test_gd_family_half_length_row_kernels(backend, monkeypatch, name):
     """Same for the gradient-descent family: pad-on-load forward rows, the irfft -> residual -> rfft kernel and the
     fused update, each with one real row per half-length transform (k_rfwd_rows_half, k_rinv_gd_mid_half,
     k_rinv_gd_update_half), float32 and float64, depth 3, 32- and 30-point row transforms."""
-    monkeypatch.setenv("LPC_ROWS_HALF", "1")
+    engine_opts(monkeypatch, rows_half=1)
     test_gd_family_matches_reference_golden(backend, name)
 
 
 def test_convolver_half_length_row_kernels(backend, monkeypatch):
-    monkeypatch.setenv("LPC_ROWS_HALF", "1")
+    engine_opts(monkeypatch, rows_half=1)
     for tag in ("a", "b", "c"):
         test_convolver_golden(backend, tag)
     test_convolver_slice_commutes(backend)
 
 
-@pytest.mark.parametrize("fused", [False, True], ids=["standalone", "fused_rows"])
 @pytest.mark.parametrize("static", [True, False], ids=["static_plan", "runtime_plan"])
-def test_8192_column_rows_static_plan(backend, monkeypatch, static, fused):
+def test_8192_column_rows_static_plan(backend, monkeypatch, static):
     """12 MP's ROW shape on a frame with only a few rows: 4096 columns pad to 8192, the half-row transform has 4096
     points = 8.8.8.8, which is served by kernels instantiated on a compile-time plan (lpc_sfft.h) -- ADMM through the
-    fused image-domain + row kernel, the gradient-descent family's residual / update kernels, and the convolver's
-    pad-on-load / crop-on-store rows.  LPC_NO_STATIC runs the same frame through the run-time plan."""
-    if not static:
-        monkeypatch.setenv("LPC_NO_STATIC", "1")
-    if fused:
-        monkeypatch.setenv("LPC_FUSE_ROWS", "1")     # the image-domain kernel inside the forward rows (opt-in)
+    X-half row kernel, the gradient-descent family's residual / update kernels, and the convolver's
+    pad-on-load / crop-on-store rows, all from the frame's plan module.  no_static=1 runs the same frame through the
+    run-time plans."""
+    engine_opts(monkeypatch, jit_min_points=0, no_static=0 if static else 1)
     H, W, C = 3, 4096, 1
     rng = np.random.default_rng(11)
     psf = orc.synthetic_psf(1, H, W, C, seed=4)
@@ -379,9 +382,8 @@ def test_8192_column_rows_static_plan(backend, monkeypatch, static, fused):
 def test_6144_row_columns_static_plan(backend, monkeypatch, static):
     """12 MP's COLUMN shape on a frame only 9 columns wide: 3072 rows pad to 6144 = 128 x 48, 16-column tiles -- pass A
     (128 points = 8.8.2, forward and inverse) and ADMM's fused middle (48 points = 8.6 over both spectra) run on
-    compile-time plans; LPC_NO_STATIC is the same frame on the run-time plans."""
-    if not static:
-        monkeypatch.setenv("LPC_NO_STATIC", "1")
+    compile-time plans; no_static=1 is the same frame on the run-time plans."""
+    engine_opts(monkeypatch, jit_min_points=0, no_static=0 if static else 1)
     H, W, C = 3072, 9, 1
     rng = np.random.default_rng(12)
     psf = orc.synthetic_psf(1, H, W, C, seed=5)
@@ -426,8 +428,7 @@ def test_other_baseline_shapes_static_plans(backend, monkeypatch, static, shape,
     1080p's half rows (1920 = 8.8.6.5; ADMM through the fused image-domain + row kernel), its column split
     2160 = 90 x 24 (pass A 90 = 6.5.3 + the register-resident 24-point middle), and the DiffuserCam-sized frame of
     C1 / C4 in full (single-pass 540-point ADMM middle = 6.6.5.3 over 2 x 8 tile columns, paired 960-point rows)."""
-    if not static:
-        monkeypatch.setenv("LPC_NO_STATIC", "1")
+    engine_opts(monkeypatch, jit_min_points=0, no_static=0 if static else 1)
     _admm_fista_vs_oracle(*shape, padded, n_admm=2 if shape[0] == 270 else 3, n_fista=2 if shape[0] == 270 else 3)
     psf = orc.synthetic_psf(1, *shape, seed=1)
     info = lpa.ADMM(torch.from_numpy(psf))._handle.plan_info() + " | " + lpa.FISTA(torch.from_numpy(psf))._handle.plan_info()
@@ -439,8 +440,11 @@ def test_xi_outside_the_sensor_window(backend, monkeypatch, shape):
     """Outside the sensor window X_divmat = 1/mu1, so a = mu1 X - xi = mu1 HV and xi' = mu1 (HV' - HV): the X half
     of the forward rows skips xi / HV_old there on all but the last iteration of a call (AdmmScalars::xiw).  Every
     read-out between calls must still see the reference's xi and X on the WHOLE padded frame, multi-iteration calls
-    must equal single-iteration calls, and the image must stay on the full-xi path's (LPC_XI_FULL) to round-off."""
+    must equal single-iteration calls, and the image must stay on the full-xi path's (option xi_full) to round-off."""
     H, W, C = shape
+    # (hv_full: the H V row transforms run on every row, so that calls of any length are the same instruction stream;
+    # the plan that also skips those outside the window is compared at the end and in the next test)
+    engine_opts(monkeypatch, jit_min_points=0, hv_full=1)
     rng = np.random.default_rng(8)
     psf = orc.synthetic_psf(1, H, W, C, seed=8)
     y = rng.random((H, W, C), dtype=np.float32)
@@ -471,9 +475,13 @@ def test_xi_outside_the_sensor_window(backend, monkeypatch, shape):
     outside = np.ones(xi4.shape[1:3], bool)
     outside[sh:sh + H, sw:sw + W] = False
     assert np.abs(xi4[0][outside]).max() > 0          # the dual is alive out there, not just zeros
-    monkeypatch.setenv("LPC_XI_FULL", "1")
+    engine_opts(monkeypatch, xi_full=1)
     _, xif, xf, vf = run([4])
     assert rel(vf, v4) <= 2e-6 and np.abs(xif - xi4).max() <= 2e-5 * scale
+    engine_opts(monkeypatch, xi_full=None, hv_full=None)           # the default plan
+    recd, xid, xd, vd = run([4])
+    assert "row transforms skipped" in recd._handle.plan_info()
+    assert rel(vd, v4) <= 2e-6 and rel(xd, x4) <= 2e-6 and np.abs(xid - xi4).max() <= 2e-5 * scale
 
 
 @pytest.mark.parametrize("kind", ["half_rows_split_columns", "paired_rows_c4"])
@@ -487,13 +495,12 @@ def test_hv_rows_outside_the_sensor_window_are_skipped(backend, monkeypatch, kin
         # C4's shape for ONE frame: 960-point paired rows (the rows of r_sp / V outside the window ride two per
         # transform: 135 rows above and below = 67 pairs + one single each), sequential 540-point middle rescaling SB
         H, W, C = 270, 480, 1
-        monkeypatch.setenv("LPC_MID_SEQ", "1")
-        monkeypatch.setenv("LPC_PROW_NT128", "1")
+        engine_opts(monkeypatch, mid_seq=1)
+        engine_opts(monkeypatch, prow_nt128=1)
         runs = ([2], [5], [4, 1, 5])
     else:
         H, W, C = 12, 1014, 1       # 24 x 2048 padded: half rows of 1024 points (compile-time plan), columns split
-        monkeypatch.setenv("LPC_ROWS_HALF", "1")
-        monkeypatch.setenv("LPC_TILE_BUDGET", "256")
+        engine_opts(monkeypatch, rows_half=1, tile_budget=256, jit_min_points=0)
         runs = ([2], [4], [5], [9], [6, 1, 5])
     rng = np.random.default_rng(11)
     psf = orc.synthetic_psf(1, H, W, C, seed=11)
@@ -524,19 +531,18 @@ def test_hv_rows_outside_the_sensor_window_are_skipped(backend, monkeypatch, kin
             assert rel(np.asarray(getattr(rec, attr)), ref.numpy()) <= tol, (steps, attr)
         scale = float(np.abs(o.xi.numpy()).max())
         assert np.abs(np.asarray(rec._xi) - o.xi.numpy()).max() <= 5e-5 * scale, steps
-    monkeypatch.setenv("LPC_HV_FULL", "1")
+    engine_opts(monkeypatch, hv_full=1)
     full = engine([6])
-    monkeypatch.delenv("LPC_HV_FULL")
+    engine_opts(monkeypatch, hv_full=None)
     assert rel(np.asarray(engine([6])._image_est), np.asarray(full._image_est)) <= 2e-6
 
 
 def test_window_structure_with_a_per_iteration_schedule(backend, monkeypatch):
     """Unrolled ADMM changes mu1 from one iteration to the next: outside the sensor window a = mu1_k HV uses THIS
     iteration's step size and the stored xi = mu1_{k-1} (HV - HV_old) the previous one's.  The window-aware launch plan
-    must agree with the plan that keeps xi and H V whole (LPC_XI_FULL, LPC_HV_FULL), for a batch of two frames."""
+    must agree with the plan that keeps xi and H V whole (options xi_full, hv_full), for a batch of two frames."""
     H, W, C, n_iter = 12, 1014, 1, 7
-    monkeypatch.setenv("LPC_ROWS_HALF", "1")
-    monkeypatch.setenv("LPC_TILE_BUDGET", "256")
+    engine_opts(monkeypatch, rows_half=1, tile_budget=256, jit_min_points=0)
     rng = np.random.default_rng(17)
     psf = torch.from_numpy(orc.synthetic_psf(1, H, W, C, seed=17))
     batch = torch.from_numpy(rng.random((2, 1, H, W, C), dtype=np.float32))
@@ -550,8 +556,8 @@ def test_window_structure_with_a_per_iteration_schedule(backend, monkeypatch):
 
     out, info = run()
     assert "H V row transforms skipped" in info, info
-    monkeypatch.setenv("LPC_XI_FULL", "1")
-    monkeypatch.setenv("LPC_HV_FULL", "1")
+    engine_opts(monkeypatch, xi_full=1)
+    engine_opts(monkeypatch, hv_full=1)
     ref, info_full = run()
     assert "xi inside the sensor window" not in info_full
     assert float(ref.abs().max()) > 0 and rel(out, ref) <= 2e-6
@@ -559,9 +565,9 @@ def test_window_structure_with_a_per_iteration_schedule(backend, monkeypatch):
 
 def test_c4_sequential_middle_on_one_frame(backend, monkeypatch):
     """C4's fused ADMM middle takes the two spectra one after the other through a 16-column tile
-    (k_cols_mid_admm_seq); the engine selects it for large batches only, LPC_MID_SEQ forces it onto one
+    (k_cols_mid_admm_seq); the engine selects it for large batches only, the option mid_seq=1 forces it onto one
     DiffuserCam-sized frame so that the CPU suite executes it.  Batches must equal single-frame runs either way."""
-    monkeypatch.setenv("LPC_MID_SEQ", "1")
+    engine_opts(monkeypatch, mid_seq=1)
     _admm_fista_vs_oracle(270, 480, 1, (540, 960), n_admm=2, n_fista=1)
     psf = orc.synthetic_psf(1, 270, 480, 1, seed=1)
     assert "T = 16" in lpa.ADMM(torch.from_numpy(psf))._handle.plan_info()
@@ -569,30 +575,29 @@ def test_c4_sequential_middle_on_one_frame(backend, monkeypatch):
 
 def test_c4_rows_on_128_threads(backend, monkeypatch):
     """960-point paired rows of a large batch run on 128 threads x 8 points (every lane owns one radix-8 butterfly of
-    the fused first stage); LPC_PROW_NT128 forces that shape onto one frame.  Same plan, same arithmetic: the result
+    the fused first stage); the option prow_nt128 forces that shape onto one frame.  Same plan, same arithmetic: the result
     must be bitwise the one of the 256-thread kernels."""
     rng = np.random.default_rng(5)
     psf = torch.from_numpy(orc.synthetic_psf(1, 270, 480, 1, seed=1))
     y = torch.from_numpy(rng.random((270, 480, 1), dtype=np.float32))
     outs = []
-    for knob in ("LPC_PROW_NT256", "LPC_PROW_NT128"):
-        monkeypatch.setenv(knob, "1")
-        rec = lpa.ADMM(psf)
+    for nt128 in (0, 1):
+        rec = lpa.ADMM(psf, engine_options={"prow_nt128": nt128})
+        assert f"{128 if nt128 else 256} threads" in rec._handle.plan_info()
         rec.set_data(y)
         outs.append(rec.apply(n_iter=3, disp_iter=None, plot=False))
-        monkeypatch.delenv(knob)
     assert torch.equal(outs[0], outs[1])
-    monkeypatch.setenv("LPC_PROW_NT128", "1")
+    engine_opts(monkeypatch, prow_nt128=1)
     _admm_fista_vs_oracle(270, 480, 1, (540, 960), n_admm=2, n_fista=1)
 
 
 @pytest.mark.parametrize("shape,padded", [((3072, 20, 1), (6144, 40)), ((1080, 20, 1), (2160, 40)), ((760, 20, 1), (1536, 40))],
                          ids=["passA128", "passA90", "passA64"])
 def test_pass_a_32_column_tiles(backend, monkeypatch, shape, padded):
-    """Wide frames run pass A (compile-time plans) on 32-column tiles while the fused middle keeps 16; LPC_PASSA_T32
+    """Wide frames run pass A (compile-time plans) on 32-column tiles while the fused middle keeps 16; the option passa_t=32
     forces that split tiling onto frames only 21 spectrum columns wide (one partly filled pass-A tile, two middle
     tiles)."""
-    monkeypatch.setenv("LPC_PASSA_T32", "1")
+    engine_opts(monkeypatch, passa_t=32, jit_min_points=0)
     _admm_fista_vs_oracle(*shape, padded, n_admm=2, n_fista=2)
 
 
@@ -618,7 +623,7 @@ def test_gd_update_with_fused_forward_rows(backend, monkeypatch, kind, cls):
     assert rel(got, o.apply(5)) <= 5e-6
     got2 = rec.apply(n_iter=4, disp_iter=None)            # reset: the cached spectra of the old iterate are dropped
     assert rel(got2, o.apply(4)) <= 5e-6
-    monkeypatch.setenv("LPC_GD_NO_FUSE_FWD", "1")
+    engine_opts(monkeypatch, gd_no_fuse_fwd=1)
     plain = cls(torch.from_numpy(psf))
     plain.set_data(torch.from_numpy(y))
     assert rel(plain.apply(n_iter=4, disp_iter=None), got2) <= 1e-6
