@@ -16,12 +16,17 @@ path would do when a batch is sharded over the node.  value = total iterations o
 max-over-ranks wall time.
 
 Rank 0 prints ONE JSON line.  On top of the driver's contract it carries:
-  roofline      fused ADMM prox/update kernel: algorithmic bytes (15R + R0)
-                / mean launch duration from HIP events recorded inside the timed region
+  roofline      ADMM prox / dual-update kernel (the TV / W half of the image-domain work, 9R per launch: reads V,
+                V_old, eta0, eta1, rho, writes eta0, eta1, rho, r_sp -- DESIGN.md section 4; the X half rides in the
+                forward row kernel, listed under `kernels`) / mean launch duration from HIP events recorded inside the
+                timed region; `traffic` = HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/traffic.json)
+  kernels       every kernel of the iteration: mean ms, algorithmic GB, GB/s, and the PMC traffic / algorithmic ratio
   cpu_baseline  the CPU oracle (torch-CPU float32 restatement of the reference, kind "port")
                 timed on this host for a bounded sample of the same workload
-  parity        engine vs oracle after the sampled iterations at full size, and the PSNR delta
-                after 100 iterations on the 270x480x3 DiffuserCam-sized frame (configs[0] size)
+  parity        full size (12 MP): engine vs the float32 oracle after >= 30 iterations (default AND TV-active
+                parameters; the oracle keeps stepping after the baseline sample, inside a time budget), vs the float64
+                oracle after 5, and the 100-iteration call vs the float64 build of the engine; plus the PSNR delta after
+                100 iterations on the 270x480x3 DiffuserCam-sized frame (configs[0] size)
 """
 import argparse
 import json
@@ -58,15 +63,22 @@ def parse():
     ap.add_argument("--algo", default="admm", choices=["admm", "fista"])
     ap.add_argument("--dtype", default="float32", choices=["float32", "float64"],
                     help="float64 runs the second build of the engine (liblpc_f64.so); the headline metric is float32")
-    ap.add_argument("--config", default="c2", choices=["c2", "c4"],
+    ap.add_argument("--config", default="c2", choices=["c2", "c4", "c5-planes"],
                     help="c2 (default, the headline metric): one 12-MP frame per GPU.  c4: BASELINE config 4, a "
                          "batch of 64 DiffuserCam frames (270x480x3) block-sharded over the ranks, ADMM 20 it, one "
-                         "all-gather (strong scaling; reported separately, never as the headline value)")
+                         "all-gather (strong scaling; reported separately, never as the headline value).  c5-planes: "
+                         "BASELINE config 5, ONE frame against a 16-plane depth stack, its 48 (plane, channel) units "
+                         "sharded over the ranks (PlaneShardedReconstructor), one all-gather (strong scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=3,
                     help="timed CPU-oracle iterations (SURVEY 8d: >= 3); two more are spent choosing the thread count")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--parity-iters", type=int, default=5)
+    ap.add_argument("--parity-iters", type=int, default=5, help="float64-oracle iterations at full size")
+    ap.add_argument("--parity-long-iters", type=int, default=30,
+                    help="float32-oracle iterations at full size the engine is compared after (per parameter set)")
+    ap.add_argument("--parity-budget-s", type=float, default=330.0,
+                    help="host seconds the float32 oracle may spend stepping towards --parity-long-iters, per parameter "
+                         "set; it stops early when the budget is spent and the comparison is made at the count reached")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short C1 / C3 / C4 / C5 legs reported under 'other_configs'")
     return ap.parse_args()

@@ -121,6 +121,12 @@ int lpc_set_psf(lpc_handle h, const lpc_real* dev_psf, void* stream);
 int lpc_convolve(lpc_handle h, const lpc_real* dev_x, lpc_real* dev_out, int n, int x_channels, int adjoint,
                  void* stream);
 
+/* convolve / deconvolve with return_fft=True (rfft_convolve.py:148-150,161-163,193-195,206-208): the spectrum
+ * rfft2(pad?(x)) * H (adjoint: * conj(H)) the reference returns instead of transforming back.  dev_out: complex values
+ * as (re, im) pairs of lpc_real, (n, D, Hp, Wp/2+1, C), natural frequency order like rfft2's.  LPC_ALGO_CONV handles. */
+int lpc_convolve_spectrum(lpc_handle h, const lpc_real* dev_x, lpc_real* dev_out, int n, int x_channels, int adjoint,
+                          void* stream);
+
 /* ---- solver state: set_data / _set_initial_estimate / reset ------------------------ */
 /* dev_data: (B,H,W,data_channels) with B == cfg.batch; data_channels is C, or 1 (broadcast over the PSF's channels,
  * as `self._convolver._pad(self._data)` does, admm.py:253 / `- self._data`, gd.py:129).  recon.py:352-381 */

@@ -96,6 +96,7 @@ class Lib:
             "lpc_padded_shape": [vp, ip, ip, ip, ip],
             "lpc_set_psf": [vp, fp, vp],
             "lpc_convolve": [vp, fp, fp, C.c_int, C.c_int, C.c_int, vp],
+            "lpc_convolve_spectrum": [vp, fp, fp, C.c_int, C.c_int, C.c_int, vp],
             "lpc_set_data": [vp, fp, C.c_int, vp],
             "lpc_set_initial_estimate": [vp, fp, vp],
             "lpc_reset": [vp, vp],
@@ -212,6 +213,9 @@ class Handle:
 
     def convolve(self, x_ptr, out_ptr, n, x_channels, adjoint, stream=0):
         self._c(self.lib.dll.lpc_convolve(self.h, x_ptr, out_ptr, n, int(x_channels), int(adjoint), stream))
+
+    def convolve_spectrum(self, x_ptr, out_ptr, n, x_channels, adjoint, stream=0):
+        self._c(self.lib.dll.lpc_convolve_spectrum(self.h, x_ptr, out_ptr, n, int(x_channels), int(adjoint), stream))
 
     def set_data(self, ptr, channels, stream=0):
         self._c(self.lib.dll.lpc_set_data(self.h, ptr, int(channels), stream))

@@ -70,7 +70,13 @@ class ADMM(ReconstructionAlgorithm):
         gram = self._custom_psi[2](self._padded_shape)
         gabs = torch.abs(gram if isinstance(gram, torch.Tensor) else torch.from_numpy(np.asarray(gram)))
         D, Hp, Wp, C = self._padded_shape
-        assert tuple(gabs.shape) == (D, Hp, Wp // 2 + 1, C), f"psi_gram must return the rfft2 spectrum, got {tuple(gabs.shape)}"
+        # the reference only needs the gram to broadcast inside R_divmat (admm.py:186-190): (1,Hp,Wc,1) is as good as the
+        # full (D,Hp,Wc,C); the engine keeps ONE plane, so a gram that differs between planes / channels is refused
+        try:
+            gabs = torch.broadcast_to(gabs, (D, Hp, Wp // 2 + 1, C))
+        except RuntimeError:
+            raise AssertionError(f"psi_gram must broadcast to the rfft2 spectrum {(D, Hp, Wp // 2 + 1, C)}, "
+                                 f"got {tuple(gabs.shape)}") from None
         plane = gabs[0, :, :, 0]
         if not torch.allclose(gabs, plane[None, :, :, None].expand_as(gabs), rtol=1e-6, atol=0):
             raise NotImplementedError("psi_gram must be the same for every depth plane and channel")

@@ -555,6 +555,7 @@ static int admm_iterate(Engine* e, int n_iter) {
   constexpr int TH4X = 4;
   const dim3 k1_grid4x(tiles_x4 * ((g.Hp + TH4X - 1) / TH4X), e->P, 1);
   const size_t k1_smem4x = (size_t)2 * (TH4X + 2) * (TW4 + 8) * sizeof(real);
+  bool sb_rows_valid = false;   // AdmmScalars::skipa may rely on the rows of SB only after a step of this very call
   for (int it = 0; it < n_iter; ++it) {
     real* Vc = e->V[e->vcur];
     real* Vo = e->V[e->vcur ^ 1];
@@ -562,11 +563,11 @@ static int admm_iterate(Engine* e, int n_iter) {
     admm_params(e, e->iters_done, par);
     AdmmScalars sc = admm_scalars(e, par);
     sc.xi_store = (it + 1 == n_iter || !sc.xiw) ? 1 : 0;
-    // rows wholly outside the sensor window: from the second iteration of a call on, SB still holds their row spectra
-    // (nothing else touches the work spectrum inside this loop); the last iteration runs complete (it stores xi out
-    // there), and the last three write H V there: xi = mu1p (HV - HV_old) of the final X half and every read-out after
-    // the call need HV_{n-2}, HV_{n-1}, HV_n whole
-    sc.skipa = (e->hv_skip && it > 0 && !sc.xi_store) ? 1 : 0;
+    // rows wholly outside the sensor window: once an iteration of THIS call has run, SB still holds their row spectra
+    // (sb_rows_valid: set below, local to the call -- no other entry point can have touched the work spectrum in
+    // between); the last iteration runs complete (it stores xi out there), and the last three write H V there:
+    // xi = mu1p (HV - HV_old) of the final X half and every read-out after the call need HV_{n-2}, HV_{n-1}, HV_n whole
+    sc.skipa = (e->hv_skip && sb_rows_valid && !sc.xi_store) ? 1 : 0;
     sc.skiphv = (e->hv_skip && it + 3 < n_iter) ? 1 : 0;
 #ifndef LPC_DOUBLE
     if (vec4 && e->xhalf_rows)
@@ -594,6 +595,7 @@ static int admm_iterate(Engine* e, int n_iter) {
     LPC_OK(admm_spectral_step(e, sc, Vo, e->HVb[e->hcur ^ 1], vec4 && e->xhalf_rows));
     e->vcur ^= 1;  // Vo now holds the new image estimate
     e->hcur ^= 1;  // ... and the other H V buffer its forward model
+    sb_rows_valid = true;   // the inverse column passes of this step left rfft(H V row) / Wp in every row of SB
     for (int k = 0; k < 4; ++k) e->last_par[k] = par[k];
     ++e->iters_done;
   }
@@ -743,6 +745,28 @@ int lpc_convolve(lpc_handle e, const real* dev_x, real* dev_out, int n, int x_ch
     LPC_OK(planar_to_hwc(e, xout, dev_out, nimg, g.H, g.W, g.W, g.uplane, 0, 0, 0));
   }
   return 0;
+}
+
+int lpc_convolve_spectrum(lpc_handle e, const real* dev_x, real* dev_out, int n, int x_channels, int adjoint,
+                          void* stream) {
+  if (!e || !dev_x || !dev_out) return fail("lpc_convolve_spectrum: null argument");
+  LPC_OK(check_channels(e, x_channels, "lpc_convolve_spectrum"));
+  if (!e->psf_set) return fail("lpc_convolve_spectrum: PSF not set");
+  if (n < 1 || n > e->cfg.batch) return fail("lpc_convolve_spectrum: n exceeds the configured batch");
+  if (e->cfg.algo != LPC_ALGO_CONV) return fail("lpc_convolve_spectrum: handle was not created with LPC_ALGO_CONV");
+  e->stream = (lpcStream_t)stream;
+  const PlaneGeom& g = e->g;
+  const int nplanes = n * g.DC, nimg = n * e->cfg.depth;
+  real* xin = (real*)e->gaux;
+  if (!e->cfg.pad) {
+    LPC_OK(hwc_to_planar(e, dev_x, xin, nimg, g.Hp, g.Wp, g.rpitch, g.rplane, x_channels));
+    LPC_OK(fft2_forward_setup(e, src_padded(e, xin), e->S, nplanes));
+  } else {
+    LPC_OK(hwc_to_planar(e, dev_x, xin, nimg, g.H, g.W, g.W, g.uplane, x_channels));
+    LPC_OK(fft2_forward_setup(e, src_unpadded(e, xin), e->S, nplanes));
+  }
+  return launch_k(e, -1, k_spectrum_mul_to_hwc<256>, grid1d((long)g.Hp * g.Wc * g.C, 256, nimg), 256, 0, g,
+                  (const real2*)e->S, (const real2*)e->Hs, adjoint ? 1 : 0, (real2*)dev_out, e->N1, e->N2);
 }
 
 int lpc_set_data(lpc_handle e, const real* dev_data, int data_channels, void* stream) {

@@ -857,10 +857,18 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   const int tid = threadIdx.x;
   constexpr int T = SBT, N = PL::n, NELEM = N * T, EM = (NELEM + NT - 1) / NT;
   static_assert(EM <= EMAX, "tile does not fit the workgroup shape");
-  const int c0 = (int)blockIdx.x * T;
-  real2* ba = SA + (long)blockIdx.y * g.cplane + c0;
-  real2* bb = SB + (long)blockIdx.y * g.cplane + c0;
-  const real2* hb = Hs + (long)((int)blockIdx.y % g.DC) * g.cplane + c0;
+  // 1-D grid of (column tiles x planes) workgroups, FRAMES FASTEST: all frames of a batch share H and |G|, and block b
+  // runs on XCD b % 8 -- consecutive blocks are the same column tile of the same PSF plane in different frames, so each
+  // XCD's L2 fetches that tile of H / |G| from HBM once and serves it to the frames it owns.  (With the tile index
+  // fastest, the 64 frames of C4 re-read H 64 times: PMC traffic 2.29 GB per launch against 1.60 GB algorithmic.)
+  const int nfr = (int)(gridDim.x / (unsigned)(cp.ntile_c * g.DC));       // frames
+  const int fr = (int)(blockIdx.x % (unsigned)nfr), rest = (int)(blockIdx.x / (unsigned)nfr);
+  const int tile = rest % cp.ntile_c, pp = rest / cp.ntile_c;             // column tile, PSF plane
+  const long pl = (long)fr * g.DC + pp;
+  const int c0 = tile * T;
+  real2* ba = SA + pl * g.cplane + c0;
+  real2* bb = SB + pl * g.cplane + c0;
+  const real2* hb = Hs + (long)pp * g.cplane + c0;
   const real* rb = Gabs + c0;
   const long rstep = g.cpitch;
   const real2 zero = make_real2((real)0., (real)0.);
@@ -1763,6 +1771,27 @@ __global__ __launch_bounds__(NT) void k_permute_spectrum_rows(const real* LPC_RE
     const int prow = (int)(e / Wc), c = (int)(e - (long)prow * Wc);
     const int k = (prow / N2) + N1 * (prow % N2);
     out[(long)prow * cpitch + c] = nat[(long)k * Wc + c];
+  }
+}
+
+// return_fft=True (rfft_convolve.py:148-150,193-195): the engine's work spectrum (planar, permuted row order: stored row
+// p = k1*N2 + k2 holds frequency k1 + N1*k2) times H or conj(H) -> the reference's layout (img, Hp, Wc, C) complex,
+// natural frequency order, channels last.  grid = (blocks over Hp*Wc*C, images).
+template <int NT>
+__global__ __launch_bounds__(NT) void k_spectrum_mul_to_hwc(PlaneGeom g, const real2* LPC_RESTRICT S,
+                                                             const real2* LPC_RESTRICT Hs, int conjH,
+                                                             real2* LPC_RESTRICT out, int N1, int N2) {
+  const long n = (long)g.Hp * g.Wc * g.C;
+  const long img = blockIdx.y;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const int c = (int)(e % g.C);
+    const long kk = e / g.C;
+    const int kc = (int)(kk % g.Wc), kr = (int)(kk / g.Wc);
+    const int p = (kr % N1) * N2 + kr / N1;
+    const long q = img * g.C + c;
+    const long off = (long)p * g.cpitch + kc;
+    const real2 v = S[q * g.cplane + off], h = Hs[(q % g.DC) * g.cplane + off];
+    out[img * n + e] = conjH ? cmul_conj(v, h) : cmul(v, h);
   }
 }
 

@@ -33,14 +33,27 @@ def _world(group):
 class ShardedReconstructor:
     """``algo_cls(psf, **algo_kwargs)`` built ONCE per rank; ``__call__(frames, n_iter)`` reconstructs this
     rank's block of ``frames`` (B,H,W,C) and returns the full (B,D,H,W,C) result on every rank (same kind
-    as ``psf``).  The native handle is re-created only when the local shard size changes."""
+    as ``psf``).  The native handle is re-created only when the local shard size changes.
+
+    No copy rides on the collective: the solver writes its shard straight into the send buffer, and for even shards on
+    the engine's device the result IS the receive buffer -- two of them alternate, so a returned batch stays valid until
+    the call after the next one (the reference's ``apply()`` likewise returns a view of solver state, recon.py:594).
+    ``gather_ms()``: duration of the most recent all-gather (HIP events on the current stream)."""
 
     def __init__(self, algo_cls, psf, group=None, solver=None, **algo_kwargs):
         self.group = group
         self.rec = solver if solver is not None else algo_cls(psf, **algo_kwargs)
         self.psf = psf
         self.is_torch = isinstance(psf, torch.Tensor)
-        self._recv = None
+        self._recv = [None, None]
+        self._turn = 0
+        self._ev = None
+
+    def gather_ms(self):
+        if self._ev is None:
+            return None
+        self._ev[1].synchronize()
+        return float(self._ev[0].elapsed_time(self._ev[1]))
 
     def __call__(self, frames, n_iter):
         rec = self.rec
@@ -49,29 +62,36 @@ class ShardedReconstructor:
         lo, hi = shard_bounds(B, world, rank)
         D, H, W, C = (int(v) for v in self.psf.shape)
         dev = rec._device
-        if hi > lo:
-            rec.set_data(frames[lo:hi][:, None])
-            local = rec.apply_batch(n_iter=n_iter)
-            if not self.is_torch:
-                local = torch.from_numpy(local)
-        else:                                     # more ranks than frames: this rank only takes part in the gather
-            local = torch.empty((0, D, H, W, C), dtype=rec._tdtype)
+        on_dev = self.is_torch and self.psf.device == dev
         if world == 1:
-            return local if self.is_torch else local.numpy()
+            rec.set_data(frames[:, None])
+            return rec.apply_batch(n_iter=n_iter)
         cap = -(-B // world)                      # slot size = largest shard
-        if self._recv is None or tuple(self._recv.shape) != (world * cap, D, H, W, C):
-            self._recv = torch.empty((world * cap, D, H, W, C), dtype=rec._tdtype, device=dev)
+        self._turn ^= 1
+        if self._recv[self._turn] is None or tuple(self._recv[self._turn].shape) != (world * cap, D, H, W, C):
+            self._recv[self._turn] = torch.empty((world * cap, D, H, W, C), dtype=rec._tdtype, device=dev)
             self._send = torch.empty((cap, D, H, W, C), dtype=rec._tdtype, device=dev)
-        send = self._send
-        send[: hi - lo].copy_(local)
-        dist.all_gather_into_tensor(self._recv, send, group=self.group)      # the single collective of the path
+        recv, send = self._recv[self._turn], self._send
+        if hi > lo:                               # (more ranks than frames: such a rank only takes part in the gather)
+            rec.set_data(frames[lo:hi][:, None])
+            if on_dev and hi - lo == cap:
+                rec.apply_batch(n_iter=n_iter, out=send)          # the shard lands in the send buffer
+            else:
+                local = rec.apply_batch(n_iter=n_iter)
+                send[: hi - lo].copy_(local if self.is_torch else torch.from_numpy(local))
+        if dev.type == "cuda":
+            self._ev = self._ev or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            self._ev[0].record()
+        dist.all_gather_into_tensor(recv, send, group=self.group)            # the single collective of the path
+        if dev.type == "cuda":
+            self._ev[1].record()
         if B == world * cap:
-            full = self._recv.clone()             # even shards: the receive buffer already is the batch
+            full = recv                           # even shards: the receive buffer already is the batch
         else:
-            full = torch.cat([self._recv[r * cap: r * cap + (b - a)]
+            full = torch.cat([recv[r * cap: r * cap + (b - a)]
                               for r in range(world) for a, b in [shard_bounds(B, world, r)]], dim=0)
         if self.is_torch:
-            return full.to(self.psf.device)
+            return full.to(self.psf.device)       # (no copy when the PSF lives on the engine's device)
         return full.cpu().numpy()
 
 
@@ -92,11 +112,22 @@ class PlaneShardedReconstructor:
     result equals the un-sharded ``algo_cls(psf).apply()`` bit for bit (tests/test_dist.py).
 
     ``__call__(data, n_iter)``: ``data`` (H, W, C) or (1, H, W, C), same kind as ``psf``; returns (D, H, W, C) on
-    every rank.  Solvers (handle, PSF spectrum, workspace) are built once per unit and kept."""
+    every rank.  Solvers (handle, PSF spectrum, workspace) are built once per unit and kept.  ``algo_kwargs`` must be
+    scalar solver keywords (mu1, tau, n_iter, ...): array-valued ones (``initial_est``) and custom ``psi*`` callables
+    describe the whole frame and raise ``ValueError``."""
 
     def __init__(self, algo_cls, psf, group=None, **algo_kwargs):
         from .admm import ADMM
 
+        # every unit gets a single-plane solver built with **algo_kwargs unchanged: an array-valued keyword describes the
+        # WHOLE frame (initial_est is (D,Hp,Wp,C); a custom psi / psi_gram or a per-channel schedule act on all channels)
+        # and would have to be sliced per (depth, channel) -- refused up front instead of failing inside a sub-solver
+        for k, v in algo_kwargs.items():
+            whole = k in ("psi", "psi_adj", "psi_gram", "initial_est") or \
+                (isinstance(v, (np.ndarray, torch.Tensor)) and v.ndim > 0)
+            if whole and v is not None:
+                raise ValueError(f"PlaneShardedReconstructor: keyword '{k}' describes the whole frame; only scalar "
+                                 "solver keywords can be handed to the per-plane solvers")
         self.group = group
         self.algo_cls = algo_cls
         self.kw = algo_kwargs

@@ -78,10 +78,13 @@ class GradientDescent(ReconstructionAlgorithm):
             assert tuple(projected.shape) == self._state_shape(), "the projection must keep the estimate's shape"
             self._handle.iterate_end(projected.data_ptr(), self._stream())
 
-    def _form_image(self):
+    def _form_image(self, out=None):
         if not self._hook:
-            return super()._form_image()
-        return self._apply_proj(self._image_est)       # the reference projects again on read-out (gd.py:136-140)
+            return super()._form_image(out=out)
+        res = self._apply_proj(self._image_est)         # the reference projects again on read-out (gd.py:136-140)
+        if out is not None:
+            out.copy_(self._to_dev(res))
+        return res
 
     def _config(self):
         return dict(lip_fact=float(self._lip_fact))

@@ -194,9 +194,13 @@ def load_data(psf_fp, data_fp, background_fp=None, return_bg=False, remove_backg
         raw_psf = raw_psf[..., None]
     assert raw_psf.ndim == 4, "a .npy / .npz PSF is a depth stack (D,H,W[,C]) (io.py:315-321)"
     resizing = shape is not None or (downsample is not None and downsample != 1)
+    # load_image(shape=...) resizes the frame BEFORE `img /= img.max()` (io.py:176-190: background, clip, resize,
+    # normalise) -- anti-aliased resampling lowers the maximum, so the order is observable (ADMM is not scale-invariant:
+    # tau).  Without `shape` the frame is normalised at full resolution and only then resized to the PSF (io.py:527-529).
+    late_norm = normalize and shape is not None
     res = preprocess_data(raw_psf, raw_data, bg_pix=bg_pix, flip=flip, flip_ud=flip_ud, flip_lr=flip_lr,
-                          gray=gray and not resizing, single_psf=single_psf, normalize=normalize, bgr_input=bgr_input,
-                          dtype=dtype, return_bg=True)
+                          gray=gray and not resizing, single_psf=single_psf, normalize=normalize and not late_norm,
+                          bgr_input=bgr_input, dtype=dtype, return_bg=True)
     psf, data, bg = res
     if resizing:
         # load_psf resizes between the background removal and the normalisation (io.py:352-375); resampling is linear
@@ -207,7 +211,11 @@ def load_data(psf_fp, data_fp, background_fp=None, return_bg=False, remove_backg
         dt = dtype or "float32"
         psf = resize(psf, factor=None if shape is not None else 1 / downsample, shape=shape, dtype=dt)
         psf = preprocess_psf(psf, bg_pix=None, gray=gray, dtype=dt)
-        # ... and the frame, already normalised, is resized to the PSF's size (io.py:527-529)
+        # ... and the frame: with `shape`, resized to it and normalised afterwards (per frame, on the device); else,
+        # already normalised, resized to the PSF's size (io.py:527-529)
+        if late_norm:
+            data = resize(data, shape=shape, dtype=dt)
+            data = preprocess_frames(data, normalize=True, gray=False, dtype=dt)
         if tuple(data.shape[-3:-1]) != tuple(psf.shape[-3:-1]):
             data = resize(data, shape=tuple(psf.shape), dtype=dt)
         if gray and data.shape[-1] == 3:

@@ -221,9 +221,14 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
         self._handle.get_state("image_est", out.data_ptr(), self._stream())
         return self._to_user(out)
 
-    def _form_image(self):
+    def _form_image(self, out=None):
         D, H, W, C = (int(v) for v in self._psf_shape)
-        out = self._empty((self._handle_batch, D, H, W, C))
+        shape = (self._handle_batch, D, H, W, C)
+        if out is None:
+            out = self._empty(shape)
+        else:      # caller's device buffer (lenslesspicam_amd.dist: the send buffer of the all-gather): no copy afterwards
+            assert out.is_contiguous() and tuple(out.shape) == shape and out.dtype == self._tdtype and \
+                out.device == self._device, "out= must be a contiguous device tensor of the result's shape and dtype"
         self._handle.form_image(out.data_ptr(), self._stream())
         return self._to_user(out)
 
@@ -256,13 +261,14 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
         assert self._data.shape[0] == 1, "Apply doesn't supports processing multiple images at once."
         return self._apply_impl(n_iter, disp_iter, plot_pause, plot, save, gamma, ax, reset, background)[0]
 
-    def apply_batch(self, n_iter=None, reset=True, background=None):
+    def apply_batch(self, n_iter=None, reset=True, background=None, out=None):
         """Additive entry: B measurements sharing the PSF in one launch sequence.  Equals B
-        independent ``apply()`` calls (frames never couple); returns (B,D,H,W,C)."""
+        independent ``apply()`` calls (frames never couple); returns (B,D,H,W,C).  ``out``: a device tensor the result is
+        written into (torch solvers on the engine's device only)."""
         assert self._data is not None, "Must set data with `set_data()`"
-        return self._apply_impl(n_iter, None, 0.0, False, False, None, None, reset, background)[1]
+        return self._apply_impl(n_iter, None, 0.0, False, False, None, None, reset, background, out=out)[1]
 
-    def _apply_impl(self, n_iter, disp_iter, plot_pause, plot, save, gamma, ax, reset, background):
+    def _apply_impl(self, n_iter, disp_iter, plot_pause, plot, save, gamma, ax, reset, background, out=None):
         if background is not None:  # recon.py:553-555 (cumulative, like the reference)
             self._data = self._data - background
             self._data[self._data < 0] = 0
@@ -296,7 +302,7 @@ class ReconstructionAlgorithm(_Boundary, abc.ABC):
         else:
             ax = None
             self._iterate(n_iter)
-        full = self._form_image()
+        full = self._form_image(out=out)
         final_im = full[0]
         if plot:
             from .plot import plot_image

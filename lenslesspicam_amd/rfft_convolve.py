@@ -72,11 +72,6 @@ class RealFFTConvolve2D(_Boundary):
         self._end_idx = self._start_idx + self._psf_shape[-3:-1]
 
     def _run(self, x, adjoint, return_fft):
-        if return_fft:
-            raise NotImplementedError(
-                "return_fft exposes the reference's spectrum layout; the engine keeps spectra in a "
-                "permuted (four-step) order and does not export them"
-            )
         was_torch = isinstance(x, torch.Tensor)
         if len(x.shape) not in (4, 5):
             raise ValueError("Expected 4D or 5D tensor")                     # rfft_convolve.py:91
@@ -95,7 +90,9 @@ class RealFFTConvolve2D(_Boundary):
         if Cx != C and Cx != 1:
             # three channels against a grayscale PSF: `vpad[...] = v` cannot broadcast 3 -> 1 (rfft_convolve.py:96-99),
             # while the un-padded operator's `rfft2(x) * H` does: every channel is convolved with the one PSF
-            if self.pad or C != 1:
+            # (only the reference's torch branch broadcasts; its NumPy branch writes into a (..., 1) scratch buffer,
+            # `self._padded_data[:] = x`, rfft_convolve.py:143,171, which raises for three channels)
+            if self.pad or C != 1 or not self.is_torch:
                 raise ValueError(f"could not broadcast an input with {Cx} channels against a PSF with {C}")
             x5 = x5.permute(0, 4, 1, 2, 3).reshape((-1,) + tuple(x5.shape[1:4]) + (1,))    # channels -> batch items
             split3 = True
@@ -103,8 +100,14 @@ class RealFFTConvolve2D(_Boundary):
         n = int(x5.shape[0])
         if n > self._handle_batch:
             self._make(n)
-        out = self._empty(tuple(x5.shape[:-1]) + (C,))      # a 1-channel input broadcasts over the PSF's channels
-        self._handle.convolve(x5.data_ptr(), out.data_ptr(), n, int(x5.shape[-1]), adjoint, self._stream())
+        if return_fft:      # rfft2(pad(x)) * H (or * conj(H)), natural frequency order: (n, D, Hp, Wp/2+1, C) complex
+            Hp, Wp = int(self._padded_shape[1]), int(self._padded_shape[2])
+            ctype = torch.complex128 if self._tdtype == torch.float64 else torch.complex64
+            out = torch.empty((n, D, Hp, Wp // 2 + 1, C), dtype=ctype, device=self._device)
+            self._handle.convolve_spectrum(x5.data_ptr(), out.data_ptr(), n, int(x5.shape[-1]), adjoint, self._stream())
+        else:
+            out = self._empty(tuple(x5.shape[:-1]) + (C,))      # a 1-channel input broadcasts over the PSF's channels
+            self._handle.convolve(x5.data_ptr(), out.data_ptr(), n, int(x5.shape[-1]), adjoint, self._stream())
         if split3:
             out = out.reshape((-1, Cx) + tuple(out.shape[1:4])).permute(0, 2, 3, 4, 1).contiguous()
         out = out.reshape(tuple(lead) + tuple(out.shape[1:]))
@@ -115,11 +118,11 @@ class RealFFTConvolve2D(_Boundary):
     def convolve(self, x, return_fft=False):
         """rfft_convolve.py:133-176"""
         y = self._run(x, False, return_fft)
-        assert y.shape[-3:-1] == x.shape[-3:-1]
+        assert return_fft or y.shape[-3:-1] == x.shape[-3:-1]
         return y
 
     def deconvolve(self, y, return_fft=False):
         """rfft_convolve.py:178-223 (multiplication by the conjugate spectrum)"""
         x = self._run(y, True, return_fft)
-        assert x.shape[-3:-1] == y.shape[-3:-1]
+        assert return_fft or x.shape[-3:-1] == y.shape[-3:-1]
         return x

@@ -67,12 +67,15 @@ class UnrolledADMM(ADMM):
         self._iterate(self._n_iter)
         return self._form_image()
 
-    def _form_image(self):
+    def _form_image(self, out=None):
         # unrolled_admm.py:236-240 clips OUT of place (no state mutation): read the state directly
         B = self._handle_batch
         D, Hp, Wp, C = self._padded_shape
-        out = self._empty((B, D, Hp, Wp, C))
+        out_arg, out = out, self._empty((B, D, Hp, Wp, C))
         self._handle.get_state("image_est", out.data_ptr(), self._stream())
         sh, sw = (int(v) for v in self._start_idx)
         H, W = int(self._psf_shape[1]), int(self._psf_shape[2])
-        return self._to_user(torch.clip(out[:, :, sh:sh + H, sw:sw + W, :], min=0.0).contiguous())
+        res = torch.clip(out[:, :, sh:sh + H, sw:sw + W, :], min=0.0).contiguous()
+        if out_arg is not None:
+            out_arg.copy_(res)
+        return self._to_user(res)

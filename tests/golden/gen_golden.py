@@ -473,9 +473,34 @@ def operator_case():
     print("wrote operators")
 
 
+def return_fft_case(name):
+    """convolve / deconvolve(return_fft=True): `rfft2(pad(x)) * H` resp. `* conj(H)`, the spectrum the reference hands
+    back before its irfft2 (rfft_convolve.py:148-150,161-163,193-195,206-208)."""
+    rng = np.random.default_rng(77)
+    out = {}
+    for tag, (d, h, w, c) in {"a": (2, 12, 20, 3), "b": (1, 9, 13, 1)}.items():
+        psf = rng.random((d, h, w, c)).astype(np.float32)
+        x = rng.standard_normal((2, d, h, w, c)).astype(np.float32)
+        out[f"{tag}_psf"], out[f"{tag}_x"] = psf, x
+        for norm in ("ortho", "backward"):
+            cv = RealFFTConvolve2D(t(psf), pad=True, norm=norm)
+            out[f"{tag}_{norm}_conv_fft"] = cv.convolve(t(x), return_fft=True).numpy()
+            out[f"{tag}_{norm}_deconv_fft"] = cv.deconvolve(t(x), return_fft=True).numpy()
+        cvn = RealFFTConvolve2D(t(psf), pad=False, norm="backward")
+        xp = rng.standard_normal([2] + [int(v) for v in cvn._padded_shape]).astype(np.float32)
+        out[f"{tag}_xp"] = xp
+        out[f"{tag}_nopad_conv_fft"] = cvn.convolve(t(xp), return_fft=True).numpy()
+        out[f"{tag}_nopad_deconv_fft"] = cvn.deconvolve(t(xp), return_fft=True).numpy()
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+    print("wrote", name, {k: v.shape for k, v in out.items() if k.endswith("_fft")})
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "return_fft":
+        return_fft_case("return_fft")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "unrolled":
         unrolled_admm_case("unrolled_admm_24x32x3_b3", 24, 32, 3, seed=21, n_iter=6, batch=3)
         unrolled_fista_case("unrolled_fista_24x32x3_b3", 24, 32, 3, seed=22, n_iter=7, batch=3)

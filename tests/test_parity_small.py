@@ -60,6 +60,39 @@ def test_convolver_golden(backend, tag):
     assert rel(cvn.deconvolve(g[f"{tag}_xp"]), g[f"{tag}_nopad_deconv"]) <= 2e-6
 
 
+def test_convolver_return_fft_golden(backend):
+    """convolve / deconvolve(return_fft=True): the spectrum rfft2(pad(x)) * H resp. * conj(H) in the reference's layout
+    (natural frequency order, channels last) although the engine keeps spectra planar in a permuted row order
+    (lpc_convolve_spectrum); golden vectors from the reference's own calls (rfft_convolve.py:148-150,193-195)."""
+    g = np.load(os.path.join(GOLDEN, "return_fft.npz"))
+    for tag in ("a", "b"):
+        psf, x, xp = g[f"{tag}_psf"], g[f"{tag}_x"], g[f"{tag}_xp"]
+        for norm in ("ortho", "backward"):
+            cv = lpa.RealFFTConvolve2D(psf, pad=True, norm=norm)
+            for name, fn in (("conv", cv.convolve), ("deconv", cv.deconvolve)):
+                got, want = fn(x, return_fft=True), g[f"{tag}_{norm}_{name}_fft"]
+                assert got.shape == want.shape and np.iscomplexobj(got)
+                assert np.abs(got - want).max() <= 2e-6 * np.abs(want).max(), (tag, norm, name)
+        cvn = lpa.RealFFTConvolve2D(torch.from_numpy(psf), pad=False, norm="backward")
+        got = cvn.convolve(torch.from_numpy(xp), return_fft=True)
+        assert isinstance(got, torch.Tensor) and got.dtype == torch.complex64
+        assert np.abs(got.cpu().numpy() - g[f"{tag}_nopad_conv_fft"]).max() <= 2e-6 * np.abs(g[f"{tag}_nopad_conv_fft"]).max()
+        got = cvn.deconvolve(torch.from_numpy(xp), return_fft=True).cpu().numpy()
+        assert np.abs(got - g[f"{tag}_nopad_deconv_fft"]).max() <= 2e-6 * np.abs(g[f"{tag}_nopad_deconv_fft"]).max()
+    # a frame with a four-step column split (stored rows permuted): natural order must still come back
+    psf = orc.synthetic_psf(1, 48, 20, 1, seed=2)
+    x = np.random.default_rng(3).standard_normal((1, 1, 48, 20, 1)).astype(np.float32)
+    cv = lpa.RealFFTConvolve2D(psf, pad=True, norm="backward", engine_options={"tile_budget": 512, "col_t": 4, "split_n2": 12})
+    assert "split" in cv._handle.plan_info()
+    xpad = np.zeros((1, 1, 96, 40, 1), np.float32)
+    xpad[:, :, 24:72, 10:30] = x
+    ppad = np.zeros((1, 96, 40, 1), np.float32)
+    ppad[:, 24:72, 10:30] = psf
+    want = np.fft.rfft2(xpad.astype(np.float64), axes=(-3, -2)) * np.fft.rfft2(ppad.astype(np.float64), axes=(-3, -2))
+    got = cv.convolve(x, return_fft=True)
+    assert np.abs(got - want).max() <= 5e-6 * np.abs(want).max()
+
+
 def test_convolver_slice_commutes(backend):
     """test/test_convolver.py:32-59: no cross-batch / cross-depth / cross-channel coupling."""
     rng = np.random.default_rng(0)

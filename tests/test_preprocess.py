@@ -166,3 +166,14 @@ def test_load_data_with_downsample(backend, tmp_path):
     d = po.resize_aa(d, shape=p.shape)
     want_psf, want_data = po.rgb2gray(p).astype(np.float32), po.rgb2gray(d).astype(np.float32)
     assert rel(psf, want_psf) <= 5e-6 and rel(data, want_data) <= 5e-6
+    # shape + normalize (what scripts/recon/admm.py passes): load_image resizes the frame FIRST and divides by the
+    # maximum of the RESIZED frame (io.py:176-190), so the returned frame peaks at exactly 1
+    psf2, data2 = prep.load_data(pf, df, shape=(1, 24, 32, 3), normalize=True, bgr_input=False, plot=False, downsample=None)
+    assert psf2.shape == (1, 24, 32, 3) and data2.shape == (1, 24, 32, 3)
+    p2 = po.resize_aa(np.clip(raw_psf.astype(np.float32) - bg, 0, None), shape=(1, 24, 32, 3))
+    p2 = p2 / np.linalg.norm(p2.ravel())
+    d2 = np.clip(raw_dat.astype(np.float32)[None] - (bg / po.get_max_val(raw_psf)) * po.get_max_val(raw_dat), 0, None)
+    d2 = po.resize_aa(d2, shape=(1, 24, 32, 3))
+    d2 = d2 / d2.max()
+    assert abs(float(np.asarray(data2).max()) - 1.0) <= 1e-6
+    assert rel(psf2, p2.astype(np.float32)) <= 5e-6 and rel(data2, d2.astype(np.float32)) <= 5e-6
