@@ -207,8 +207,8 @@ static void choose_plan(Engine* e, bool allow_static) {
   PlanSpec& sp = e->spec;
   std::vector<int> rad;
   // the X half of the image-domain work moves into the forward rows when the stencil half can run as the tiled
-  // 16-byte-lane kernel (k_admm_spatial_v4<.., XHALF = false>): float32, padded width a multiple of 4
-  const bool xhalf = admm && f32 && g.Wp % 4 == 0 && !o.no_xhalf && !o.k1_scalar;
+  // four-pixel-lane kernel (k_admm_spatial_v4<.., XHALF = false>): padded width a multiple of 4
+  const bool xhalf = admm && g.Wp % 4 == 0 && !o.no_xhalf && !o.k1_scalar;
   // ---- rows
   if (e->rows_half) {
     const int n = g.Wp / 2;
@@ -539,13 +539,8 @@ static int admm_iterate(Engine* e, int n_iter) {
   const size_t k1_smem = (size_t)(2 * (TH + 2) * (TW + 2) + (TH + 1) * TW + TH * (TW + 1)) * sizeof(real);
   const unsigned tiles_x = (g.Wp + TW - 1) / TW, tiles_y = (g.Hp + TH - 1) / TH;
   const dim3 k1_grid(tiles_x * tiles_y, e->P, 1);
-  // 16-byte-lane kernel whenever the padded width allows aligned float4 rows (every BASELINE size does)
-  const bool force_scalar = e->opt.k1_scalar != 0;
-#ifdef LPC_DOUBLE
-  const bool vec4 = false;  // the 16-byte-lane kernel is float-only
-#else
-  const bool vec4 = (g.Wp % 4 == 0) && !force_scalar;
-#endif
+  // 16-byte-lane kernel whenever the padded width allows aligned four-pixel lanes (every BASELINE size does)
+  const bool vec4 = (g.Wp % 4 == 0) && !e->opt.k1_scalar;
   constexpr int TH4 = 8, TW4 = 256;
   const unsigned tiles_x4 = (g.Wp + TW4 - 1) / TW4, tiles_y4 = (g.Hp + TH4 - 1) / TH4;
   const dim3 k1_grid4(tiles_x4 * tiles_y4, e->P, 1);
@@ -569,7 +564,6 @@ static int admm_iterate(Engine* e, int n_iter) {
     // xi = mu1p (HV - HV_old) of the final X half and every read-out after the call need HV_{n-2}, HV_{n-1}, HV_n whole
     sc.skipa = (e->hv_skip && sb_rows_valid && !sc.xi_store) ? 1 : 0;
     sc.skiphv = (e->hv_skip && it + 3 < n_iter) ? 1 : 0;
-#ifndef LPC_DOUBLE
     if (vec4 && e->xhalf_rows)
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4X, NT, false>, k1_grid4x, NT, k1_smem4x, g, sc, (const real*)Vc,
                       (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
@@ -581,7 +575,6 @@ static int admm_iterate(Engine* e, int n_iter) {
                       (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
                       (const real*)e->Y, e->Rsp, e->Aarr, tiles_x4));
     else
-#endif
     LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial<TH, TW, NT>, k1_grid, NT, k1_smem, g, sc, (const real*)Vc,
                     (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
                     (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,

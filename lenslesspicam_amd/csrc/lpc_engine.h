@@ -260,7 +260,6 @@ int rows_inv_single(Engine* e, const real2* S, const RealDst& dst, int nplanes, 
 int admm_rows_fwd(Engine* e);                                   // e->Rsp, e->Aarr -> the two work spectra
 int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc);          // e->Rsp and (xi, HV, HV_old, y) -> the two work spectra
 int admm_rows_inv(Engine* e, real* Vout, real* HVout, bool skip_hv_outside = false);          // the two work spectra -> V, H V
-int admm_rows_fused(Engine* e, const AdmmScalars& sc, const real* Vc, const real* Vo);   // k_admm_rows_fused
 // lpc_cols.cpp
 int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1, int kid, bool crop_rows_only = false,
                real sb_outside_scale = (real)0.);

@@ -1120,77 +1120,57 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
   }
 }
 
-#ifndef LPC_DOUBLE  // float4 lanes: the float64 build uses k_admm_spatial
 // ---- K1, 16-byte-lane version (padded width a multiple of 4) -----------------------------------
-// Same arithmetic as k_admm_spatial, re-shaped for HBM: every lane moves float4 (a wave covers 1 KiB of
-// one image row per array), tiles are 8 rows x 256 columns, only V / V_old are staged in LDS (+1 halo,
-// circular); q = mu2 U - eta of the lower / right neighbour is RECOMPUTED in registers from the LDS
-// tile and one extra (L1/L2-resident) load of eta instead of being exchanged through LDS, so there is
+// Same arithmetic as k_admm_spatial, re-shaped for HBM: every lane moves four pixels (float4: a wave covers 1 KiB of
+// one image row per array; the float64 build moves two 16-byte halves), tiles are TH rows x 256 columns, only V / V_old
+// are staged in LDS (+1 halo, circular); q = mu2 U - eta of the lower / right neighbour is RECOMPUTED in registers from
+// the LDS tile and one extra (L1/L2-resident) load of eta instead of being exchanged through LDS, so there is
 // one barrier and 21 KiB of LDS per workgroup (7 workgroups per CU).
-static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+#ifdef LPC_DOUBLE
+struct alignas(16) real4 { double x, y, z, w; };     // two 16-byte halves per lane
+#else
+typedef float4 real4;
+#endif
+static __host__ __device__ __forceinline__ real4 make_real4(real x, real y, real z, real w) {
+  real4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r;
+}
+static __device__ __forceinline__ real4 ld4(const real* p) { return *reinterpret_cast<const real4*>(p); }
+static __device__ __forceinline__ void st4(real* p, real4 v) { *reinterpret_cast<real4*>(p) = v; }
 
 // eta' and q for one pixel and one difference direction
-static __device__ __forceinline__ void tv_component(const AdmmScalars& p, float vc, float vn, float oc, float on,
-                                                     float eta, float& eta_new, float& q) {
-  const float psi = vn - vc;                       // finite_diff: roll(+1) - x   (admm.py:349-359)
+static __device__ __forceinline__ void tv_component(const AdmmScalars& p, real vc, real vn, real oc, real on,
+                                                     real eta, real& eta_new, real& q) {
+  const real psi = vn - vc;                       // finite_diff: roll(+1) - x   (admm.py:349-359)
   if (!p.first) {
-    const float uo = soft_thresh_dev((on - oc) + div_by(eta, p.mu2p, p.r_mu2p), p.thrp);
+    const real uo = soft_thresh_dev((on - oc) + div_by(eta, p.mu2p, p.r_mu2p), p.thrp);
     eta = eta + p.mu2p * (psi - uo);               // pending eta update of the previous iteration
   }
-  const float un = soft_thresh_dev(psi + div_by(eta, p.mu2, p.r_mu2), p.thr);
-  eta_new = eta;
-  q = p.mu2 * un - eta;
-}
-
-// ---- the same arithmetic, two pixels per operand (packed FP32 on gfx950, see v2f in lpc_rt.h) ----
-static __device__ __forceinline__ v2f div_by2(v2f x, float d, float r) {      // div_by, two quotients
-#if defined(LPC_SIMT_EMU)
-  (void)r;
-  return mk2(x.x / d, x.y / d);
-#else
-  const v2f rr = mk2(r, r);
-  const v2f q = x * rr;
-  const v2f e = fma2(mk2(-d, -d), q, x);
-  return fma2(e, rr, q);
-#endif
-}
-static __device__ __forceinline__ v2f soft_thresh2(v2f a, float thr) {
-  return mk2(soft_thresh_dev(a.x, thr), soft_thresh_dev(a.y, thr));
-}
-static __device__ __forceinline__ void tv_component2(const AdmmScalars& p, v2f vc, v2f vn, v2f oc, v2f on, v2f eta,
-                                                      v2f& eta_new, v2f& q) {
-  const v2f psi = vn - vc;
-  if (!p.first) {
-    const v2f uo = soft_thresh2((on - oc) + div_by2(eta, p.mu2p, p.r_mu2p), p.thrp);
-    eta = eta + p.mu2p * (psi - uo);
-  }
-  const v2f un = soft_thresh2(psi + div_by2(eta, p.mu2, p.r_mu2), p.thr);
+  const real un = soft_thresh_dev(psi + div_by(eta, p.mu2, p.r_mu2), p.thr);
   eta_new = eta;
   q = p.mu2 * un - eta;
 }
 
 // XHALF == false: the TV / W half only (eta, rho, r_sp); xi and a = mu1 X - xi are then produced by the forward row
-// kernel itself (k_rfwd_half_x), which needs nothing but its own row for them.
+// kernel itself (k_rfwd_half_x / k_rfwd_arrays_x), which needs nothing but its own row for them.
 template <int TH, int NT, bool XHALF = true>
 __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars p,
-                                                         const float* LPC_RESTRICT V,
-                                                         const float* LPC_RESTRICT Vold,
-                                                         const float* LPC_RESTRICT HV,
-                                                         const float* LPC_RESTRICT HVold, float* LPC_RESTRICT xi,
-                                                         const float* LPC_RESTRICT eta0,
-                                                         const float* LPC_RESTRICT eta1,
-                                                         float* LPC_RESTRICT eta0_out,
-                                                         float* LPC_RESTRICT eta1_out,
-                                                         float* LPC_RESTRICT rho,
-                                                         const float* LPC_RESTRICT Y,
-                                                         float* LPC_RESTRICT Rsp, float* LPC_RESTRICT Aout,
+                                                         const real* LPC_RESTRICT V,
+                                                         const real* LPC_RESTRICT Vold,
+                                                         const real* LPC_RESTRICT HV,
+                                                         const real* LPC_RESTRICT HVold, real* LPC_RESTRICT xi,
+                                                         const real* LPC_RESTRICT eta0,
+                                                         const real* LPC_RESTRICT eta1,
+                                                         real* LPC_RESTRICT eta0_out,
+                                                         real* LPC_RESTRICT eta1_out,
+                                                         real* LPC_RESTRICT rho,
+                                                         const real* LPC_RESTRICT Y,
+                                                         real* LPC_RESTRICT Rsp, real* LPC_RESTRICT Aout,
                                                          unsigned tiles_x) {
   LPC_DYN_SMEM(smem);
   constexpr int TW = 256, LP = TW + 8;          // LDS row: [3] = col -1, [4..259] = cols 0..255, [260] = col 256
   constexpr int VH = TH + 2;
-  float* sV = (float*)smem;                     // [VH][LP]
-  float* sO = sV + VH * LP;
+  real* sV = (real*)smem;                     // [VH][LP]
+  real* sO = sV + VH * LP;
   const int tid = threadIdx.x;
   const unsigned nblk = gridDim.x, bid = blockIdx.x;   // XCD-aware tile order (see k_admm_spatial)
   const unsigned qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7, idx = bid >> 3;
@@ -1199,28 +1179,28 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
   const int r0 = (int)ty_ * TH, c0 = (int)(tile - ty_ * tiles_x) * TW;
   const long pl = blockIdx.y;
   const long poff = pl * g.rplane;
-  const float* v = V + poff;
-  const float* vo = Vold + poff;
+  const real* v = V + poff;
+  const real* vo = Vold + poff;
   auto wrap_r = [&](int r) { r = r < 0 ? r + g.Hp : r; return r >= g.Hp ? r % g.Hp : r; };
   auto wrap_c = [&](int c) { c = c < 0 ? c + g.Wp : c; return c >= g.Wp ? c % g.Wp : c; };
 
-  // ---- stage V, V_old: body as float4, the two halo columns as scalars ----
+  // ---- stage V, V_old: body as real4, the two halo columns as scalars ----
   for (int e = tid; e < VH * (TW / 4); e += NT) {
     const int ly = e / (TW / 4), l4 = e - ly * (TW / 4);
     const long o = (long)wrap_r(r0 + ly - 1) * g.rpitch + wrap_c(c0 + 4 * l4);
     st4(sV + ly * LP + 4 + 4 * l4, ld4(v + o));
-    st4(sO + ly * LP + 4 + 4 * l4, p.first ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(vo + o));
+    st4(sO + ly * LP + 4 + 4 * l4, p.first ? make_real4((real)0., (real)0., (real)0., (real)0.) : ld4(vo + o));
   }
   for (int e = tid; e < VH * 2; e += NT) {
     const int ly = e >> 1, side = e & 1;
     const long o = (long)wrap_r(r0 + ly - 1) * g.rpitch + wrap_c(side ? c0 + TW : c0 - 1);
     sV[ly * LP + (side ? 4 + TW : 3)] = v[o];
-    sO[ly * LP + (side ? 4 + TW : 3)] = p.first ? 0.f : vo[o];
+    sO[ly * LP + (side ? 4 + TW : 3)] = p.first ? (real)0. : vo[o];
   }
   __syncthreads();
 
   const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
-  const float* y = Y + (long)dpl * g.uplane;
+  const real* y = Y + (long)dpl * g.uplane;
   const int lane = tid & 63, wv = tid >> 6;
   const int gc = c0 + 4 * lane;
 #pragma unroll
@@ -1232,249 +1212,133 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
     const long o_dn = poff + (long)wrap_r(gr + 1) * g.rpitch + gc;        // eta0 of the row below
     const long o_rt = poff + (long)gr * g.rpitch + wrap_c(gc + 4);        // eta1 of the pixel right of the quad
     // global loads first (all independent)
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const float4 hv4 = XHALF ? ld4(HV + o) : z4, xi4 = XHALF ? ld4(xi + o) : z4, rho4 = ld4(rho + o);
-    const float4 e04 = ld4(eta0 + o), e14 = ld4(eta1 + o), e0d4 = ld4(eta0 + o_dn);
-    const float e1r = eta1[o_rt];
-    float4 ho4 = z4;
+    const real4 z4 = make_real4((real)0., (real)0., (real)0., (real)0.);
+    const real4 hv4 = XHALF ? ld4(HV + o) : z4, xi4 = XHALF ? ld4(xi + o) : z4, rho4 = ld4(rho + o);
+    const real4 e04 = ld4(eta0 + o), e14 = ld4(eta1 + o), e0d4 = ld4(eta0 + o_dn);
+    const real e1r = eta1[o_rt];
+    real4 ho4 = z4;
     if (XHALF && !p.first) ho4 = ld4(HVold + o);      // previous H V: lets the previous X be recomputed instead of stored
     // LDS neighbourhood: rows ly-1, ly, ly+1 of the quad, plus the pixel left and right of it
-    const float* rowm = sV + ly * LP + 4 + 4 * lane;        // global row gr-1  (local ly)
-    const float* rowc = rowm + LP;                          // gr
-    const float* rowp = rowc + LP;                          // gr+1
-    const float* orm = sO + ly * LP + 4 + 4 * lane;
-    const float* orc = orm + LP;
-    const float* orp = orc + LP;
-    const float4 vm4 = ld4(rowm), vc4 = ld4(rowc), vp4 = ld4(rowp);
-    const float4 om4 = ld4(orm), oc4 = ld4(orc), op4 = ld4(orp);
-    const float vl = rowc[-1], vr = rowc[4], ol = orc[-1], orr = orc[4];
-    const float vcs[6] = {vl, vc4.x, vc4.y, vc4.z, vc4.w, vr};       // cols gc-1 .. gc+4 of row gr
-    const float ocs[6] = {ol, oc4.x, oc4.y, oc4.z, oc4.w, orr};
-    const float vms[4] = {vm4.x, vm4.y, vm4.z, vm4.w}, vps[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
-    const float oms[4] = {om4.x, om4.y, om4.z, om4.w}, ops[4] = {op4.x, op4.y, op4.z, op4.w};
-    const float hvs[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, xis[4] = {xi4.x, xi4.y, xi4.z, xi4.w};
-    const float rhs[4] = {rho4.x, rho4.y, rho4.z, rho4.w}, hos[4] = {ho4.x, ho4.y, ho4.z, ho4.w};
-    const float e0s[4] = {e04.x, e04.y, e04.z, e04.w}, e0ds[4] = {e0d4.x, e0d4.y, e0d4.z, e0d4.w};
-    const float e1s[5] = {e14.x, e14.y, e14.z, e14.w, e1r};
-    float q1[5], e1n[5];
+    const real* rowm = sV + ly * LP + 4 + 4 * lane;        // global row gr-1  (local ly)
+    const real* rowc = rowm + LP;                          // gr
+    const real* rowp = rowc + LP;                          // gr+1
+    const real* orm = sO + ly * LP + 4 + 4 * lane;
+    const real* orc = orm + LP;
+    const real* orp = orc + LP;
+    const real4 vm4 = ld4(rowm), vc4 = ld4(rowc), vp4 = ld4(rowp);
+    const real4 om4 = ld4(orm), oc4 = ld4(orc), op4 = ld4(orp);
+    const real vl = rowc[-1], vr = rowc[4], ol = orc[-1], orr = orc[4];
+    const real vcs[6] = {vl, vc4.x, vc4.y, vc4.z, vc4.w, vr};       // cols gc-1 .. gc+4 of row gr
+    const real ocs[6] = {ol, oc4.x, oc4.y, oc4.z, oc4.w, orr};
+    const real vms[4] = {vm4.x, vm4.y, vm4.z, vm4.w}, vps[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
+    const real oms[4] = {om4.x, om4.y, om4.z, om4.w}, ops[4] = {op4.x, op4.y, op4.z, op4.w};
+    const real hvs[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, xis[4] = {xi4.x, xi4.y, xi4.z, xi4.w};
+    const real rhs[4] = {rho4.x, rho4.y, rho4.z, rho4.w}, hos[4] = {ho4.x, ho4.y, ho4.z, ho4.w};
+    const real e0s[4] = {e04.x, e04.y, e04.z, e04.w}, e0ds[4] = {e0d4.x, e0d4.y, e0d4.z, e0d4.w};
+    const real e1s[5] = {e14.x, e14.y, e14.z, e14.w, e1r};
+    real q1[5], e1n[5];
 #pragma unroll
     for (int i = 0; i < 5; ++i)   // column-difference component at cols gc .. gc+4 (the 5th only for q)
       tv_component(p, vcs[i + 1], vcs[i], ocs[i + 1], ocs[i], e1s[i], e1n[i], q1[i]);
-    float xin[4], e0n[4], rhn[4], rs[4], as[4];
+    real xin[4], e0n[4], rhn[4], rs[4], as[4];
     const bool row_in = (gr >= g.sh) && (gr < g.sh + g.H);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      float q0c, q0d, dummy;
+      real q0c, q0d, dummy;
       tv_component(p, vcs[i + 1], vms[i], ocs[i + 1], oms[i], e0s[i], e0n[i], q0c);   // this pixel
       tv_component(p, vps[i], vcs[i + 1], ops[i], ocs[i + 1], e0ds[i], dummy, q0d);   // the pixel below
-      const float vc = vcs[i + 1], hv = hvs[i];
-      float xiv = xis[i], rhov = rhs[i];
+      const real vc = vcs[i + 1], hv = hvs[i];
+      real xiv = xis[i], rhov = rhs[i];
       const int cc = gc + i;
       const bool inside = row_in && (cc >= g.sw) && (cc < g.sw + g.W);
-      const float yv = (XHALF && inside) ? y[(long)(gr - g.sh) * g.W + (cc - g.sw)] : 0.f;
+      const real yv = (XHALF && inside) ? y[(long)(gr - g.sh) * g.W + (cc - g.sw)] : (real)0.;
       if (!p.first) {
         if (XHALF) {
-          const float xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
+          const real xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
           xiv = xiv + p.mu1p * (hv - xo);
         }
-        const float wo = fmaxf(div_by(rhov, p.mu3p, p.r_mu3p) + w_sees(ocs[i + 1], p.clamp_old, inside), 0.f);
+        const real wo = rmax(div_by(rhov, p.mu3p, p.r_mu3p) + w_sees(ocs[i + 1], p.clamp_old, inside), (real)0.);
         rhov = rhov + p.mu3p * (vc - wo);
       }
-      const float xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
-      const float wn = fmaxf(div_by(rhov, p.mu3, p.r_mu3) + w_sees(vc, p.clamp_cur, inside), 0.f);
-      const float d1 = q0d - q0c;
-      const float d2 = q1[i + 1] - q1[i];
+      const real xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
+      const real wn = rmax(div_by(rhov, p.mu3, p.r_mu3) + w_sees(vc, p.clamp_cur, inside), (real)0.);
+      const real d1 = q0d - q0c;
+      const real d2 = q1[i + 1] - q1[i];
       xin[i] = xiv; rhn[i] = rhov;
       rs[i] = (p.mu3 * wn - rhov) + (d1 + d2);
       as[i] = p.mu1 * xnew - xiv;
     }
-    if (XHALF) st4(xi + o, make_float4(xin[0], xin[1], xin[2], xin[3]));
-    st4(rho + o, make_float4(rhn[0], rhn[1], rhn[2], rhn[3]));
-    st4(eta0_out + o, make_float4(e0n[0], e0n[1], e0n[2], e0n[3]));
-    st4(eta1_out + o, make_float4(e1n[0], e1n[1], e1n[2], e1n[3]));
-    st4(Rsp + o, make_float4(rs[0], rs[1], rs[2], rs[3]));
-    if (XHALF) st4(Aout + o, make_float4(as[0], as[1], as[2], as[3]));
+    if (XHALF) st4(xi + o, make_real4(xin[0], xin[1], xin[2], xin[3]));
+    st4(rho + o, make_real4(rhn[0], rhn[1], rhn[2], rhn[3]));
+    st4(eta0_out + o, make_real4(e0n[0], e0n[1], e0n[2], e0n[3]));
+    st4(eta1_out + o, make_real4(e1n[0], e1n[1], e1n[2], e1n[3]));
+    st4(Rsp + o, make_real4(rs[0], rs[1], rs[2], rs[3]));
+    if (XHALF) st4(Aout + o, make_real4(as[0], as[1], as[2], as[3]));
   }
 }
 
-// ---- K1 fused into the forward row pass (wide frames, one real row per half-length transform) -------------------
-// The image-domain half of an ADMM iteration never needs more than rows r-1, r, r+1 of V, so the workgroup that is
-// about to transform row r of `r_sp` (or of `a`) can COMPUTE that row instead of reading it: `r_sp` and `a` never
-// exist in HBM (-4R per iteration: 2.4 GB of 22 at 12 MP) and one launch disappears.  The two outputs separate
-// cleanly:  r_sp = (mu3 W - rho') + Psi^T(mu2 U - eta')  depends on V, V_old, eta, rho only,
-//           a    = mu1 X - xi'                           depends on xi, HV, HV_old, y only,
-// so block (row, 0) does the TV / W part (reads V x3 rows, V_old x3, eta0 x2, eta1, rho; writes eta0', eta1', rho')
-// and block (row, 1) the X part (reads xi, HV, HV_old, y; writes xi').  Same arithmetic, statement for statement, as
-// k_admm_spatial_v4.  The rows above / below are re-read from L2: blocks are handed out
-// in an XCD-aware order (block b runs on XCD b % 8: each XCD gets a contiguous band of rows), so rows r and r+1 are
-// in flight together on ONE L2.  grid = (2 * Hp, planes); `plan` has length Wp/2, `twW` is the length-Wp table.
-// TVHALF == false ("X half only", the default launch sequence): block (row, 0) transforms the row of r_sp that the tiled
-// image-domain kernel (k_admm_spatial_v4<.., XHALF = false>) wrote, exactly like k_rfwd_half; only `a` and the xi update
-// -- which need no neighbours -- ride in the row kernel: the tiled kernel no longer touches xi, HV, HV_old, y and `a`
-// makes no round trip through HBM (-2R per iteration), while the stencil half keeps its own occupancy.  `Vold` then
-// carries the r_sp array.
-template <int NT, int EMAX, bool SK, int UNR = 1, int MINW = 1, class PL = Fft1dPlan, bool TVHALF = true>
-__global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmScalars p, PL plan,
-                                                         const real2* LPC_RESTRICT twW,
-                                                         const float* LPC_RESTRICT V, const float* LPC_RESTRICT Vold,
-                                                         const float* LPC_RESTRICT HV, const float* LPC_RESTRICT HVold,
-                                                         float* LPC_RESTRICT xi, const float* LPC_RESTRICT eta0,
-                                                         const float* LPC_RESTRICT eta1, float* LPC_RESTRICT eta0_out,
-                                                         float* LPC_RESTRICT eta1_out, float* LPC_RESTRICT rho,
-                                                         const float* LPC_RESTRICT Y, real2* LPC_RESTRICT SA,
-                                                         real2* LPC_RESTRICT SB) {
+// ---- forward rows of r_sp and a, with the X half of the image-domain work (wide frames: one real row per half-length
+// transform) -------------------------------------------------------------------------------------------------------
+// The image-domain work of an ADMM iteration separates cleanly:
+//   r_sp = (mu3 W - rho') + Psi^T(mu2 U - eta')  depends on V, V_old, eta, rho only and needs neighbours (TV stencil),
+//   a    = mu1 X - xi'                           depends on xi, HV, HV_old, y only and needs nothing but its own pixel.
+// The tiled kernel (k_admm_spatial_v4<.., XHALF = false>) keeps the stencil half at its own occupancy and writes r_sp;
+// here block (row, 0) transforms that stored row exactly like k_rfwd_half, and block (row, 1) COMPUTES the row of `a`
+// (and the pending xi update) from xi, HV, HV_old, y in registers and transforms it: `a` never exists in HBM and the
+// tiled kernel no longer touches xi, HV, HV_old, y (-2R per iteration).  Same arithmetic, statement for statement, as
+// the X part of k_admm_spatial_v4.  grid = (2 * Hp, planes); `plan` has length Wp/2, `twW` is the length-Wp table.
+// (Three ways to split the image-domain work were built and measured, profiles/r02_notes.md: the stand-alone kernel,
+// everything inside the forward rows -- its stencil half then runs at the row kernel's 4 workgroups per CU, no faster
+// than the pair once the rows run on compile-time plans -- and this one, a win on every box and shape.)
+template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+__global__ __launch_bounds__(NT) void k_rfwd_half_x(PlaneGeom g, AdmmScalars p, PL plan, const real2* LPC_RESTRICT twW,
+                                                     const real* LPC_RESTRICT Rsp, const real* LPC_RESTRICT HV,
+                                                     const real* LPC_RESTRICT HVold, real* LPC_RESTRICT xi,
+                                                     const real* LPC_RESTRICT Y, real2* LPC_RESTRICT SA,
+                                                     real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
-  const unsigned nblk = gridDim.x, bid = blockIdx.x;   // XCD-aware order (see k_admm_spatial)
-  const unsigned qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-  // TVHALF: each XCD gets a contiguous band of rows (the halo rows are shared through ITS L2).  X half only: no row
-  // needs a neighbour, and rows inside the sensor window cost more than rows outside (AdmmScalars::xiw) -- bands would
-  // leave the XCDs that hold the window rows working while the others idle, so rows go round-robin over the XCDs
-  const unsigned tile = TVHALF ? (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx : bid;
-  // (block b runs on XCD b % 8: the even XCDs transform the rows of r_sp, the odd ones form and transform the rows of
-  // `a` -- about twice the work per row, on half of the rows once those outside the sensor window are skipped.
-  // Flipping the pair every fourth row to mix both kinds on every XCD measured SLOWER: 0.47 -> 0.60 ms, r02ak)
-  // (a compact grid without the empty blocks of skipped `a` rows, two light blocks per heavy one on every XCD, measured
-  // the same: 0.498 / 0.480 vs 0.499 / 0.481 ms, r02an)
-  const int gr = (int)(tile >> 1), arr = (int)(tile & 1);
+  // No row needs a neighbour, and rows inside the sensor window cost more than rows outside (AdmmScalars::xiw): bands of
+  // rows per XCD would leave the XCDs that hold the window rows working while the others idle, so rows go round-robin
+  // over the XCDs (block b runs on XCD b % 8: the even XCDs transform the rows of r_sp, the odd ones form and transform
+  // the rows of `a` -- about twice the work per row, on half of the rows once those outside the window are skipped.
+  // Flipping the pair every fourth row to mix both kinds on every XCD measured SLOWER: 0.47 -> 0.60 ms, r02ak; a compact
+  // grid without the empty blocks of skipped `a` rows measured the same: 0.498 / 0.480 vs 0.499 / 0.481 ms, r02an)
+  const int gr = (int)(blockIdx.x >> 1), arr = (int)(blockIdx.x & 1);
   const long pl = blockIdx.y;
   const long poff = pl * g.rplane;
   const long o_row = poff + (long)gr * g.rpitch;
   const int n4 = g.Wp >> 2;
-  if constexpr (!TVHALF) {
-    if (arr == 1 && p.skipa && (gr < g.sh || gr >= g.sh + g.H)) return;   // AdmmScalars::skipa (uniform per block)
-    if (arr == 0) {      // the stored row of r_sp: first stage fused into the fill, like k_rfwd_half
-      const real2* a2 = (const real2*)(Vold + o_row);
-      auto src = [&](int i, int) { return a2[i]; };
-      fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
-      untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, SA + pl * g.cplane + (long)gr * g.cpitch, tid);
-      return;
-    }
+  if (arr == 1 && p.skipa && (gr < g.sh || gr >= g.sh + g.H)) return;   // AdmmScalars::skipa (uniform per block)
+  if (arr == 0) {      // the stored row of r_sp: first stage fused into the fill, like k_rfwd_half
+    const real2* a2 = (const real2*)(Rsp + o_row);
+    auto src = [&](int i, int) { return a2[i]; };
+    fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
+    untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, SA + pl * g.cplane + (long)gr * g.cpitch, tid);
+    return;
   }
-#ifdef LPC_DEBUG_KNOBS   // timing experiments only: MINW == 3 skips the image-domain half (the tile is filled with junk)
-  if (MINW == 3) {
-    for (int q = tid; q < n4; q += NT) {
-      s[lds_slot<SK>(2 * q)] = make_real2((real)q, (real)tid);
-      s[lds_slot<SK>(2 * q + 1)] = make_real2((real)gr, (real)arr);
-    }
-  } else
-#endif
-  if (TVHALF && arr == 0) {
-    const long o_up = poff + (long)(gr == 0 ? g.Hp - 1 : gr - 1) * g.rpitch;
-    const long o_dn = poff + (long)(gr + 1 == g.Hp ? 0 : gr + 1) * g.rpitch;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // everything one float4 of the row needs from HBM / L2; PF > 1: the NEXT quad's loads are issued before this
-    // quad's arithmetic (the static-plan build of this kernel needs 70 VGPRs of a 128-VGPR budget: the spare registers
-    // buy a second set of loads in flight per wave)
-    struct Quad { float4 vm, vc, vp, om, oc, op, e0, e0d, e1, rho; float vl, vr, ol, orr, e1r; };
-    auto load_quad = [&](int q) {
-      Quad c;
-      const int gc = 4 * q;
-      const int cl = gc == 0 ? g.Wp - 1 : gc - 1, cr = gc + 4 == g.Wp ? 0 : gc + 4;
-      c.vm = ld4(V + o_up + gc); c.vc = ld4(V + o_row + gc); c.vp = ld4(V + o_dn + gc);
-      c.vl = V[o_row + cl]; c.vr = V[o_row + cr];
-      c.om = z4; c.oc = z4; c.op = z4; c.ol = 0.f; c.orr = 0.f;
-      if (!p.first) {
-        c.om = ld4(Vold + o_up + gc); c.oc = ld4(Vold + o_row + gc); c.op = ld4(Vold + o_dn + gc);
-        c.ol = Vold[o_row + cl]; c.orr = Vold[o_row + cr];
-      }
-      c.e0 = ld4(eta0 + o_row + gc); c.e0d = ld4(eta0 + o_dn + gc); c.e1 = ld4(eta1 + o_row + gc);
-      c.e1r = eta1[o_row + cr];
-      c.rho = ld4(rho + o_row + gc);
-      return c;
-    };
-    auto do_quad = [&](const Quad& c, int q, auto vw_tag) {
-      constexpr bool VW = decltype(vw_tag)::value;
-      const int gc = 4 * q;
-      // only for the two iterations after a read-out clamped the estimate: what the W-update saw (w_sees)
-      const bool rin = VW && (gr >= g.sh) && (gr < g.sh + g.H);
-      const float vcs[6] = {c.vl, c.vc.x, c.vc.y, c.vc.z, c.vc.w, c.vr};       // cols gc-1 .. gc+4 of row gr
-      const float ocs[6] = {c.ol, c.oc.x, c.oc.y, c.oc.z, c.oc.w, c.orr};
-      const float vms[4] = {c.vm.x, c.vm.y, c.vm.z, c.vm.w}, vps[4] = {c.vp.x, c.vp.y, c.vp.z, c.vp.w};
-      const float oms[4] = {c.om.x, c.om.y, c.om.z, c.om.w}, ops[4] = {c.op.x, c.op.y, c.op.z, c.op.w};
-      const float rhs[4] = {c.rho.x, c.rho.y, c.rho.z, c.rho.w};
-      const float e0s[4] = {c.e0.x, c.e0.y, c.e0.z, c.e0.w}, e0ds[4] = {c.e0d.x, c.e0d.y, c.e0d.z, c.e0d.w};
-      const float e1s[5] = {c.e1.x, c.e1.y, c.e1.z, c.e1.w, c.e1r};
-      // two pixels per operand: pairs (0,1) and (2,3) of the quad; the 5th column difference (needed only for q) alone
-      float q1[5], e1n[5], e0n[4], rhn[4], rs[4];
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int i = 2 * h;
-        v2f en, qq;
-        tv_component2(p, mk2(vcs[i + 1], vcs[i + 2]), mk2(vcs[i], vcs[i + 1]), mk2(ocs[i + 1], ocs[i + 2]),
-                      mk2(ocs[i], ocs[i + 1]), mk2(e1s[i], e1s[i + 1]), en, qq);               // column differences
-        e1n[i] = en.x; e1n[i + 1] = en.y; q1[i] = qq.x; q1[i + 1] = qq.y;
-      }
-      tv_component(p, vcs[5], vcs[4], ocs[5], ocs[4], e1s[4], e1n[4], q1[4]);
-#pragma unroll
-      for (int h = 0; h < 2; ++h) {
-        const int i = 2 * h;
-        const v2f vc2 = mk2(vcs[i + 1], vcs[i + 2]), oc2 = mk2(ocs[i + 1], ocs[i + 2]);
-        v2f en, q0c, q0d, dummy;
-        tv_component2(p, vc2, mk2(vms[i], vms[i + 1]), oc2, mk2(oms[i], oms[i + 1]), mk2(e0s[i], e0s[i + 1]), en,
-                      q0c);                                                                        // these pixels
-        tv_component2(p, mk2(vps[i], vps[i + 1]), vc2, mk2(ops[i], ops[i + 1]), oc2, mk2(e0ds[i], e0ds[i + 1]),
-                      dummy, q0d);                                                                 // the pixels below
-        e0n[i] = en.x; e0n[i + 1] = en.y;
-        v2f rhov = mk2(rhs[i], rhs[i + 1]);
-        if (!p.first) {
-          const v2f vo2 = VW ? mk2(w_sees(oc2.x, p.clamp_old, rin && gc + i >= g.sw && gc + i < g.sw + g.W),
-                                   w_sees(oc2.y, p.clamp_old, rin && gc + i + 1 >= g.sw && gc + i + 1 < g.sw + g.W))
-                             : oc2;
-          const v2f t = div_by2(rhov, p.mu3p, p.r_mu3p) + vo2;
-          const v2f wo = mk2(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f));
-          rhov = rhov + p.mu3p * (vc2 - wo);
-        }
-        const v2f vw2 = VW ? mk2(w_sees(vc2.x, p.clamp_cur, rin && gc + i >= g.sw && gc + i < g.sw + g.W),
-                                 w_sees(vc2.y, p.clamp_cur, rin && gc + i + 1 >= g.sw && gc + i + 1 < g.sw + g.W))
-                           : vc2;
-        const v2f t = div_by2(rhov, p.mu3, p.r_mu3) + vw2;
-        const v2f wn = mk2(fmaxf(t.x, 0.f), fmaxf(t.y, 0.f));
-        const v2f d1 = q0d - q0c;
-        const v2f d2 = mk2(q1[i + 1], q1[i + 2]) - mk2(q1[i], q1[i + 1]);
-        const v2f r2 = (p.mu3 * wn - rhov) + (d1 + d2);
-        rhn[i] = rhov.x; rhn[i + 1] = rhov.y;
-        rs[i] = r2.x; rs[i + 1] = r2.y;
-      }
-      st4(rho + o_row + gc, make_float4(rhn[0], rhn[1], rhn[2], rhn[3]));
-      st4(eta0_out + o_row + gc, make_float4(e0n[0], e0n[1], e0n[2], e0n[3]));
-      st4(eta1_out + o_row + gc, make_float4(e1n[0], e1n[1], e1n[2], e1n[3]));
-      s[lds_slot<SK>(2 * q)] = make_real2(rs[0], rs[1]);          // z[j] = (x[2j], x[2j+1])
-      s[lds_slot<SK>(2 * q + 1)] = make_real2(rs[2], rs[3]);
-    };
-    // Measured on MI355X (profiles/r02_notes.md): issuing the next quad's loads ahead of this quad's arithmetic (whole
-    // quad: 176 VGPRs, 2 workgroups per CU; first-touch rows only: 142 VGPRs) is SLOWER than this plain loop at 70
-    // VGPRs and 4 workgroups per CU (1.84 vs 2.21 / 1.98 ms): the kernel is bound by instruction issue (VALU 38 %,
-    // all instructions 55 % of every SIMD cycle, PMC), not by exposed latency.
-    if (!p.clamp_cur && !p.clamp_old) {
-#pragma unroll 1
-      for (int q = tid; q < n4; q += NT) do_quad(load_quad(q), q, std::false_type{});
-    } else {
-#pragma unroll 1
-      for (int q = tid; q < n4; q += NT) do_quad(load_quad(q), q, std::true_type{});
-    }
-  } else {
+  {
     const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
     const bool row_in = (gr >= g.sh) && (gr < g.sh + g.H);
-    const float* y = Y + (long)dpl * g.uplane + (long)(gr - g.sh) * g.W;     // dereferenced only when row_in
-    const bool y4 = ((g.sw | g.W) & 3) == 0;                                 // window and pitch allow float4 loads of y
-    struct QuadX { float4 hv, xi, ho; float ys[4]; bool ins[4]; bool skip; };
+    const real* y = Y + (long)dpl * g.uplane + (long)(gr - g.sh) * g.W;     // dereferenced only when row_in
+    const bool y4 = ((g.sw | g.W) & 3) == 0;                                 // window and pitch allow real4 loads of y
+    struct QuadX { real4 hv, xi, ho; real ys[4]; bool ins[4]; bool skip; };
     auto load_quadx = [&](int q) {
       QuadX c;
       const int gc = 4 * q;
       // the whole quad lies outside the sensor window: HV is all it needs (see AdmmScalars::xiw)
       c.skip = p.xiw && !(row_in && gc + 4 > g.sw && gc < g.sw + g.W);
       c.hv = ld4(HV + o_row + gc);
-      c.xi = c.ho = make_float4(0.f, 0.f, 0.f, 0.f);
+      c.xi = c.ho = make_real4((real)0., (real)0., (real)0., (real)0.);
       if (!c.skip) c.xi = ld4(xi + o_row + gc);
       if (!p.first && (!c.skip || p.xi_store)) c.ho = ld4(HVold + o_row + gc);
 #pragma unroll
-      for (int i = 0; i < 4; ++i) { c.ys[i] = 0.f; c.ins[i] = false; }
+      for (int i = 0; i < 4; ++i) { c.ys[i] = (real)0.; c.ins[i] = false; }
       if (row_in) {
         if (y4) {
           if (gc >= g.sw && gc < g.sw + g.W) {
-            const float4 yv = ld4(y + (gc - g.sw));
+            const real4 yv = ld4(y + (gc - g.sw));
             c.ys[0] = yv.x; c.ys[1] = yv.y; c.ys[2] = yv.z; c.ys[3] = yv.w;
             c.ins[0] = c.ins[1] = c.ins[2] = c.ins[3] = true;
           }
@@ -1495,51 +1359,48 @@ __global__ __launch_bounds__(NT, MINW) void k_admm_rows_fused(PlaneGeom g, AdmmS
       const int gc = 4 * q;
       const QuadX c = nxt;
       if (q + NT < n4) nxt = load_quadx(q + NT);
-      const float4 hv4 = c.hv, xi4 = c.xi, ho4 = c.ho;
-      const float* ys = c.ys;
+      const real4 hv4 = c.hv, xi4 = c.xi, ho4 = c.ho;
+      const real* ys = c.ys;
       const bool* ins = c.ins;
-      const float hvs[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, xis[4] = {xi4.x, xi4.y, xi4.z, xi4.w};
-      const float hos[4] = {ho4.x, ho4.y, ho4.z, ho4.w};
-      float xin[4], as[4];
+      const real hvs[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, xis[4] = {xi4.x, xi4.y, xi4.z, xi4.w};
+      const real hos[4] = {ho4.x, ho4.y, ho4.z, ho4.w};
+      real xin[4], as[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        float xiv = xis[i];
-        const float hv = hvs[i], yv = ys[i];
+        real xiv = xis[i];
+        const real hv = hvs[i], yv = ys[i];
         if (p.xiw && !ins[i]) {      // outside the window: a = mu1 HV, xi = mu1p (HV - HV_old) (stored on request only)
-          xin[i] = p.first ? 0.f : p.mu1p * (hv - hos[i]);
+          xin[i] = p.first ? (real)0. : p.mu1p * (hv - hos[i]);
           as[i] = p.mu1 * hv;
           continue;
         }
         if (!p.first) {
-          const float xo = (ins[i] ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
+          const real xo = (ins[i] ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
           xiv = xiv + p.mu1p * (hv - xo);
         }
-        const float xnew = (ins[i] ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
+        const real xnew = (ins[i] ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
         xin[i] = xiv;
         as[i] = p.mu1 * xnew - xiv;
       }
-      if (!c.skip || p.xi_store) st4(xi + o_row + gc, make_float4(xin[0], xin[1], xin[2], xin[3]));
+      if (!c.skip || p.xi_store) st4(xi + o_row + gc, make_real4(xin[0], xin[1], xin[2], xin[3]));
       s[lds_slot<SK>(2 * q)] = make_real2(as[0], as[1]);
       s[lds_slot<SK>(2 * q + 1)] = make_real2(as[2], as[3]);
     }
   }
   __syncthreads();
-#ifdef LPC_DEBUG_KNOBS   // timing experiments only (results are garbage): MINW == 2 skips the butterflies
-  if (MINW != 2)
-#endif
   fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
-  untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, (arr ? SB : SA) + pl * g.cplane + (long)gr * g.cpitch, tid);
+  untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, SB + pl * g.cplane + (long)gr * g.cpitch, tid);
 }
 
 // ---- paired forward rows with the X half computed on the fly (narrow frames: C1 / C4, 760 x 1014) ---------------
-// Same split of the image-domain work as k_admm_rows_fused<.., TVHALF = false>, for frames whose rows ride in pairs:
+// Same split of the image-domain work as k_rfwd_half_x, for frames whose rows ride in pairs:
 // row r of r_sp (stored by k_admm_spatial_v4<.., XHALF = false>) is the real part, and the imaginary part
 // a = mu1 X - xi' is formed element by element from xi, HV, HV_old and y inside the source functor of the first FFT
 // stage (which also stores xi').  Compile-time plans only.
 template <int NT, int EMAX, bool SK, class PL>
-__global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p, PL plan, const float* LPC_RESTRICT Rsp,
-                                                       const float* LPC_RESTRICT HV, const float* LPC_RESTRICT HVold,
-                                                       float* LPC_RESTRICT xi, const float* LPC_RESTRICT Y,
+__global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p, PL plan, const real* LPC_RESTRICT Rsp,
+                                                       const real* LPC_RESTRICT HV, const real* LPC_RESTRICT HVold,
+                                                       real* LPC_RESTRICT xi, const real* LPC_RESTRICT Y,
                                                        real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
@@ -1551,9 +1412,9 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p
   if (p.skipa && (int)blockIdx.x >= g.H) {
     bool v1;
     const int r0 = outside_pair_row(g, (int)blockIdx.x - g.H, v1);
-    const float* ra = Rsp + pl * g.rplane + (long)r0 * g.rpitch;
-    const float* rb = ra + g.rpitch;
-    auto two = [&](int i, int) { return make_real2(ra[i], v1 ? rb[i] : 0.f); };
+    const real* ra = Rsp + pl * g.rplane + (long)r0 * g.rpitch;
+    const real* rb = ra + g.rpitch;
+    auto two = [&](int i, int) { return make_real2(ra[i], v1 ? rb[i] : (real)0.); };
     fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, two, LdsNatural{});
     real2* o0 = SA + pl * g.cplane + (long)r0 * g.cpitch;
     untangle_store<NT, SK>(s, g.Wp, g.Wc, o0, o0 + g.cpitch, v1, tid);
@@ -1563,22 +1424,22 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p
   const long o_row = pl * g.rplane + (long)row * g.rpitch;
   const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
   const bool row_in = (row >= g.sh) && (row < g.sh + g.H);
-  const float* y = Y + (long)dpl * g.uplane + (long)(row - g.sh) * g.W;     // dereferenced only when row_in
+  const real* y = Y + (long)dpl * g.uplane + (long)(row - g.sh) * g.W;     // dereferenced only when row_in
   auto src = [&](int i, int) {
     const long o = o_row + i;
     const bool inside = row_in && (i >= g.sw) && (i < g.sw + g.W);
-    const float hv = HV[o];
+    const real hv = HV[o];
     if (p.xiw && !inside) {        // outside the sensor window (see AdmmScalars::xiw)
-      if (p.xi_store) xi[o] = p.first ? 0.f : p.mu1p * (hv - HVold[o]);
+      if (p.xi_store) xi[o] = p.first ? (real)0. : p.mu1p * (hv - HVold[o]);
       return make_real2(Rsp[o], p.mu1 * hv);
     }
-    const float yv = inside ? y[i - g.sw] : 0.f;
-    float xiv = xi[o];
+    const real yv = inside ? y[i - g.sw] : (real)0.;
+    real xiv = xi[o];
     if (!p.first) {
-      const float xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * HVold[o] + yv);   // previous X
+      const real xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * HVold[o] + yv);   // previous X
       xiv = xiv + p.mu1p * (hv - xo);
     }
-    const float xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
+    const real xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
     xi[o] = xiv;
     return make_real2(Rsp[o], p.mu1 * xnew - xiv);
   };
@@ -1586,8 +1447,6 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p
   untangle_store<NT, SK>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
                          SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
 }
-
-#endif  // !LPC_DOUBLE
 
 // ---- plug-and-play ADMM: the U-prox is an external denoiser (admm.py:126-133,235-243,266-275,300-311) ----------
 // Explicit state (U and eta are image-shaped, Psi^T is the identity), plain streaming kernels around the caller's

@@ -53,10 +53,9 @@ static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
-  return launch_k(e, LPC_K_ROW_FWD, k_admm_rows_fused<RNT, REM, RSK, 1, 1, RowPA, false>, dim3(2 * g.Hp, e->P), RNT,
-                  kRowSmem, g, *sc, row_arg(e), (const real2*)e->planW.tw, (const real*)nullptr, (const real*)e->Rsp,
-                  (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)nullptr,
-                  (const real*)nullptr, (real*)nullptr, (real*)nullptr, (real*)nullptr, (const real*)e->Y, SA, SB);
+  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_half_x<RNT, REM, RSK, RowPA>, dim3(2 * g.Hp, e->P), RNT, kRowSmem, g, *sc,
+                  row_arg(e), (const real2*)e->planW.tw, (const real*)e->Rsp, (const real*)e->HVb[e->hcur],
+                  (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->Y, SA, SB);
 }
 #endif
 #else   // gradient-descent family

@@ -70,6 +70,7 @@ class ShardedReconstructor:
         self._turn ^= 1
         if self._recv[self._turn] is None or tuple(self._recv[self._turn].shape) != (world * cap, D, H, W, C):
             self._recv[self._turn] = torch.empty((world * cap, D, H, W, C), dtype=rec._tdtype, device=dev)
+        if getattr(self, "_send", None) is None or tuple(self._send.shape) != (cap, D, H, W, C):
             self._send = torch.empty((cap, D, H, W, C), dtype=rec._tdtype, device=dev)
         recv, send = self._recv[self._turn], self._send
         if hi > lo:                               # (more ranks than frames: such a rank only takes part in the gather)

@@ -173,12 +173,16 @@ def test_channel_broadcast_rules(backend):
     cv1 = lpa.RealFFTConvolve2D(psf1, pad=True)
     with pytest.raises(ValueError, match="broadcast"):
         cv1.convolve(np.repeat(x1, 3, axis=-1))
-    cvn = lpa.RealFFTConvolve2D(psf1, pad=False)
+    # the un-padded operator broadcasts 3 -> 1 in the reference's torch branch only (`rfft2(x) * H`); its NumPy branch
+    # writes into a (..., 1) scratch buffer (rfft_convolve.py:143) and raises
+    cvn = lpa.RealFFTConvolve2D(torch.from_numpy(psf1), pad=False)
     xp = rng.standard_normal([2] + cvn._padded_shape[:3] + [3]).astype(np.float32)
-    full = cvn.convolve(xp)
-    assert full.shape == xp.shape
+    full = cvn.convolve(torch.from_numpy(xp))
+    assert tuple(full.shape) == xp.shape
     for c in range(3):
-        assert np.array_equal(full[..., c:c + 1], cvn.convolve(np.ascontiguousarray(xp[..., c:c + 1])))
+        assert torch.equal(full[..., c:c + 1], cvn.convolve(torch.from_numpy(np.ascontiguousarray(xp[..., c:c + 1]))))
+    with pytest.raises(ValueError, match="broadcast"):
+        lpa.RealFFTConvolve2D(psf1, pad=False).convolve(xp)
     with pytest.raises(ValueError, match="spatial size"):
         cv3.convolve(np.zeros((1, 1, 13, 16, 3), np.float32))
     # the C ABI itself refuses a channel count it cannot read safely

@@ -353,7 +353,8 @@ def test_forced_four_step_column_split(backend, monkeypatch, h, hp, n2):
 
 
 @pytest.mark.parametrize("static", [False, True], ids=["runtime_plan", "plan_module"])
-@pytest.mark.parametrize("name", ["admm_24x32x3_tv", "admm_47x29x3_tv", "admm_24x32x3_init_bg", "admm_24x32x3_default"])
+@pytest.mark.parametrize("name", ["admm_24x32x3_tv", "admm_47x29x3_tv", "admm_24x32x3_init_bg", "admm_24x32x3_default",
+                                  "admm_24x32x1_f64"])
 def test_admm_half_length_row_kernels(backend, monkeypatch, name, static):
     """ADMM's row passes switch to one real row per half-length complex transform for wide frames only; the option
     rows_half=1 forces them on the golden-vector sizes (row transforms of 32 and 30 points, the second one without the
@@ -604,6 +605,24 @@ def test_c4_sequential_middle_on_one_frame(backend, monkeypatch):
     _admm_fista_vs_oracle(270, 480, 1, (540, 960), n_admm=2, n_fista=1)
     psf = orc.synthetic_psf(1, 270, 480, 1, seed=1)
     assert "T = 16" in lpa.ADMM(torch.from_numpy(psf))._handle.plan_info()
+
+
+def test_c4_sequential_middle_frames_fastest_block_order(backend):
+    """The sequential middle hands its workgroups out frames-fastest (all frames of a batch share H and |G|: one XCD's L2
+    serves a column tile of them to the frames it owns).  A batch of 3 colour frames -- 3 frames x 3 PSF planes x 31
+    column tiles, none of them a power of two -- must equal the single-frame runs of the same plan bit for bit."""
+    rng = np.random.default_rng(31)
+    psf = torch.from_numpy(orc.synthetic_psf(1, 270, 480, 3, seed=2))
+    ys = torch.from_numpy(rng.random((3, 1, 270, 480, 3), dtype=np.float32))
+    opts = {"mid_seq": 1, "prow_nt128": 1, "jit_min_points": 0}
+    rec = lpa.ADMM(psf, engine_options=opts)
+    rec.set_data(ys)
+    assert "one spectrum at a time" in rec._handle.plan_info()
+    got = rec.apply_batch(n_iter=2)
+    single = lpa.ADMM(psf, engine_options=opts)
+    for b in range(3):
+        single.set_data(ys[b, 0])
+        assert torch.equal(single.apply(n_iter=2, disp_iter=None), got[b]), b
 
 
 def test_c4_rows_on_128_threads(backend, monkeypatch):

@@ -2,9 +2,12 @@
 """Condense rocprofv3 outputs (gpurun_out/prof_*) into the tracked profiles/ directory.
 
 usage: tools/summarize_prof.py <round-tag> [gpurun_out]
-Writes profiles/<tag>_kernel_stats.csv (verbatim --stats summary), profiles/<tag>_counters.md and,
-for the ADMM prox/update kernel, profiles/k1_traffic.json (HBM bytes per launch from the PMC
-passes: FETCH_SIZE is doubled as MI355X_MICROARCH.md section HBM prescribes for gfx950, units KiB).
+Writes profiles/<tag>_kernel_stats.csv (verbatim --stats summary), profiles/<tag>_counters.md and merges the HBM
+traffic per launch of every hot-loop kernel into profiles/traffic.json, keyed by the plan module the profiled run used
+(HBM bytes = (2 * FETCH_SIZE + WRITE_SIZE) KiB: FETCH_SIZE is doubled as MI355X_MICROARCH.md section HBM prescribes for
+gfx950).  Per-dispatch values are condensed with the MEDIAN: the profiled command is a 40-iteration call after a
+40-iteration warm-up, so 72 of the 80 dispatches of a hot-loop kernel are steady-state ones (the first iteration of a
+call skips V_old, the last three run without the sensor-window skips) and the median is their value.
 """
 import collections
 import csv
@@ -41,7 +44,8 @@ for d in sorted(glob.glob(os.path.join(src, "prof_*"))):
             meta[k] = (r["Workgroup_Size"], r["LDS_Block_Size"], r["VGPR_Count"], r["SGPR_Count"])
 
 lines = [f"# rocprofv3 PMC summary ({tag})", "",
-         "Separate `--pmc` passes (FETCH_SIZE | WRITE_SIZE | SQ_*), `bench.py --n-iter 4`, mean per dispatch.",
+         "Separate `--pmc` passes (FETCH_SIZE | WRITE_SIZE | SQ_* | TCC_*), `bench.py --n-iter 40 --steps 1 --warmup 1`, MEDIAN per "
+         "dispatch (= the steady-state iterations of a call: 72 of 80 dispatches).",
          "FETCH_SIZE / WRITE_SIZE are KiB; `HBM GB` = (2*FETCH_SIZE + WRITE_SIZE) KiB (gfx950 correction, guide section HBM).", ""]
 cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY",
         "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VALU", "SQ_LDS_IDX_ACTIVE", "SQ_LDS_BANK_CONFLICT", "TCC_HIT_sum", "TCC_MISS_sum"]
@@ -52,7 +56,7 @@ for k in sorted(agg):
     if not k.startswith("k_"):
         continue
     d = agg[k]
-    mean = {c: (sum(v) / len(v) if v else None) for c, v in d.items()}
+    mean = {c: (sorted(v)[len(v) // 2] if v else None) for c, v in d.items()}      # median, see the docstring
     n = max(len(v) for v in d.values())
     hbm = None
     if mean.get("FETCH_SIZE") is not None and mean.get("WRITE_SIZE") is not None:
@@ -63,12 +67,41 @@ for k in sorted(agg):
                  f"| {k} | {wg} | {lds} | {vg} | {sg} | {n} | - | ")
     lines[-1] += " | ".join(f"{mean[c]:.3g}" if mean.get(c) is not None else "-" for c in cols) + " |"
 open(os.path.join(out, f"{tag}_counters.md"), "w").write("\n".join(lines) + "\n")
-for k, v in traffic.items():
-    # LPC_K_SPATIAL: the tiled kernel; only when the whole image-domain work is fused into the rows (LPC_FUSE_ROWS) is
-    # it k_admm_rows_fused (which otherwise is the forward row kernel carrying the X half)
-    if k.startswith("k_admm_spatial") or (k.startswith("k_admm_rows_fused") and not any(
-            q.startswith("k_admm_spatial") for q in traffic)):
-        json.dump({"kernel": k, "hbm_bytes_per_launch": v, "source": f"profiles/{tag}_counters.md", "snapshot": tag,
-                   "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes"},
-                  open(os.path.join(out, "k1_traffic.json"), "w"), indent=1)
+
+
+def kid_of(k):
+    """hot-loop kernel name -> bench.py's kernel id (lpc_kernel_id); None for set-up / layout kernels"""
+    if k.startswith("k_admm_spatial"):
+        return "spatial"
+    if k.startswith(("k_admm_rows_fused", "k_rfwd_arrays_x")) or (k.startswith(("k_rfwd_half", "k_rfwd_arrays")) and "SPlan" in k):
+        return "row_fwd"
+    if k.startswith(("k_rinv_half", "k_rinv_arrays")) and "SPlan" in k:
+        return "row_inv"
+    if k.startswith("k_cols_mid_admm"):
+        return "col_mid"
+    if k.startswith("k_cols<") and "SPlan" in k:
+        return "col_a_inv" if k.split(",")[2].strip() == "true" else "col_a_fwd"
+    return None
+
+
+bench_json = os.path.join(src, "prof_bench.json")
+plan = None
+if os.path.exists(bench_json):
+    for ln in open(bench_json):
+        if ln.startswith("{"):
+            bj = json.loads(ln)
+            plan = bj.get("engine_plan", "")
+            workload = bj.get("config", {}).get("workload", "")
+if plan and "plan module " in plan:
+    key = plan.split("plan module ")[1].strip()
+    entry = {"plan_module": key, "workload": workload, "snapshot": tag, "n_iter": 40, "source": f"profiles/{tag}_counters.md",
+             "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, median per dispatch", "kernels": {}}
+    for k, v in traffic.items():
+        kid = kid_of(k)
+        if kid:
+            entry["kernels"][kid] = {"kernel": k, "hbm_bytes_per_launch": v}
+    tf = os.path.join(out, "traffic.json")
+    tj = json.load(open(tf)) if os.path.exists(tf) else {"plans": []}
+    tj["plans"] = [e for e in tj["plans"] if e.get("plan_module") != key] + [entry]
+    json.dump(tj, open(tf, "w"), indent=1)
 print("\n".join(lines))
