@@ -623,15 +623,15 @@ def main():
                 parity["full_size_psnr_delta_db"] = d
                 del t64
                 # (4) the headline call itself: n_iter iterations in one call (all but four on the steady-state path of
-                # the launch plan) vs the float64 build of the engine (no window structure; anchored to the float64
-                # oracle by tests/test_parity_fullsize.py), default and TV-active parameters
+                # the launch plan) vs the float64 build of the engine with the window structure switched off (anchored
+                # to the float64 oracle by tests/test_parity_fullsize.py), default and TV-active parameters
                 for tag, kw in (("defaults", {}), ("tv_active", tv)):
                     if kw is None:
                         continue
                     r32 = rec if not kw else lpa.ADMM(psf, **kw)
                     r32.set_data(y)
                     g32 = r32.apply(n_iter=n_iter, disp_iter=None)
-                    r64 = lpa.ADMM(psf.double(), dtype="float64", **kw)
+                    r64 = lpa.ADMM(psf.double(), dtype="float64", engine_options={"hv_full": 1, "xi_full": 1}, **kw)
                     r64.set_data(y.double())
                     e, d = rel_psnr(g32, r64.apply(n_iter=n_iter, disp_iter=None))
                     parity[f"full_size_{n_iter}it_vs_float64_build_{tag}"] = {"rel_err": e, "psnr_delta_db": d}

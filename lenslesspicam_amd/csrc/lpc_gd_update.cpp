@@ -1,13 +1,17 @@
-// lpc_gd_update.cpp -- launches of the gradient-descent update rows (own translation unit: the device compiler works on
-// the units in parallel, and this kernel family is the longest to compile)
+// lpc_gd_update.cpp -- launches of the gradient-descent update rows.  This kernel family is the longest to compile (the
+// fused momentum / projection update behind an inverse row transform, one instantiation per workgroup shape), so it is
+// spread over three translation units that the device compiler works on in parallel: this one (one real row per
+// half-length transform) and lpc_gd_update_p0.cpp / lpc_gd_update_p1.cpp (paired rows without / with the folded radix-2
+// stage).
 #include "lpc_engine.h"
 #include "lpc_gd_kernels.h"
+
+int gd_rows_update_paired_r2(Engine* e, const GdScalars& sc, const real* alpha);   // lpc_gd_update_p1.cpp
+int gd_rows_update_paired_plain(Engine* e, const GdScalars& sc, const real* alpha);   // lpc_gd_update_p0.cpp
 
 // spectrum rows of the gradient (e->S2) -> irfft -> shift + crop -> fused momentum / projection update of x
 int gd_rows_update(Engine* e, const GdScalars& sc, const real* alpha) {
   const PlaneGeom& g = e->g;
-  const int nblk = (g.H + 1) / 2;
-  const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;
   if (e->mod && e->mod->gd_rows_update) return e->mod->gd_rows_update(e, &sc, alpha);
   if (e->rows_half)
     return dispatch_row(g.Wp / 2, e->planWh.skew_ok, false, [&](auto NTc, auto EM, auto SK, auto) {
@@ -17,12 +21,7 @@ int gd_rows_update(Engine* e, const GdScalars& sc, const real* alpha) {
                       LPC_ROW_SMEM_BYTES(g.Wp / 2, sk), g, e->planWh, e->planW.tw, (const real2*)e->S2, e->gx,
                       e->gaux, alpha, sc);
     });
-  return dispatch_row(g.Wp, pinv.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
-    constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
-    constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
-    return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update<nt, em, sk, r2>, dim3(nblk, e->P), nt,
-                    LPC_ROW_SMEM_BYTES(g.Wp, sk), g, pinv, (const real2*)e->S2, e->gx, e->gaux, alpha, sc);
-  });
+  return e->rows_r2 ? gd_rows_update_paired_r2(e, sc, alpha) : gd_rows_update_paired_plain(e, sc, alpha);
 }
 
 // the same + the forward row transform of the updated rows (e->S2 -> x, e->S): compile-time half-row plans only

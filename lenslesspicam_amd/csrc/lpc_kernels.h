@@ -851,7 +851,7 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
                                                            real2* LPC_RESTRICT SB, const real2* LPC_RESTRICT Hs,
                                                            const real* LPC_RESTRICT Gabs, const real2* LPC_RESTRICT phr,
                                                            const real2* LPC_RESTRICT phc, real mu1, real mu2, real mu3,
-                                                           real rscale, real sb_outside_scale) {
+                                                           real rscale, real sb_outside_scale, int tiles_first) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
@@ -862,8 +862,13 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   // XCD's L2 fetches that tile of H / |G| from HBM once and serves it to the frames it owns.  (With the tile index
   // fastest, the 64 frames of C4 re-read H 64 times: PMC traffic 2.29 GB per launch against 1.60 GB algorithmic.)
   const int nfr = (int)(gridDim.x / (unsigned)(cp.ntile_c * g.DC));       // frames
-  const int fr = (int)(blockIdx.x % (unsigned)nfr), rest = (int)(blockIdx.x / (unsigned)nfr);
-  const int tile = rest % cp.ntile_c, pp = rest / cp.ntile_c;             // column tile, PSF plane
+  int fr = (int)(blockIdx.x % (unsigned)nfr), rest = (int)(blockIdx.x / (unsigned)nfr);
+  int tile = rest % cp.ntile_c, pp = rest / cp.ntile_c;                   // column tile, PSF plane
+  if (tiles_first) {     // A/B option seq_tiles_first: column tiles fastest, then planes (the order of round 2)
+    tile = (int)(blockIdx.x % (unsigned)cp.ntile_c);
+    const int q = (int)(blockIdx.x / (unsigned)cp.ntile_c);
+    fr = q / g.DC; pp = q % g.DC;
+  }
   const long pl = (long)fr * g.DC + pp;
   const int c0 = tile * T;
   real2* ba = SA + pl * g.cplane + c0;

@@ -139,7 +139,7 @@ static int m_admm_mid(Engine* e, const ColPass* cp, const AdmmScalars* sc, real 
   return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, true>,
                   dim3(cp->ntile_c * e->P), NT, (size_t)MidP::n * (T + 1) * sizeof(real2), g, pa, *cp, SA, SB,
                   (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, sc->mu1,
-                  sc->mu2, sc->mu3, rscale, sb_outside_scale);
+                  sc->mu2, sc->mu3, rscale, sb_outside_scale, e->opt.seq_tiles_first);
 #else                                   // both spectra side by side: [N][2 T]
   const FastDiv t2 = make_fastdiv((unsigned)(2 * T));
   return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<NT, EM, MidPA, 2 * T, true>, dim3(cp->G * cp->ntile_c, e->P), NT,

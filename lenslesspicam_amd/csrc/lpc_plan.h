@@ -111,6 +111,7 @@ struct EngineOpts {
   int mid_seq = -1;           // single-pass ADMM middle: -1 by batch size; 1 one spectrum at a time; 0 side by side
   int mid_lds = 0;            // no register-resident middles
   int prow_nt128 = -1;        // short paired rows on 128 threads: -1 by batch size
+  int seq_tiles_first = 0;    // sequential middle: workgroups handed out column tiles fastest instead of frames fastest
   int hv_full = 0;            // every row of H V transformed in every iteration
   int xi_full = 0;            // xi kept on the whole padded frame
   int no_xhalf = 0;           // stand-alone image-domain kernel (no X half inside the forward rows)
@@ -146,6 +147,7 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "mid_seq") o.mid_seq = (int)iv;
       else if (k == "mid_lds") o.mid_lds = (int)iv;
       else if (k == "prow_nt128") o.prow_nt128 = (int)iv;
+      else if (k == "seq_tiles_first") o.seq_tiles_first = (int)iv;
       else if (k == "hv_full") o.hv_full = (int)iv;
       else if (k == "xi_full") o.xi_full = (int)iv;
       else if (k == "no_xhalf") o.no_xhalf = (int)iv;

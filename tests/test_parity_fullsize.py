@@ -59,6 +59,9 @@ def c2_inputs():
     return psf, scene, y.cpu().numpy()
 
 
+PLAIN = {"hv_full": 1, "xi_full": 1}     # launch plan without the sensor-window structure (include/lpc.h)
+
+
 @pytest.fixture(scope="module")
 def c2_tv_params(c2_inputs):
     """TV-active hyper-parameters at 12 MP.  The soft-threshold branch must be LIVE within 5 iterations: with a
@@ -107,10 +110,10 @@ def test_c2_admm_5_iterations_vs_float64_oracle(c2_inputs, c2_tv_params, tv_acti
 
 
 def test_c2_float64_build_vs_float64_oracle(c2_inputs, c2_tv_params):
-    """Anchor of the long comparisons below: the float64 build (liblpc_f64.so: scalar image-domain kernel, xi and H V
-    on the whole padded frame) against the float64 oracle, 12 MP, 5 iterations, TV-active."""
+    """Anchor of the long comparisons below: the float64 build (liblpc_f64.so) with xi and H V on the whole padded frame
+    (options xi_full, hv_full: no sensor-window structure) against the float64 oracle, 12 MP, 5 iterations, TV-active."""
     psf, _, y = c2_inputs
-    rec = lpa.ADMM(torch.from_numpy(psf).cuda().double(), dtype="float64", **c2_tv_params)
+    rec = lpa.ADMM(torch.from_numpy(psf).cuda().double(), dtype="float64", engine_options=PLAIN, **c2_tv_params)
     assert "xi inside the sensor window" not in rec._handle.plan_info()
     rec.set_data(torch.from_numpy(y).cuda().double())
     got = rec.apply(n_iter=5, disp_iter=None).cpu().numpy()
@@ -127,7 +130,8 @@ def test_c2_float64_build_vs_float64_oracle(c2_inputs, c2_tv_params):
 def test_c2_admm_100_iterations_in_one_call(c2_inputs, c2_tv_params, tv_active):
     """BASELINE.json's headline is 100 iterations; inside one lpc_iterate() call iterations 2 ... 97 run with the sensor-
     window structure (AdmmScalars::skipa / skiphv / xiw), the last three complete.  Compare that call with (i) the same
-    engine with the structure off (<= 5e-5 of max|ref|) and (ii) the float64 build (<= 3e-4), <= 0.01 dB of PSNR vs the scene
+    engine with the structure off (<= 5e-5 of max|ref|) and (ii) the float64 build with the structure off (<= 3e-4;
+    and the float64 build with the structure ON agrees with it to 1e-9), <= 0.01 dB of PSNR vs the scene
     (north_star: "PSNR within 0.01 dB of reference" on 100-iteration ADMM at 4056x3040x3; reference loop
     lensless/recon/recon.py:575-576 over admm.py:313-338)."""
     psf, scene, y = c2_inputs
@@ -148,10 +152,17 @@ def test_c2_admm_100_iterations_in_one_call(c2_inputs, c2_tv_params, tv_active):
     assert "H V row transforms skipped" in info and "plan module" in info, info
     if tv_active:
         assert 0.02 < nz < 0.999, nz                           # the soft-threshold branch is still live after 100
-    full, info_full, _ = run(engine_options={"hv_full": 1, "xi_full": 1})
+    full, info_full, _ = run(engine_options=PLAIN)
     assert "xi inside the sensor window" not in info_full, info_full
-    f64, info64, _ = run(dtype="float64")
+    f64, info64, _ = run(dtype="float64", engine_options=PLAIN)
     assert "xi inside the sensor window" not in info64, info64
+    # the structure is exact in real arithmetic: in float64 the call with it and the call without it agree to ~1e-12
+    f64s, info64s, _ = run(dtype="float64")
+    assert "H V row transforms skipped" in info64s, info64s
+    e_id = rel(f64s, f64)
+    print(f"C2 ADMM-100 float64, window structure on vs off: {e_id:.2e}")
+    assert e_id <= 1e-9, e_id
+    del f64s
     p = {k: orc.psnr(v[0].astype(np.float32), scene) for k, v in (("got", got), ("full", full), ("f64", f64))}
     e_full, e_64 = rel(got, full), rel(got, f64)
     print(f"C2 ADMM-100 {kw or 'defaults'}: vs structure-off {e_full:.2e} ({p['got'] - p['full']:+.2e} dB), "
