@@ -320,11 +320,12 @@ def default_lib(dtype: str = "float32") -> Lib:
             )
         torch.cuda.init()
         path = DEFAULT_LIB_F64 if dtype == "float64" else DEFAULT_LIB
-        if not os.path.exists(path):
-            # fresh checkout on a GPU box (the .so is git-ignored): compile the HIP sources once, in-tree.
-            # This builds the product library itself -- there still is no other execution path.
-            from . import build as _build
+        from . import build as _build
 
+        if _build.is_stale():
+            # fresh checkout on a GPU box (the .so is git-ignored), or sources edited since the last build: compile the
+            # HIP sources in-tree before anything runs -- never a library that does not match the sources next to it.
+            # This builds the product library itself; there still is no other execution path.
             _build.build_hip(force=True, verbose=False)
         lib = Lib(path)
         if not lib.backend().startswith("hip"):

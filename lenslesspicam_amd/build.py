@@ -43,9 +43,15 @@ def fingerprint():
     return h.hexdigest()[:12]
 
 
+FP_FILE = os.path.join(HERE, "_lib", "BUILD_FP")
+
+
 def is_stale():
-    return any(not os.path.exists(o) or any(os.path.getmtime(f) > os.path.getmtime(o) for f in sources())
-               for o in (OUT, OUT_F64))
+    """the libraries are missing, or were built from other sources than the ones in the tree (by content, not by
+    modification time: a snapshot copied to another machine must not look stale, an edited header must)"""
+    if not (os.path.exists(OUT) and os.path.exists(OUT_F64) and os.path.exists(FP_FILE)):
+        return True
+    return open(FP_FILE).read().strip() != fingerprint()
 
 
 def build_hip(force=False, verbose=True):
@@ -80,6 +86,7 @@ def build_hip(force=False, verbose=True):
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+    open(FP_FILE, "w").write(fp + "\n")
     if os.path.isdir(MODULES):                               # modules of other sources are dead weight in the snapshot
         for f in os.listdir(MODULES):
             if f.startswith("lpcmod_") and f"_{fp}_" not in f:

@@ -197,8 +197,12 @@ static void choose_plan(Engine* e, bool allow_static) {
   // of a 256-thread group idle.
   // The gradient-descent family switches earlier (its irfft -> residual -> rfft kernel runs two transforms per
   // workgroup): 2048 columns FISTA +6.8 %, ADMM -1 %.
+  // ... and with compile-time plans at every even width: its paired-row kernels exist on run-time plans only, and a
+  // half-length transform on its own plan beats them (same-box A/B, profiles/r03_notes.md: FISTA 270x480x3 3.85 -> 3.35 ms
+  // per 60 iterations, 380x507x3 4.40 -> 3.75 ms).  ADMM keeps the size rule with either kind of plan (540 x 960: paired
+  // 0.298 vs half 0.311 ms per 5 iterations; 768 x 1024: 0.374 vs 0.364; 3072 x 4096: paired 43.6 vs half 44.6 ms per 50).
   const bool half_ok = g.Wp % 2 == 0 && g.Wp >= 4;
-  const bool wide = admm ? 5 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024 : g.Wp >= 2048;
+  const bool wide = admm ? 5 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024 : (g.Wp >= 2048 || (allow_static && g.Wp >= 128));
   e->rows_half = half_ok && wide;
   if (o.rows_half == 0) e->rows_half = false;
   if (o.rows_half == 1 && half_ok) e->rows_half = true;
