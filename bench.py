@@ -492,7 +492,8 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("LPC_K_SPATIAL = ADMM prox / dual-update kernel; split of the image-domain work: "
-                           + rec._handle.plan_info().split(";")[-1].strip()) if args.algo == "admm"
+                           + next((p.strip() for p in rec._handle.plan_info().split(";") if "image-domain" in p or "TV / W" in p),
+                                  "")) if args.algo == "admm"
                 else "k_rinv_gd_update (inverse rows + fused projected update)",
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),

@@ -86,6 +86,10 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
                                sc.skipa ? sc.mu1 * (real)g.Wp : (real)0.));
   {
     ColPass cp = e->passB;
+    // pairs of column tiles on one XCD: measured (profiles/r03_notes.md) -6 % on the 5-iteration C1 call, whose 8-column
+    // tiles read half cache lines (middle 0.0278 -> 0.0228 ms); at 12 MP (16 columns = whole lines) it removes a third of
+    // the middle's excess HBM reads (2.44 -> 2.28 GB against 1.91 GB asked for) but runs 3 % slower -- off there
+    cp.swz = e->opt.mid_swz >= 0 ? e->opt.mid_swz : ((size_t)cp.T * sizeof(real2) < 128 ? 1 : 0);
     const dim3 grid(cp.G * cp.ntile_c, e->P);
     const FastDiv t2 = make_fastdiv((unsigned)(2 * cp.T));
     auto reg_mid = [&](auto kernel) {

@@ -360,6 +360,7 @@ static int setup_geometry(Engine* e) {
   A.tw_mode = 0; A.zr0 = 0; A.zr1 = g.Hp; A.twH = e->twH; A.need0 = 0; A.needn = g.Hp;
   A.sc_plane0 = INT_MAX; A.sc_r0 = 0; A.sc_r1 = g.Hp; A.sc = (real)1.;
   A.tdiv = make_fastdiv((unsigned)e->T); A.tcdiv = make_fastdiv((unsigned)ntc);
+  A.swz = 0;
   ColPass& B = e->passB;
   B = A;
   B.N = e->N2; B.G = e->N1; B.istride = 1; B.gstride = e->N2;
@@ -601,6 +602,12 @@ static int admm_iterate(Engine* e, int n_iter) {
 
 #include "lpc_gd_engine.inc"
 
+// process-wide defaults from the environment first (the ONE launch-plan variable the library reads), then the handle's own
+static std::string parse_all_opts(const char* handle_opts, EngineOpts& o) {
+  std::string err = parse_engine_opts(std::getenv("LPC_OPTIONS"), o);
+  return err.empty() ? parse_engine_opts(handle_opts, o) : err;
+}
+
 // =============================================================================== C ABI ==
 extern "C" {
 
@@ -623,8 +630,7 @@ int lpc_create(const lpc_config* cfg, lpc_handle* out) {
   e->cfg = *cfg;
   e->cfg.options = nullptr;            // (the caller's string is not kept)
   {   // process-wide defaults from the environment first, then the handle's own
-    std::string err = parse_engine_opts(std::getenv("LPC_OPTIONS"), e->opt);
-    if (err.empty()) err = parse_engine_opts(cfg->options, e->opt);
+    std::string err = parse_all_opts(cfg->options, e->opt);
     if (!err.empty()) { delete e; return fail("lpc_create: " + err); }
   }
   e->tk = cfg->fista_tk; e->nest_mu = cfg->nesterov_mu; e->nest_p = cfg->nesterov_p;
@@ -657,8 +663,7 @@ int lpc_plan_module(const lpc_config* cfg, int build, char* key_buf, size_t n) {
   if (cfg->height < 1 || cfg->width < 1 || cfg->depth < 1 || cfg->batch < 1) return fail("lpc_plan_module: bad size");
   Engine tmp;
   tmp.cfg = *cfg;
-  std::string err = parse_engine_opts(std::getenv("LPC_OPTIONS"), tmp.opt);
-  if (err.empty()) err = parse_engine_opts(cfg->options, tmp.opt);
+  std::string err = parse_all_opts(cfg->options, tmp.opt);
   if (!err.empty()) return fail("lpc_plan_module: " + err);
   bool want_static = false;
   LPC_OK(setup_shape(&tmp, &want_static));

@@ -10,6 +10,7 @@
 // with sizeof(lpc_engine).  Concurrent builders (one process per GPU) write to private temporaries and rename.
 #include "lpc_engine.h"
 
+#include <cerrno>
 #include <dlfcn.h>
 #include <sys/stat.h>
 #include <sys/types.h>
@@ -64,10 +65,8 @@ static std::vector<std::string> module_dirs(const EngineOpts& opt) {
   if (!opt.module_dir.empty()) d.push_back(opt.module_dir);
   const std::string self = self_path();
   if (!self.empty()) d.push_back(dir_of(self) + "/modules");
-  const char* xdg = std::getenv("XDG_CACHE_HOME");
-  const char* home = std::getenv("HOME");
-  if (xdg && *xdg) d.push_back(std::string(xdg) + "/lenslesspicam_amd");
-  else if (home && *home) d.push_back(std::string(home) + "/.cache/lenslesspicam_amd");
+  const char* home = std::getenv("HOME");          // a read-only installation still gets its modules: per-user cache
+  if (home && *home) d.push_back(std::string(home) + "/.cache/lenslesspicam_amd");
   return d;
 }
 

@@ -472,6 +472,11 @@ struct ColPass {
   real sc;
   FastDiv tdiv;     // fast divide by T
   FastDiv tcdiv;    // fast divide by ntile_c
+  // ADMM LDS middle: hand the workgroups out so that two adjacent column tiles run on the SAME XCD (block b runs on XCD
+  // b % 8): within every 16 consecutive blocks, block 8 s + x takes tile 2 x + s.  With 8-column tiles (64-byte row
+  // segments: single-pass columns of one DiffuserCam-sized frame) the two tiles share every cache line, and on one L2 the
+  // second one's loads are hits.
+  int swz;
 };
 
 // plain pass over ONE spectrum array, in place (global -> registers -> [LDS] -> registers -> global)
@@ -769,8 +774,10 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
   const int T = cp.T, T2 = 2 * cp.T;
-  const int grp = (int)fd_div(blockIdx.x, cp.tcdiv);
-  const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * T;
+  unsigned bid = blockIdx.x;
+  if (cp.swz && bid < (gridDim.x & ~15u)) bid = (bid & ~15u) + ((bid & 7u) << 1) + ((bid >> 3) & 1u);   // ColPass::swz
+  const int grp = (int)fd_div(bid, cp.tcdiv);
+  const int c0 = ((int)bid - grp * cp.ntile_c) * T;
   const long rowoff = ((long)grp * cp.gstride) * g.cpitch + c0;
   real2* ba = SA + (long)blockIdx.y * g.cplane + rowoff;
   real2* bb = SB + (long)blockIdx.y * g.cplane + rowoff;

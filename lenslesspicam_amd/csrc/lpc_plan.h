@@ -112,6 +112,8 @@ struct EngineOpts {
   int mid_lds = 0;            // no register-resident middles
   int prow_nt128 = -1;        // short paired rows on 128 threads: -1 by batch size
   int seq_tiles_first = 0;    // sequential middle: workgroups handed out column tiles fastest instead of frames fastest
+  int mid_swz = -1;           // side-by-side LDS middle: pairs of column tiles on one XCD (ColPass::swz); -1: when a tile
+                              // row is narrower than a 128-byte line
   int hv_full = 0;            // every row of H V transformed in every iteration
   int xi_full = 0;            // xi kept on the whole padded frame
   int no_xhalf = 0;           // stand-alone image-domain kernel (no X half inside the forward rows)
@@ -148,6 +150,7 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "mid_lds") o.mid_lds = (int)iv;
       else if (k == "prow_nt128") o.prow_nt128 = (int)iv;
       else if (k == "seq_tiles_first") o.seq_tiles_first = (int)iv;
+      else if (k == "mid_swz") o.mid_swz = (int)iv;
       else if (k == "hv_full") o.hv_full = (int)iv;
       else if (k == "xi_full") o.xi_full = (int)iv;
       else if (k == "no_xhalf") o.no_xhalf = (int)iv;

@@ -223,11 +223,19 @@ def test_unusual_shapes_against_oracle(shape):
     assert rel(cv.convolve(x.cuda()), oc.convolve(x)) <= 5e-6
     assert rel(cv.deconvolve(x.cuda()), oc.deconvolve(x)) <= 5e-6
     rec = lpa.ADMM(torch.from_numpy(psf).cuda(), tau=2e-6, mu2=1e-4)
+    # none of these shapes is on anybody's list: each gets its compile-time-plan kernels from a plan module built on
+    # first use (no silent drop to the run-time plans), and wherever the padded width is a multiple of 4 the X half, the
+    # xi window and the H V skip follow
+    info = rec._handle.plan_info()
+    assert "plan module" in info and "[static" in info, info
+    if rec._padded_shape[2] % 4 == 0:
+        assert "row transforms skipped" in info, info
     rec.set_data(torch.from_numpy(y).cuda())
     o64 = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
     o64.set_data(y)
     assert rel(rec.apply(n_iter=4, disp_iter=None), o64.apply(4)) <= 1e-5
     f = lpa.FISTA(torch.from_numpy(psf).cuda())
+    assert "plan module" in f._handle.plan_info() or rec._padded_shape[2] % 2 == 1, f._handle.plan_info()
     f.set_data(torch.from_numpy(y).cuda())
     of = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
     of.set_data(y)

@@ -625,6 +625,22 @@ def test_c4_sequential_middle_frames_fastest_block_order(backend):
         assert torch.equal(single.apply(n_iter=2, disp_iter=None), got[b]), b
 
 
+def test_middle_tile_pairs_on_one_xcd(backend):
+    """Option mid_swz: the side-by-side LDS middle hands its workgroups out so that the two 128-byte column tiles of a
+    256-byte pair run on the same XCD (ColPass::swz) -- a permutation of the block order, so the result must be bit for
+    bit the default order's.  61 column tiles x 2 planes: full groups of 16 and a tail that keeps the natural order."""
+    rng = np.random.default_rng(41)
+    psf = torch.from_numpy(orc.synthetic_psf(2, 270, 480, 1, seed=3))
+    y = torch.from_numpy(rng.random((270, 480, 1), dtype=np.float32))
+    outs = []
+    for swz in (0, 1):
+        rec = lpa.ADMM(psf, engine_options={"mid_swz": swz})
+        assert "LDS middle [static" in rec._handle.plan_info()
+        rec.set_data(y)
+        outs.append(rec.apply(n_iter=2, disp_iter=None, plot=False))
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_c4_rows_on_128_threads(backend, monkeypatch):
     """960-point paired rows of a large batch run on 128 threads x 8 points (every lane owns one radix-8 butterfly of
     the fused first stage); the option prow_nt128 forces that shape onto one frame.  Same plan, same arithmetic: the result
