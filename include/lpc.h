@@ -88,6 +88,7 @@ typedef struct lpc_config {
  *   mid_swz=0|1        side-by-side middle: adjacent column tiles on one XCD (default: when a tile row is < 128 bytes)
  *   xi_full=1 hv_full=1 no_xhalf=1 k1_scalar=1      ADMM without the sensor-window structure of xi / of the H V row
  *                      transforms; with the stand-alone image-domain kernel; ... in its scalar-lane form
+ *   row_rad=16.16.8 passa_rad=16.8 mid_rad=6.10.9   radices of the compile-time row / pass-A / LDS-middle plan (tuning)
  *   no_r2=1 no_skew=1 gd_no_fuse_fwd=1              run-time row plans without the folded radix-2 stage / the LDS skew;
  *                      gradient-descent update without the next iteration's forward rows
  * An unknown key makes lpc_create fail. */

@@ -166,6 +166,25 @@ static void set_static_fft(StaticFft& f, int n, const std::vector<int>& rad, int
   f.T = T; f.nt = nt; f.em = em;
 }
 static inline int round_up64(int v) { return (v + 63) / 64 * 64; }
+// options row_rad / passa_rad / mid_rad: "16.16.8" replaces `rad` when it is a factorisation of n into radices that have
+// a butterfly (lpc_fft.h: Dft<R>)
+static void override_radices(const std::string& opt, int n, std::vector<int>& rad) {
+  if (opt.empty()) return;
+  std::vector<int> r;
+  long prod = 1;
+  size_t i = 0;
+  while (i < opt.size()) {
+    size_t j = opt.find('.', i);
+    if (j == std::string::npos) j = opt.size();
+    const int v = std::atoi(opt.substr(i, j - i).c_str());
+    static const int ok[] = {2, 3, 4, 5, 6, 8, 9, 10, 16, 18, 30};
+    if (std::find(std::begin(ok), std::end(ok), v) == std::end(ok)) return;
+    r.push_back(v);
+    prod *= v;
+    i = j + 1;
+  }
+  if (prod == n && (int)r.size() <= LPC_SPEC_MAX_ST) rad = r;
+}
 
 // `allow_static`: choose compile-time plans (-> e->spec, served by a plan module) wherever the kernels exist; false: the
 // run-time plans of the core library alone.  Sets N1, N2, T, rows_half and the spec; touches nothing on the device.
@@ -219,7 +238,9 @@ static void choose_plan(Engine* e, bool allow_static) {
     plan_radices(n, rad);
     if (n == 4096) rad = {16, 16, 16};   // one butterfly per thread and stage, one LDS round trip fewer than 8.8.8.8
                                           // (same-box A/B, profiles/r02_notes.md: inverse rows 0.518 -> 0.487 ms)
-    const int nt = std::min(1024, std::max(64, round_up64(n / rad[0])));   // every lane owns a first-stage butterfly
+    override_radices(o.row_rad, n, rad);
+    int nt = std::min(1024, std::max(64, round_up64(n / rad[0])));   // every lane owns a first-stage butterfly
+    if (o.row_nt >= 64 && o.row_nt <= 1024 && o.row_nt % 64 == 0) nt = o.row_nt;
     set_static_fft(sp.row, n, rad, 1, nt, (n + nt - 1) / nt);
     if (sp.row.n && sp.row.em <= 16) {
       sp.row_kind = LPC_ROWS_HALF;
@@ -234,6 +255,7 @@ static void choose_plan(Engine* e, bool allow_static) {
       for (size_t i = rad.size() - 1; i-- > 0;)
         if (rad[i] == 8) { rad[i] = 4; rad.back() = 4; std::stable_sort(rad.begin(), rad.end(), [](int a, int b) { return (a == 8) > (b == 8); }); break; }
     }
+    override_radices(o.row_rad, n, rad);
     int nt = std::min(1024, std::max(64, round_up64(n / rad[0])));
     // short rows (960 = 8.8.5.3: 120 first-stage butterflies): 128 threads x 8 points for batches, where every lane
     // then owns a butterfly of the stage that issues the global loads (forward rows 0.642 -> 0.576 ms at 64 frames);
@@ -242,6 +264,7 @@ static void choose_plan(Engine* e, bool allow_static) {
       const bool batch = (long)e->P * g.Hp >= 8192;
       if (o.prow_nt128 == 0 || (o.prow_nt128 < 0 && !batch)) nt = 256;
     }
+    if (o.row_nt >= 64 && o.row_nt <= 1024 && o.row_nt % 64 == 0) nt = o.row_nt;
     set_static_fft(sp.row, n, rad, 1, nt, (n + nt - 1) / nt);
     if (sp.row.n && sp.row.em <= 16) {
       sp.row_kind = LPC_ROWS_PAIRED;
@@ -258,6 +281,7 @@ static void choose_plan(Engine* e, bool allow_static) {
     if (o.passa_t > 0) T = o.passa_t;
     while (T > 1 && (long)e->N1 * T > kMaxTilePoints) T /= 2;
     plan_radices(e->N1, rad);
+    override_radices(o.passa_rad, e->N1, rad);
     const int pts = e->N1 * T;
     int nt = T >= 32 ? 512 : 256;
     while (nt < 1024 && (pts + nt - 1) / nt > 16) nt *= 2;
@@ -273,6 +297,7 @@ static void choose_plan(Engine* e, bool allow_static) {
     // one spectrum at a time: 6.10.9 inside a 128-register budget = TWO workgroups per CU overlapping one another's
     // loads and barriers -- 0.650 ms per launch at 64 frames against 0.84 ms for 30.18 and 0.95 ms for 6.6.5.3
     if (n == 540) rad = seq ? std::vector<int>{6, 10, 9} : std::vector<int>{30, 18};
+    override_radices(o.mid_rad, n, rad);
     const int pts = n * (seq ? T : 2 * T);
     const int nt = pts <= 4096 ? 256 : (pts <= 9216 ? 512 : 1024);
     set_static_fft(sp.mid, n, rad, T, nt, (pts + nt - 1) / nt);

@@ -120,6 +120,10 @@ struct EngineOpts {
   int k1_scalar = 0;          // ... in its scalar-lane form
   int no_r2 = 0, no_skew = 0; // run-time row plans: no folded radix-2 stage / no LDS skew
   int gd_no_fuse_fwd = 0;     // gradient-descent update without the next iteration's forward rows
+  int row_nt = 0;             // threads per row workgroup of the compile-time row plan (tuning; multiple of 64)
+  std::string row_rad, passa_rad, mid_rad;   // "16.16.8": radices of the compile-time row / pass-A / LDS-middle plan
+                              // instead of the chooser's (an experiment costs one module: ~3 s); ignored unless the
+                              // product is the transform length and every radix has a butterfly
   std::string module_dir;     // where plan modules are looked for and written first (default: <libdir>/modules)
   std::string compiler;       // hipcc to compile a missing module with (default: $ROCM_PATH/bin/hipcc, /opt/rocm/bin/hipcc)
 };
@@ -158,6 +162,10 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "no_r2") o.no_r2 = (int)iv;
       else if (k == "no_skew") o.no_skew = (int)iv;
       else if (k == "gd_no_fuse_fwd") o.gd_no_fuse_fwd = (int)iv;
+      else if (k == "row_nt") o.row_nt = (int)iv;
+      else if (k == "row_rad") o.row_rad = v;
+      else if (k == "passa_rad") o.passa_rad = v;
+      else if (k == "mid_rad") o.mid_rad = v;
       else if (k == "module_dir") o.module_dir = v;
       else if (k == "compiler") o.compiler = v;
       else return "unknown engine option '" + k + "'";
