@@ -103,6 +103,7 @@ PREBUILT = [
     dict(algo=1, height=270, width=480, channels=3, batch=8),                                                # C4 / 8 GPUs
     dict(algo=1, height=1080, width=1920, channels=3, depth=16), dict(algo=4, height=1080, width=1920, channels=3),  # C5
     dict(algo=1, height=760, width=1014, channels=1), dict(algo=4, height=760, width=1014, channels=1),     # profile/*.py
+    dict(algo=1, height=1080, width=1920, channels=3),                                                       # one plane of C5
 ]
 PREBUILT_F64 = [dict(algo=1, height=3040, width=4056, channels=3), dict(algo=4, height=3040, width=4056, channels=3)]
 

@@ -238,8 +238,12 @@ static void choose_plan(Engine* e, bool allow_static) {
     plan_radices(n, rad);
     if (n == 4096) rad = {16, 16, 16};   // one butterfly per thread and stage, one LDS round trip fewer than 8.8.8.8
                                           // (same-box A/B, profiles/r02_notes.md: inverse rows 0.518 -> 0.487 ms)
+    if (n == 2048 && admm) rad = {16, 16, 8};   // same idea, 256 threads x 8 points: 3072 x 4096 frames 44.4 -> 43.1 ms per
+                                                 // 50 iterations (profiles/r03k_ab.log; the paired 2048-point rows of
+                                                 // 1536 x 2048 frames and the 1024-point rows are faster on 8.8.8.x)
     override_radices(o.row_rad, n, rad);
     int nt = std::min(1024, std::max(64, round_up64(n / rad[0])));   // every lane owns a first-stage butterfly
+    if (n == 2048 && admm && rad[0] == 16) nt = 256;
     if (o.row_nt >= 64 && o.row_nt <= 1024 && o.row_nt % 64 == 0) nt = o.row_nt;
     set_static_fft(sp.row, n, rad, 1, nt, (n + nt - 1) / nt);
     if (sp.row.n && sp.row.em <= 16) {
@@ -281,6 +285,8 @@ static void choose_plan(Engine* e, bool allow_static) {
     if (o.passa_t > 0) T = o.passa_t;
     while (T > 1 && (long)e->N1 * T > kMaxTilePoints) T /= 2;
     plan_radices(e->N1, rad);
+    if (e->N1 == 90) rad = {10, 9};      // two stages instead of 6.5.3: 16 x 1080p planes 48.1 -> 46.9 ms per 20 iterations
+                                          // (r03k_ab.log; 9.10, 18.5, 30.3 are slower, and 128 = 16.8 is slower than 8.8.2 at 12 MP)
     override_radices(o.passa_rad, e->N1, rad);
     const int pts = e->N1 * T;
     int nt = T >= 32 ? 512 : 256;

@@ -455,8 +455,8 @@ def _admm_fista_vs_oracle(H, W, C, padded, n_admm=3, n_fista=3, seed=13, tol=5e-
 @pytest.mark.parametrize("static", [True, False], ids=["static_plan", "runtime_plan"])
 @pytest.mark.parametrize("shape,padded", [((3, 1920, 1), (5, 3840)), ((1080, 9, 1), (2160, 18)),
                                           ((270, 480, 1), (540, 960)), ((3, 1014, 1), (5, 2048)),
-                                          ((760, 9, 1), (1536, 18))],
-                         ids=["rows1920", "cols90x24", "c1_540x960", "rows2048", "cols64x24"])
+                                          ((760, 9, 1), (1536, 18)), ((3, 2028, 1), (5, 4096))],
+                         ids=["rows1920", "cols90x24", "c1_540x960", "rows2048", "cols64x24", "rows2048half"])
 def test_other_baseline_shapes_static_plans(backend, monkeypatch, static, shape, padded):
     """The remaining BASELINE shapes with compile-time plans, each on a frame that keeps the emulator fast:
     1080p's half rows (1920 = 8.8.6.5; ADMM through the fused image-domain + row kernel), its column split
