@@ -141,3 +141,27 @@ def test_integration_md_stub_runs_verbatim():
     rec.set_data(y[0])
     assert torch.equal(got, rec.apply(n_iter=7, disp_iter=None))
     del native
+
+
+def test_library_reads_the_environment_in_three_places_only():
+    """Launch-plan choices travel in lpc_config.options (include/lpc.h); the library itself may look at LPC_OPTIONS
+    (process-wide defaults, same syntax), ROCM_PATH (where hipcc lives) and HOME (per-user module cache) -- nothing else,
+    outside the LPC_DEBUG_KNOBS build."""
+    import re
+
+    csrc = os.path.join(ROOT, "lenslesspicam_amd", "csrc")
+    calls = []
+    for f in sorted(os.listdir(csrc)):
+        debug = False
+        for ln in open(os.path.join(csrc, f)):
+            if ln.startswith("#ifdef LPC_DEBUG_KNOBS"):
+                debug = True
+            elif ln.startswith("#endif"):
+                debug = False
+            elif not debug:
+                calls += re.findall(r'getenv\("([A-Z_]+)"\)', ln)
+    assert sorted(calls) == ["HOME", "LPC_OPTIONS", "ROCM_PATH"], calls
+    for f in sorted(os.listdir(os.path.join(ROOT, "tests"))):
+        if f.endswith(".py") and f != "test_abi_and_layout.py":
+            src = open(os.path.join(ROOT, "tests", f)).read()
+            assert not re.search(r'(environ|setenv)[^\n]*"LPC_(?!EMU_THREADS)', src), f

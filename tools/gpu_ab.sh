@@ -1,11 +1,8 @@
 #!/bin/bash
-# usage: tools/gpu_ab.sh <outdir> "<label>:<ENV=VAL ...>" ... -- on the GPU box: short default-bench runs under different
-# environment knobs, one summary line each
-out=gpurun_out/$1; shift; mkdir -p $out
-export MPLBACKEND=Agg
-B="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-other-configs $BENCH_ARGS"
-for spec in "$@"; do
-  label=${spec%%:*}; envs=${spec#*:}
-  echo -n "== $label [$envs] : "
-  env $envs $B > $out/bench_$label.json 2> $out/bench_$label.log && python tools/kernel_summary.py $out/bench_$label.json || tail -3 $out/bench_$label.log
-done
+# usage (GPU box): tools/gpu_ab.sh ALGO D H W C B N_ITER REPS "opts_a" "opts_b" ...
+# Same-box A/B of launch-plan option strings (include/lpc.h, lpc_config.options) on one workload: every variant is run
+# five times, interleaved; prints best / median ms per call and the HIP-event kernel table (tools/probe/ab_probe.py).
+# A variant that names another plan (radices, tile widths, ...) costs one plan module: ~3 s of hipcc on first use.
+#   tools/gpu_ab.sh admm 1 270 480 3 64 20 3 "" "seq_tiles_first=1"          # C4, block order of the sequential middle
+#   tools/gpu_ab.sh admm 16 1080 1920 3 1 20 2 "" "passa_rad=10.9"             # C5, pass-A radices
+python tools/probe/ab_probe.py "$@" 2>&1 | grep -v "amdgpu.ids"
