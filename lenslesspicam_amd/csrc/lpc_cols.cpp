@@ -9,6 +9,7 @@ int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1,
   ColPass cp = e->passA;
   cp.tw_mode = inverse ? 2 : 1;
   cp.zr0 = zr0; cp.zr1 = zr1;
+  cp.rev = (e->opt.rev_order & (inverse ? 4 : 2)) ? 1 : 0;
   if (!inverse && sb_outside_scale != (real)0.) {   // ADMM work spectra: planes [P, 2P) = SB, rows outside the window
     cp.sc_plane0 = e->P; cp.sc_r0 = g.sh; cp.sc_r1 = g.sh + g.H; cp.sc = sb_outside_scale;
   }
@@ -89,6 +90,7 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
     // pairs of column tiles on one XCD: measured (profiles/r03_notes.md) -6 % on the 5-iteration C1 call, whose 8-column
     // tiles read half cache lines (middle 0.0278 -> 0.0228 ms); at 12 MP (16 columns = whole lines) it removes a third of
     // the middle's excess HBM reads (2.44 -> 2.28 GB against 1.91 GB asked for) but runs 3 % slower -- off there
+    cp.rev = (e->opt.rev_order & 8) ? 1 : 0;
     cp.swz = e->opt.mid_swz >= 0 ? e->opt.mid_swz : ((size_t)cp.T * sizeof(real2) < 128 ? 1 : 0);
     const dim3 grid(cp.G * cp.ntile_c, e->P);
     const FastDiv t2 = make_fastdiv((unsigned)(2 * cp.T));

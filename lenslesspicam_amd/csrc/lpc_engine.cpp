@@ -392,6 +392,7 @@ static int setup_geometry(Engine* e) {
   A.sc_plane0 = INT_MAX; A.sc_r0 = 0; A.sc_r1 = g.Hp; A.sc = (real)1.;
   A.tdiv = make_fastdiv((unsigned)e->T); A.tcdiv = make_fastdiv((unsigned)ntc);
   A.swz = 0;
+  A.rev = 0;
   ColPass& B = e->passB;
   B = A;
   B.N = e->N2; B.G = e->N1; B.istride = 1; B.gstride = e->N2;
@@ -502,6 +503,7 @@ static AdmmScalars admm_scalars(const Engine* e, const double cur[4]) {
   p.xiw = e->xi_window ? 1 : 0;
   p.xi_store = 1;              // admm_iterate clears it on all but the last iteration of a call
   p.skipa = p.skiphv = 0;      // set by admm_iterate inside a call (AdmmScalars::skipa)
+  p.rev = (e->opt.rev_order & 1) ? 1 : 0;
   return p;
 }
 

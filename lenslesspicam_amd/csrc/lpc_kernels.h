@@ -477,6 +477,9 @@ struct ColPass {
   // segments: single-pass columns of one DiffuserCam-sized frame) the two tiles share every cache line, and on one L2 the
   // second one's loads are hits.
   int swz;
+  // walk the grid backwards (planes and blocks): a pass that starts where the previous kernel finished finds the last
+  // ~256 MB that one wrote still in the memory-side cache (MI355X: 256 MB Infinity Cache in front of HBM)
+  int rev;
 };
 
 // plain pass over ONE spectrum array, in place (global -> registers -> [LDS] -> registers -> global)
@@ -487,9 +490,11 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
-  const int grp = (int)fd_div(blockIdx.x, cp.tcdiv);
-  const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * cp.T;
-  real2* base = S + (long)blockIdx.y * g.cplane + (long)grp * cp.gstride * g.cpitch + c0;
+  const unsigned bx = cp.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;     // ColPass::rev
+  const unsigned by = cp.rev ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
+  const int grp = (int)fd_div(bx, cp.tcdiv);
+  const int c0 = ((int)bx - grp * cp.ntile_c) * cp.T;
+  real2* base = S + (long)by * g.cplane + (long)grp * cp.gstride * g.cpitch + c0;
   const long rstep = (long)cp.istride * g.cpitch;
   const int row0 = grp * cp.gstride;
   auto in = [&](int i, int c) {
@@ -497,7 +502,7 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
     const int row = row0 + i * cp.istride;
     if (c0 + c < g.Wc && (INV || (row >= cp.zr0 && row < cp.zr1))) x = base[i * rstep + c];
     // (a select + an unconditional product instead of this branch measured slower: pass A 0.47 -> 0.50 ms, r02am)
-    if (!INV && (int)blockIdx.y >= cp.sc_plane0 && (row < cp.sc_r0 || row >= cp.sc_r1)) x = cscale(x, cp.sc);
+    if (!INV && (int)by >= cp.sc_plane0 && (row < cp.sc_r0 || row >= cp.sc_r1)) x = cscale(x, cp.sc);
     return x;
   };
   // compile-time plans (short transforms): the plan's twiddles and this group's four-step twiddles
@@ -774,14 +779,15 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
   const int T = cp.T, T2 = 2 * cp.T;
-  unsigned bid = blockIdx.x;
+  unsigned bid = cp.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
+  const unsigned by = cp.rev ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
   if (cp.swz && bid < (gridDim.x & ~15u)) bid = (bid & ~15u) + ((bid & 7u) << 1) + ((bid >> 3) & 1u);   // ColPass::swz
   const int grp = (int)fd_div(bid, cp.tcdiv);
   const int c0 = ((int)bid - grp * cp.ntile_c) * T;
   const long rowoff = ((long)grp * cp.gstride) * g.cpitch + c0;
-  real2* ba = SA + (long)blockIdx.y * g.cplane + rowoff;
-  real2* bb = SB + (long)blockIdx.y * g.cplane + rowoff;
-  const int pp = (int)blockIdx.y % g.DC;
+  real2* ba = SA + (long)by * g.cplane + rowoff;
+  real2* bb = SB + (long)by * g.cplane + rowoff;
+  const int pp = (int)by % g.DC;
   const real2* hb = Hs + (long)pp * g.cplane + rowoff;
   const real* rb = Gabs + rowoff;  // |PsiT Psi| spectrum: one plane, the same for every channel
   const int npair = cp.N * T;
@@ -869,11 +875,12 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   // XCD's L2 fetches that tile of H / |G| from HBM once and serves it to the frames it owns.  (With the tile index
   // fastest, the 64 frames of C4 re-read H 64 times: PMC traffic 2.29 GB per launch against 1.60 GB algorithmic.)
   const int nfr = (int)(gridDim.x / (unsigned)(cp.ntile_c * g.DC));       // frames
-  int fr = (int)(blockIdx.x % (unsigned)nfr), rest = (int)(blockIdx.x / (unsigned)nfr);
+  const unsigned bx = cp.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;   // ColPass::rev
+  int fr = (int)(bx % (unsigned)nfr), rest = (int)(bx / (unsigned)nfr);
   int tile = rest % cp.ntile_c, pp = rest / cp.ntile_c;                   // column tile, PSF plane
   if (tiles_first) {     // A/B option seq_tiles_first: column tiles fastest, then planes (the order of round 2)
-    tile = (int)(blockIdx.x % (unsigned)cp.ntile_c);
-    const int q = (int)(blockIdx.x / (unsigned)cp.ntile_c);
+    tile = (int)(bx % (unsigned)cp.ntile_c);
+    const int q = (int)(bx / (unsigned)cp.ntile_c);
     fr = q / g.DC; pp = q % g.DC;
   }
   const long pl = (long)fr * g.DC + pp;
@@ -978,6 +985,7 @@ struct AdmmScalars {
   // cached Psi V / H V).  The clamp is a pure function of V, so no copy is kept: clamp_cur / clamp_old say that the
   // W-update of this / of the previous iteration saw clamp(V) / clamp(V_old).
   int clamp_cur, clamp_old;
+  int rev;    // the tiled kernel walks its grid backwards (see ColPass::rev)
 };
 // the estimate as the W-update saw it
 static __device__ __forceinline__ real w_sees(real v, bool clamped, bool inside) {
@@ -1184,12 +1192,12 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
   real* sV = (real*)smem;                     // [VH][LP]
   real* sO = sV + VH * LP;
   const int tid = threadIdx.x;
-  const unsigned nblk = gridDim.x, bid = blockIdx.x;   // XCD-aware tile order (see k_admm_spatial)
+  const unsigned nblk = gridDim.x, bid = p.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;   // XCD-aware tile order (see k_admm_spatial)
   const unsigned qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7, idx = bid >> 3;
   const unsigned tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
   const unsigned ty_ = tile / tiles_x;
   const int r0 = (int)ty_ * TH, c0 = (int)(tile - ty_ * tiles_x) * TW;
-  const long pl = blockIdx.y;
+  const long pl = p.rev ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
   const long poff = pl * g.rplane;
   const real* v = V + poff;
   const real* vo = Vold + poff;

@@ -111,6 +111,10 @@ struct EngineOpts {
   int mid_seq = -1;           // single-pass ADMM middle: -1 by batch size; 1 one spectrum at a time; 0 side by side
   int mid_lds = 0;            // no register-resident middles
   int prow_nt128 = -1;        // short paired rows on 128 threads: -1 by batch size
+  int rev_order = 9;          // bit 0 / 1 / 2 / 3: the tiled ADMM kernel / forward pass A / inverse pass A / the LDS middle walk
+                              // their grids BACKWARDS: a kernel that starts where its predecessor finished finds the last
+                              // ~256 MB that one wrote in the memory-side cache.  Default 9 (K1 and the middle; measured
+                              // same-box, profiles/r03_notes.md: C4 -3.3 %, C5 -2.5 %, C2 -1.5 %; all four: +1 %)
   int seq_tiles_first = 0;    // sequential middle: workgroups handed out column tiles fastest instead of frames fastest
   int mid_swz = -1;           // side-by-side LDS middle: pairs of column tiles on one XCD (ColPass::swz); -1: when a tile
                               // row is narrower than a 128-byte line
@@ -153,6 +157,7 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "mid_seq") o.mid_seq = (int)iv;
       else if (k == "mid_lds") o.mid_lds = (int)iv;
       else if (k == "prow_nt128") o.prow_nt128 = (int)iv;
+      else if (k == "rev_order") o.rev_order = (int)iv;
       else if (k == "seq_tiles_first") o.seq_tiles_first = (int)iv;
       else if (k == "mid_swz") o.mid_swz = (int)iv;
       else if (k == "hv_full") o.hv_full = (int)iv;

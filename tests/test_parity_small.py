@@ -641,6 +641,23 @@ def test_middle_tile_pairs_on_one_xcd(backend):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("shape,opts", [((2, 96, 40, 1), {"tile_budget": 512, "col_t": 4, "split_n2": 12}),
+                                        ((1, 270, 480, 1), {"mid_seq": 1}), ((2, 270, 480, 1), {})],
+                         ids=["split_columns", "sequential_middle", "side_by_side_middle"])
+def test_backward_grid_walks_change_nothing(backend, shape, opts):
+    """Option rev_order: which ADMM kernels hand their workgroups out from the last block to the first (so that a kernel
+    starts on what its predecessor wrote last, still in the memory-side cache).  A permutation of the block order of
+    kernels whose blocks are independent: every setting must give the default's result bit for bit."""
+    psf = torch.from_numpy(orc.synthetic_psf(*shape, seed=1))
+    y = torch.from_numpy(np.random.default_rng(2).random((shape[1], shape[2], 1), dtype=np.float32))
+    outs = []
+    for ro in (0, 9, 15):
+        rec = lpa.ADMM(psf, tau=2e-6, mu2=1e-4, engine_options={"rev_order": ro, "jit_min_points": 0, **opts})
+        rec.set_data(y)
+        outs.append(rec.apply(n_iter=3, disp_iter=None))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+
+
 def test_c4_rows_on_128_threads(backend, monkeypatch):
     """960-point paired rows of a large batch run on 128 threads x 8 points (every lane owns one radix-8 butterfly of
     the fused first stage); the option prow_nt128 forces that shape onto one frame.  Same plan, same arithmetic: the result
