@@ -55,7 +55,9 @@ int conv_middle(Engine* e, real2* S, int nplanes, bool adjoint, int zr0, int zr1
   // one lane = one whole pass-B column transform in registers, for the lengths choose_split produces most
   auto reg_mid = [&](auto kernel) {
     const dim3 rgrid((g.Wc + 63) / 64, cp.G, nplanes);
-    return launch_k(e, LPC_K_COL_MID, kernel, rgrid, 64, 0, g, e->planB, cp, S, (const real2*)e->Hs,
+    PlaneGeom gl = g;
+    gl.rev = (e->opt.gd_rev & 4) ? 1 : 0;       // PlaneGeom::rev
+    return launch_k(e, LPC_K_COL_MID, kernel, rgrid, 64, 0, gl, e->planB, cp, S, (const real2*)e->Hs,
                     adjoint ? 1 : 0, hscale, e->Ppsf);
   };
   const int regN = (split && e->mid_reg) ? cp.N : 0;

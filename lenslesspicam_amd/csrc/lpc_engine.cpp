@@ -338,6 +338,7 @@ static int setup_shape(Engine* e, bool* want_static_out) {
   g.uplane = (long)g.H * g.W;
   g.DC = c.depth * c.channels;
   g.C = c.channels;
+  g.rev = 0;
   e->Ppsf = g.DC;
   e->P = c.batch * g.DC;
   e->Pdata = c.batch * c.channels;
@@ -384,6 +385,8 @@ static int setup_geometry(Engine* e) {
   // forward pass A (any plan) or, for single-pass columns, by the module's fused middle (option hv_full: off)
   e->hv_skip = e->xi_window && !e->opt.hv_full && e->mod->admm_rows_inv && (e->N1 > 1 || e->mod->admm_mid);
   e->gd_fuse_fwd = c.algo >= LPC_ALGO_GD && e->mod && e->mod->gd_rows_update_fwd && !e->opt.gd_no_fuse_fwd;
+  if (e->opt.gd_rev < 0)     // EngineOpts::gd_rev
+    e->opt.gd_rev = ((size_t)g.cplane * e->P * sizeof(real2) > ((size_t)200 << 20)) ? 4 : 0;
   LPC_OK(make_twiddles(e, g.Hp, &e->twH));
   const int ntc = (g.Wc + e->T - 1) / e->T;
   ColPass& A = e->passA;

@@ -174,8 +174,8 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid_half(PlaneGeom g, PL plan, c
                                                           const real* LPC_RESTRICT Y) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, u = blockIdx.x;
-  const long pl = blockIdx.y;
+  const int tid = threadIdx.x, u = (int)LPC_BX(g);
+  const long pl = LPC_BY(g);
   const int hh = g.Hp / 2, hw = g.Wp / 2, M = g.Wp >> 1;
   const int sr = wrap_add(g.sh + u, hh, g.Hp);
   tangle_half_load<NT, EMAX, SK>(s, M, twW, Sin + pl * g.cplane + (long)sr * g.cpitch, tid);
@@ -214,8 +214,8 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update_half(PlaneGeom g, PL plan
                                                              GdScalars p) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, u = blockIdx.x;
-  const long pl = blockIdx.y;
+  const int tid = threadIdx.x, u = (int)LPC_BX(g);
+  const long pl = LPC_BY(g);
   const int hh = g.Hp / 2, hw = g.Wp / 2;
   const int sr = wrap_add(g.sh + u, hh, g.Hp);
   tangle_half_load<NT, EMAX, SK>(s, g.Wp >> 1, twW, Sin + pl * g.cplane + (long)sr * g.cpitch, tid);
@@ -255,8 +255,8 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update_fwd_half(PlaneGeom g, PL 
                                                                  const real* LPC_RESTRICT alpha, GdScalars p) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, u = blockIdx.x;
-  const long pl = blockIdx.y;
+  const int tid = threadIdx.x, u = (int)LPC_BX(g);
+  const long pl = LPC_BY(g);
   const int hh = g.Hp / 2, hw = g.Wp / 2, M = g.Wp >> 1;
   const int sr = wrap_add(g.sh + u, hh, g.Hp);
   tangle_half_load<NT, EMAX, SK>(s, M, twW, Sin + pl * g.cplane + (long)sr * g.cpitch, tid);

@@ -27,7 +27,13 @@ struct PlaneGeom {
   long uplane;     // floats per un-padded plane
   int DC;          // D*C: number of PSF planes (state plane q uses PSF plane q % DC)
   int C;           // channels (data plane of state plane q = (q / DC) * C + q % C)
+  int rev;         // per launch (the launcher sets it on its copy): the row kernels that honour it hand their workgroups
+                   // out from the last (plane, row) to the first (see ColPass::rev)
 };
+// block coordinates of a kernel that honours PlaneGeom::rev
+#define LPC_BX(g) ((g).rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x)
+#define LPC_BY(g) ((g).rev ? gridDim.y - 1u - blockIdx.y : blockIdx.y)
+#define LPC_BZ(g) ((g).rev ? gridDim.z - 1u - blockIdx.z : blockIdx.z)
 
 static __device__ __forceinline__ int wrap_add(int i, int d, int n) {  // (i + d) mod n for |d| <= n
   int r = i + d;
@@ -255,14 +261,15 @@ __global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, PL plan, const re
   // block b runs on XCD b % 8: the array flips every fourth row so that each XCD transforms rows of both (the rows of
   // B outside the sensor window may be skipped: with `arr = b & 1` only the odd XCDs would have less to do: 0.49 -> 0.47 ms, r02ak)
   const int tid = threadIdx.x;
-  int row = blockIdx.x >> 1, arr = (blockIdx.x ^ (blockIdx.x >> 3)) & 1;
-  const long pl = blockIdx.y;
+  const unsigned bx = LPC_BX(g);
+  int row = bx >> 1, arr = (bx ^ (bx >> 3)) & 1;
+  const long pl = LPC_BY(g);
   // AdmmScalars::skiphv: grid.x = 2 H + (Hp - H) -- both arrays on the rows of the sensor window, then A (= V) alone on
   // the rows above and below it (no empty workgroups: each would still claim its LDS and a launch slot)
   if (skip_b_outside) {
-    if ((int)blockIdx.x < 2 * g.H) row += g.sh;
+    if ((int)bx < 2 * g.H) row += g.sh;
     else {
-      const int q = (int)blockIdx.x - 2 * g.H;
+      const int q = (int)bx - 2 * g.H;
       row = q < g.sh ? q : q + g.H;
       arr = 0;
     }
@@ -350,13 +357,14 @@ __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, PL plan,
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
-  const long pl = blockIdx.y;
+  const long pl = LPC_BY(g);
+  const unsigned bx = LPC_BX(g);
   // window_only (AdmmScalars::skiphv; grid.x = H + outside_pair_count): blocks [0, H) = the rows of the sensor window,
   // both arrays; the others = two rows of A (= V) outside the window per transform, B (= H V) is not produced there
-  const bool pairs = window_only && (int)blockIdx.x >= g.H;
+  const bool pairs = window_only && (int)bx >= g.H;
   bool vb = true;
-  const int row = !window_only ? (int)blockIdx.x
-                               : (pairs ? outside_pair_row(g, (int)blockIdx.x - g.H, vb) : g.sh + (int)blockIdx.x);
+  const int row = !window_only ? (int)bx
+                               : (pairs ? outside_pair_row(g, (int)bx - g.H, vb) : g.sh + (int)bx);
   const real2* ia = SA + pl * g.cplane + (long)row * g.cpitch;
   const real2* ib = pairs ? ia + g.cpitch : SB + pl * g.cplane + (long)row * g.cpitch;
   if (R2) tangle_r2_load<NT>(s, g.Wp, ia, ib, vb, tid);
@@ -659,14 +667,14 @@ __global__ __launch_bounds__(64) void k_cols_mid_mul_reg(PlaneGeom g, Fft1dPlan 
                                                           real2* LPC_RESTRICT S, const real2* LPC_RESTRICT Hs,
                                                           int conjH, real hscale, int psf_planes) {
   constexpr int N = R1 * R2;
-  const int col = (int)blockIdx.x * 64 + (int)threadIdx.x;
+  const int col = (int)LPC_BX(g) * 64 + (int)threadIdx.x;
   if (col >= g.Wc) return;
   // plain 64-bit addresses on purpose: with wave-uniform bases + 32-bit offsets this kernel needs 58 instead of
   // 214 AGPRs but runs 65 % slower (0.62 vs 0.38 ms at 12 MP) -- the hoisted address arithmetic is what lets
   // all 2N loads of a lane be in flight at once
-  const long rowoff = (long)blockIdx.y * cp.gstride * g.cpitch + col;
-  real2* base = S + (long)blockIdx.z * g.cplane + rowoff;
-  const real2* hb = Hs + (long)((int)blockIdx.z % psf_planes) * g.cplane + rowoff;
+  const long rowoff = (long)LPC_BY(g) * cp.gstride * g.cpitch + col;
+  real2* base = S + (long)LPC_BZ(g) * g.cplane + rowoff;
+  const real2* hb = Hs + (long)((int)LPC_BZ(g) % psf_planes) * g.cplane + rowoff;
   real2 x[N], h[N];
 #pragma unroll
   for (int n = 0; n < N; ++n) x[n] = base[(long)n * g.cpitch];
@@ -1325,8 +1333,9 @@ __global__ __launch_bounds__(NT) void k_rfwd_half_x(PlaneGeom g, AdmmScalars p, 
   // the rows of `a` -- about twice the work per row, on half of the rows once those outside the window are skipped.
   // Flipping the pair every fourth row to mix both kinds on every XCD measured SLOWER: 0.47 -> 0.60 ms, r02ak; a compact
   // grid without the empty blocks of skipped `a` rows measured the same: 0.498 / 0.480 vs 0.499 / 0.481 ms, r02an)
-  const int gr = (int)(blockIdx.x >> 1), arr = (int)(blockIdx.x & 1);
-  const long pl = blockIdx.y;
+  const unsigned bx = LPC_BX(g);
+  const int gr = (int)(bx >> 1), arr = (int)(bx & 1);
+  const long pl = LPC_BY(g);
   const long poff = pl * g.rplane;
   const long o_row = poff + (long)gr * g.rpitch;
   const int n4 = g.Wp >> 2;
@@ -1425,13 +1434,14 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
-  const long pl = blockIdx.y;
+  const long pl = LPC_BY(g);
+  const unsigned bx = LPC_BX(g);
   // p.skipa (grid.x = H + outside_pair_count): blocks [0, H) = the rows of the sensor window as below; the others
   // transform two rows of r_sp outside the window at once -- `a` = mu1 HV needs no transform there, SB keeps the row
   // spectra the last inverse row pass read and the fused middle rescales them (AdmmScalars::skipa)
-  if (p.skipa && (int)blockIdx.x >= g.H) {
+  if (p.skipa && (int)bx >= g.H) {
     bool v1;
-    const int r0 = outside_pair_row(g, (int)blockIdx.x - g.H, v1);
+    const int r0 = outside_pair_row(g, (int)bx - g.H, v1);
     const real* ra = Rsp + pl * g.rplane + (long)r0 * g.rpitch;
     const real* rb = ra + g.rpitch;
     auto two = [&](int i, int) { return make_real2(ra[i], v1 ? rb[i] : (real)0.); };
@@ -1440,7 +1450,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p
     untangle_store<NT, SK>(s, g.Wp, g.Wc, o0, o0 + g.cpitch, v1, tid);
     return;
   }
-  const int row = p.skipa ? g.sh + (int)blockIdx.x : (int)blockIdx.x;
+  const int row = p.skipa ? g.sh + (int)bx : (int)bx;
   const long o_row = pl * g.rplane + (long)row * g.rpitch;
   const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
   const bool row_in = (row >= g.sh) && (row < g.sh + g.H);

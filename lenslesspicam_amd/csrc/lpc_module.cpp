@@ -11,6 +11,12 @@
 #error "lpc_module.cpp is compiled with the flags of plan_spec_defines() (lpc_plan.h)"
 #endif
 
+static inline PlaneGeom geom_rev(const Engine* e, bool rev) {   // the launch's copy of the geometry (PlaneGeom::rev)
+  PlaneGeom g = e->g;
+  g.rev = rev ? 1 : 0;
+  return g;
+}
+
 // ============================================================================== rows ==
 #if LPC_MOD_ROW_KIND != 0
 typedef SPlan<LPC_MOD_ROW_RAD> RowP;
@@ -45,7 +51,8 @@ static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outsi
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const int hrows = skip_hv_outside ? g.Hp + g.H : 2 * g.Hp;
-  return launch_k(e, LPC_K_ROW_INV, k_rinv_half<RNT, REM, RSK, RowPA>, dim3(hrows, e->P), RNT, kRowSmem, g, row_arg(e),
+  return launch_k(e, LPC_K_ROW_INV, k_rinv_half<RNT, REM, RSK, RowPA>, dim3(hrows, e->P), RNT, kRowSmem,
+                  geom_rev(e, e->opt.rev_rows & 2), row_arg(e),
                   e->planW.tw, (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
 }
 #if LPC_MOD_ROW_X
@@ -53,7 +60,8 @@ static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
-  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_half_x<RNT, REM, RSK, RowPA>, dim3(2 * g.Hp, e->P), RNT, kRowSmem, g, *sc,
+  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_half_x<RNT, REM, RSK, RowPA>, dim3(2 * g.Hp, e->P), RNT, kRowSmem,
+                  geom_rev(e, e->opt.rev_rows & 1), *sc,
                   row_arg(e), (const real2*)e->planW.tw, (const real*)e->Rsp, (const real*)e->HVb[e->hcur],
                   (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->Y, SA, SB);
 }
@@ -61,17 +69,20 @@ static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
 #else   // gradient-descent family
 static int m_gd_rows_mid(Engine* e) {
   const PlaneGeom& g = e->g;
-  return launch_k(e, LPC_K_ROW_INV, k_rinv_gd_mid_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem, g,
+  return launch_k(e, LPC_K_ROW_INV, k_rinv_gd_mid_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem,
+                  geom_rev(e, e->opt.gd_rev & 1),
                   row_arg(e), e->planW.tw, (const real2*)e->S, e->S2, (const real*)e->Y);
 }
 static int m_gd_rows_update(Engine* e, const GdScalars* sc, const real* alpha) {
   const PlaneGeom& g = e->g;
-  return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem, g,
+  return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem,
+                  geom_rev(e, e->opt.gd_rev & 2),
                   row_arg(e), e->planW.tw, (const real2*)e->S2, e->gx, e->gaux, alpha, *sc);
 }
 static int m_gd_rows_update_fwd(Engine* e, const GdScalars* sc, const real* alpha) {
   const PlaneGeom& g = e->g;
-  return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update_fwd_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem, g,
+  return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update_fwd_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem,
+                  geom_rev(e, e->opt.gd_rev & 2),
                   row_arg(e), e->planW.tw, (const real2*)e->S2, e->S, e->gx, e->gaux, alpha, *sc);
 }
 #endif
@@ -92,7 +103,8 @@ static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outsi
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const int irows = skip_hv_outside ? g.H + outside_pair_count(g) : g.Hp;
-  return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<RNT, REM, RSK, false, RowPA>, dim3(irows, e->P), RNT, kRowSmem, g,
+  return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<RNT, REM, RSK, false, RowPA>, dim3(irows, e->P), RNT, kRowSmem,
+                  geom_rev(e, e->opt.rev_rows & 2),
                   row_arg(e), (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
 }
 #if LPC_MOD_ROW_X
@@ -102,7 +114,8 @@ static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
   real2* SB = e->S + (size_t)e->P * g.cplane;
   // sc->skipa: the window rows as usual + the rows of r_sp outside it two per transform
   const int xrows = sc->skipa ? g.H + outside_pair_count(g) : g.Hp;
-  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA>, dim3(xrows, e->P), RNT, kRowSmem, g, *sc,
+  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA>, dim3(xrows, e->P), RNT, kRowSmem,
+                  geom_rev(e, e->opt.rev_rows & 1), *sc,
                   row_arg(e), (const real*)e->Rsp, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1],
                   e->xi, (const real*)e->Y, SA, SB);
 }

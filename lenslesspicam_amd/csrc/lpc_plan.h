@@ -115,6 +115,10 @@ struct EngineOpts {
                               // their grids BACKWARDS: a kernel that starts where its predecessor finished finds the last
                               // ~256 MB that one wrote in the memory-side cache.  Default 9 (K1 and the middle; measured
                               // same-box, profiles/r03_notes.md: C4 -3.3 %, C5 -2.5 %, C2 -1.5 %; all four: +1 %)
+  int rev_rows = 0;           // bit 0 / 1: ADMM forward / inverse rows (plan-module kernels) backwards (measured: no gain)
+  int gd_rev = -1;            // gradient-descent family / operator, backwards: bit 0 residual rows, 1 update rows, 2 the
+                              // register middle.  -1: the middle, when a work spectrum is larger than the memory-side
+                              // cache (12 MP FISTA 80.3 -> 75.5 ms per 40 iterations; 152-MB spectra: +1 %, off)
   int seq_tiles_first = 0;    // sequential middle: workgroups handed out column tiles fastest instead of frames fastest
   int mid_swz = -1;           // side-by-side LDS middle: pairs of column tiles on one XCD (ColPass::swz); -1: when a tile
                               // row is narrower than a 128-byte line
@@ -158,6 +162,8 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "mid_lds") o.mid_lds = (int)iv;
       else if (k == "prow_nt128") o.prow_nt128 = (int)iv;
       else if (k == "rev_order") o.rev_order = (int)iv;
+      else if (k == "rev_rows") o.rev_rows = (int)iv;
+      else if (k == "gd_rev") o.gd_rev = (int)iv;
       else if (k == "seq_tiles_first") o.seq_tiles_first = (int)iv;
       else if (k == "mid_swz") o.mid_swz = (int)iv;
       else if (k == "hv_full") o.hv_full = (int)iv;
