@@ -247,3 +247,38 @@ def test_too_wide_frame_is_rejected_cleanly():
 
     with pytest.raises(NativeError, match="16384"):
         lpa.RealFFTConvolve2D(torch.zeros((1, 8, 9000, 1), device="cuda"), pad=True)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_shapes_get_plan_modules_and_match_the_oracle(seed):
+    """The reference accepts any (H, W) (rfft_convolve.py:110-117); so must the fast path.  Random frame shapes -- odd and
+    even sizes, gray and colour, one or two depth planes -- each get their plan module on first use (never seen before:
+    compiled here), and ADMM (TV-active, 6 iterations in one call: two of them on the sensor-window fast path where the
+    padded width allows it), FISTA and the operator pair must match the float64 oracle."""
+    torch.set_num_threads(16)
+    rng = np.random.default_rng(1000 + seed)
+    H, W = int(rng.integers(130, 900)), int(rng.integers(130, 1400))
+    C, D = int(rng.choice([1, 3])), int(rng.choice([1, 1, 2]))
+    psf = orc.synthetic_psf(D, H, W, C, seed=seed)
+    y = rng.random((H, W, C), dtype=np.float32)
+    kw = dict(tau=2e-6, mu2=1e-4)
+    rec = lpa.ADMM(torch.from_numpy(psf).cuda(), **kw)
+    info = rec._handle.plan_info()
+    assert "plan module" in info and "[static" in info, (H, W, C, D, info)
+    rec.set_data(torch.from_numpy(y).cuda())
+    got = rec.apply(n_iter=6, disp_iter=None)
+    for d in range(D):                                         # the reference's ADMM is 2-D: plane d alone (SURVEY row A9)
+        o = orc.ADMMOracle(psf[d:d + 1], dtype=torch.float64, **kw)
+        o.set_data(y)
+        assert rel(got[d], o.apply(6)[0]) <= 1e-5, (H, W, C, D, d, info)
+    f = lpa.FISTA(torch.from_numpy(psf).cuda())
+    finfo = f._handle.plan_info()
+    assert "plan module" in finfo or f._padded_shape[2] % 2 == 1, (H, W, finfo)
+    f.set_data(torch.from_numpy(y).cuda())
+    of = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
+    of.set_data(y)
+    assert rel(f.apply(n_iter=6, disp_iter=None), of.apply(6)) <= 1e-5, (H, W, C, D, finfo)
+    cv = lpa.RealFFTConvolve2D(torch.from_numpy(psf).cuda(), pad=True)
+    oc = orc.ConvolverOracle(psf, pad=True)
+    x = torch.from_numpy(rng.standard_normal((1, D, H, W, C)).astype(np.float32))
+    assert rel(cv.convolve(x.cuda()), oc.convolve(x)) <= 5e-6 and rel(cv.deconvolve(x.cuda()), oc.deconvolve(x)) <= 5e-6

@@ -712,3 +712,27 @@ def test_gd_update_with_fused_forward_rows(backend, monkeypatch, kind, cls):
     plain = cls(torch.from_numpy(psf))
     plain.set_data(torch.from_numpy(y))
     assert rel(plain.apply(n_iter=4, disp_iter=None), got2) <= 1e-6
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_small_shapes_through_plan_modules(backend, monkeypatch, seed):
+    """Random small frames with jit_min_points=0: every one gets a plan module compiled for it (g++ under the emulator,
+    hipcc on the GPU) whatever its padded sizes factor into -- odd widths (paired rows), widths that are not a multiple
+    of 4 (no X half), single-pass and forced four-step columns -- and ADMM / FISTA must match the float64 oracle."""
+    engine_opts(monkeypatch, jit_min_points=0, **({"tile_budget": 512, "col_t": 4} if seed % 2 else {}))
+    rng = np.random.default_rng(500 + seed)
+    H, W, C = int(rng.integers(9, 70)), int(rng.integers(9, 90)), int(rng.choice([1, 3]))
+    psf = orc.synthetic_psf(1, H, W, C, seed=seed)
+    y = rng.random((H, W, C), dtype=np.float32)
+    rec = lpa.ADMM(torch.from_numpy(psf), tau=2e-6, mu2=1e-4)
+    info = rec._handle.plan_info()
+    assert "plan module" in info, (H, W, C, info)
+    rec.set_data(torch.from_numpy(y))
+    o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
+    o.set_data(y)
+    assert rel(rec.apply(n_iter=6, disp_iter=None), o.apply(6)) <= 5e-6, (H, W, C, info)
+    f = lpa.FISTA(torch.from_numpy(psf))
+    f.set_data(torch.from_numpy(y))
+    of = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
+    of.set_data(y)
+    assert rel(f.apply(n_iter=6, disp_iter=None), of.apply(6)) <= 5e-6, (H, W, C, f._handle.plan_info())
