@@ -94,7 +94,7 @@ struct lpc_engine {
   bool xhalf_rows = false; // ADMM: xi / a = mu1 X - xi computed by the forward row kernel of the module
   bool xi_window = false;  // ... which then skips xi / HV_old outside the sensor window (AdmmScalars::xiw)
   bool hv_skip = false;    // ... and rows wholly outside it skip the H V row transforms in both directions (AdmmScalars::skipa)
-  bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (LPC_MID_LDS=1: off)
+  bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (option mid_lds=1: off)
   bool rows_r2 = false; // row plans end in a radix-2 stage: fold it into the Hermitian (un)tangling
   ColPass passA{}, passB{};
   int P = 0, Ppsf = 0, Pdata = 0;

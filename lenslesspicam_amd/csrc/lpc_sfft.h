@@ -2,10 +2,9 @@
 //
 // lpc_fft.h runs any 5-smooth length from a plan passed by value at launch time: radix per stage from a `switch`,
 // index arithmetic through run-time strides and reciprocal multiplications, tail guards on every loop, and a plan
-// structure that alone takes ~60 SGPRs.  The shapes that carry BASELINE.json's configurations are few and known
-// (4096-point half rows of a 12-MP frame, its 128 x 48 column split, 1920 / 90 x 24 for the 1080p depth stack, ...);
-// for those the host picks a kernel instantiated on `SPlanArg<SPlan<radices...>>` instead of `Fft1dPlan`, and
-// fft_tile() -- same name, same contract, overloaded on the plan type -- expands into straight-line stages:
+// structure that alone takes ~60 SGPRs.  A kernel instantiated on `SPlanArg<SPlan<radices...>>` instead of `Fft1dPlan`
+// gets fft_tile() -- same name, same contract, overloaded on the plan type -- expanded into straight-line stages; the
+// instantiations a frame shape needs are compiled per shape into a plan module (lpc_plan.h, lpc_module.cpp):
 //   * length, radix, stride, twiddle step, tile width and thread count are constants: butterfly / element indices are
 //     shifts and masks, LDS offsets are immediates, no tail guards when the work divides by the workgroup;
 //   * the stage loop is unrolled at compile time (no radix switch, so registers are allocated for the radices that
