@@ -129,3 +129,43 @@ def test_shard_bounds_cover_everything():
             assert spans[0][0] == 0 and spans[-1][1] == n
             assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
             assert max(hi - lo for lo, hi in spans) - min(hi - lo for lo, hi in spans) <= 1
+
+
+def _jit_race_worker(rank, world, port, emu_path, out_dir):
+    import sys
+
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), LPC_EMU_THREADS="2")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import lenslesspicam_amd as lpa
+    from lenslesspicam_amd import _native, recon
+    from lenslesspicam_amd.dist import reconstruct_sharded
+
+    lib = _native.Lib(emu_path)
+    recon.runtime = lambda dtype="float32": (lib, torch.device("cpu"))
+    rng = np.random.default_rng(3)
+    psf = rng.random((1, 20, 44, 1), dtype=np.float32) ** 4
+    frames = rng.random((2, 20, 44, 1), dtype=np.float32)
+    opts = {"jit_min_points": 0, "module_dir": os.path.join(out_dir, "modules")}     # an EMPTY module directory
+    dist.barrier()                                               # both ranks reach lpc_create together ...
+    full = reconstruct_sharded(lpa.ADMM, psf, frames, n_iter=4, tau=2e-6, mu2=1e-4, engine_options=opts)
+    probe = lpa.ADMM(psf, tau=2e-6, mu2=1e-4, engine_options=opts)
+    assert "plan module" in probe._handle.plan_info()            # ... and both ended up on the module, not the fallback
+    np.save(os.path.join(out_dir, f"jit_rank{rank}.npy"), full)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_compile_the_same_plan_module_at_once(emu_lib, tmp_path):
+    """One process per GPU: every rank of a node may find the module of a new frame shape missing at the same moment.
+    Each compiles into a private temporary and renames it into place (lpc_jit.cpp) -- both must come up on the module
+    and agree bit for bit with a single-process run."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_jit_race_worker, args=(2, port, emu_lib.path, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "jit_rank0.npy"), np.load(tmp_path / "jit_rank1.npy")
+    assert np.array_equal(a, b)
+    mods = [f for f in os.listdir(tmp_path / "modules") if f.endswith(".so")]
+    assert len(mods) == 1 and not [f for f in os.listdir(tmp_path / "modules") if ".tmp" in f], os.listdir(tmp_path / "modules")
