@@ -177,7 +177,7 @@ static void override_radices(const std::string& opt, int n, std::vector<int>& ra
     size_t j = opt.find('.', i);
     if (j == std::string::npos) j = opt.size();
     const int v = std::atoi(opt.substr(i, j - i).c_str());
-    static const int ok[] = {2, 3, 4, 5, 6, 8, 9, 10, 16, 18, 30};
+    static const int ok[] = {2, 3, 4, 5, 6, 8, 9, 10, 12, 15, 16, 18, 20, 24, 30};
     if (std::find(std::begin(ok), std::end(ok), v) == std::end(ok)) return;
     r.push_back(v);
     prod *= v;
@@ -241,6 +241,9 @@ static void choose_plan(Engine* e, bool allow_static) {
     if (n == 2048 && admm) rad = {16, 16, 8};   // same idea, 256 threads x 8 points: 3072 x 4096 frames 44.4 -> 43.1 ms per
                                                  // 50 iterations (profiles/r03k_ab.log; the paired 2048-point rows of
                                                  // 1536 x 2048 frames and the 1024-point rows are faster on 8.8.8.x)
+    if (n == 1920 && admm) rad = {16, 8, 15};   // 1080p frames, three stages on 128 threads x 15 points: 4 of C5's planes
+                                                 // 49.1 -> 46.4 ms per 20 iterations (r03u_ab.log; 16.15.8 47.9, 24.10.8
+                                                 // 48.4, 20.12.8 47.4; the gradient-descent family is FASTER on 8.8.6.5)
     override_radices(o.row_rad, n, rad);
     int nt = std::min(1024, std::max(64, round_up64(n / rad[0])));   // every lane owns a first-stage butterfly
     if (n == 2048 && admm && rad[0] == 16) nt = 256;

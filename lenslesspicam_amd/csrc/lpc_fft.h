@@ -195,6 +195,10 @@ template <> struct WTab<18> { static constexpr WPair w[18] = {{(real)1.000000000
 template <> struct WTab<9> { static constexpr WPair w[9] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)7.66044443118978013452e-01, (real)-6.42787609686539251896e-01}, {(real)1.73648177666930414453e-01, (real)-9.84807753012208020316e-01}, {(real)-4.99999999999999777955e-01, (real)-8.66025403784438707611e-01}, {(real)-9.39692620785908316883e-01, (real)-3.42020143325668879442e-01}, {(real)-9.39692620785908427905e-01, (real)3.42020143325668657397e-01}, {(real)-5.00000000000000444089e-01, (real)8.66025403784438374544e-01}, {(real)1.73648177666929970364e-01, (real)9.84807753012208131338e-01}, {(real)7.66044443118977791407e-01, (real)6.42787609686539584963e-01}}; };
 template <> struct WTab<10> { static constexpr WPair w[10] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)8.09016994374947451263e-01, (real)-5.87785252292473137103e-01}, {(real)3.09016994374947451263e-01, (real)-9.51056516295153531182e-01}, {(real)-3.09016994374947340241e-01, (real)-9.51056516295153642204e-01}, {(real)-8.09016994374947340241e-01, (real)-5.87785252292473248126e-01}, {(real)-1.00000000000000000000e+00, (real)-1.22464679914735320717e-16}, {(real)-8.09016994374947562285e-01, (real)5.87785252292473026081e-01}, {(real)-3.09016994374947562285e-01, (real)9.51056516295153531182e-01}, {(real)3.09016994374947229218e-01, (real)9.51056516295153642204e-01}, {(real)8.09016994374947340241e-01, (real)5.87785252292473359148e-01}}; };
 
+template <> struct WTab<12> { static constexpr WPair w[12] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)8.66025403784438707611e-01, (real)-4.99999999999999944489e-01}, {(real)5.00000000000000111022e-01, (real)-8.66025403784438596588e-01}, {(real)6.12323399573676603587e-17, (real)-1.00000000000000000000e+00}, {(real)-4.99999999999999777955e-01, (real)-8.66025403784438707611e-01}, {(real)-8.66025403784438707611e-01, (real)-4.99999999999999944489e-01}, {(real)-1.00000000000000000000e+00, (real)-1.22464679914735320717e-16}, {(real)-8.66025403784438818633e-01, (real)4.99999999999999722444e-01}, {(real)-5.00000000000000444089e-01, (real)8.66025403784438374544e-01}, {(real)-1.83697019872102968750e-16, (real)1.00000000000000000000e+00}, {(real)5.00000000000000111022e-01, (real)8.66025403784438596588e-01}, {(real)8.66025403784438374544e-01, (real)5.00000000000000444089e-01}}; };
+template <> struct WTab<15> { static constexpr WPair w[15] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)9.13545457642600866599e-01, (real)-4.06736643075800152758e-01}, {(real)6.69130606358858237570e-01, (real)-7.43144825477394133095e-01}, {(real)3.09016994374947451263e-01, (real)-9.51056516295153531182e-01}, {(real)-1.04528463267653332069e-01, (real)-9.94521895368273400884e-01}, {(real)-4.99999999999999777955e-01, (real)-8.66025403784438707611e-01}, {(real)-8.09016994374947340241e-01, (real)-5.87785252292473248126e-01}, {(real)-9.78147600733805688833e-01, (real)-2.07911690817759314820e-01}, {(real)-9.78147600733805688833e-01, (real)2.07911690817759065020e-01}, {(real)-8.09016994374947562285e-01, (real)5.87785252292473026081e-01}, {(real)-5.00000000000000444089e-01, (real)8.66025403784438374544e-01}, {(real)-1.04528463267654234126e-01, (real)9.94521895368273289861e-01}, {(real)3.09016994374947229218e-01, (real)9.51056516295153642204e-01}, {(real)6.69130606358858459615e-01, (real)7.43144825477394022073e-01}, {(real)9.13545457642600977621e-01, (real)4.06736643075800152758e-01}}; };
+template <> struct WTab<20> { static constexpr WPair w[20] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)9.51056516295153531182e-01, (real)-3.09016994374947395752e-01}, {(real)8.09016994374947451263e-01, (real)-5.87785252292473137103e-01}, {(real)5.87785252292473137103e-01, (real)-8.09016994374947451263e-01}, {(real)3.09016994374947451263e-01, (real)-9.51056516295153531182e-01}, {(real)6.12323399573676603587e-17, (real)-1.00000000000000000000e+00}, {(real)-3.09016994374947340241e-01, (real)-9.51056516295153642204e-01}, {(real)-5.87785252292473026081e-01, (real)-8.09016994374947451263e-01}, {(real)-8.09016994374947340241e-01, (real)-5.87785252292473248126e-01}, {(real)-9.51056516295153531182e-01, (real)-3.09016994374947506774e-01}, {(real)-1.00000000000000000000e+00, (real)-1.22464679914735320717e-16}, {(real)-9.51056516295153753227e-01, (real)3.09016994374946896151e-01}, {(real)-8.09016994374947562285e-01, (real)5.87785252292473026081e-01}, {(real)-5.87785252292473248126e-01, (real)8.09016994374947340241e-01}, {(real)-3.09016994374947562285e-01, (real)9.51056516295153531182e-01}, {(real)-1.83697019872102968750e-16, (real)1.00000000000000000000e+00}, {(real)3.09016994374947229218e-01, (real)9.51056516295153642204e-01}, {(real)5.87785252292472915059e-01, (real)8.09016994374947562285e-01}, {(real)8.09016994374947340241e-01, (real)5.87785252292473359148e-01}, {(real)9.51056516295153531182e-01, (real)3.09016994374947617796e-01}}; };
+template <> struct WTab<24> { static constexpr WPair w[24] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)9.65925826289068312214e-01, (real)-2.58819045102520739476e-01}, {(real)8.66025403784438707611e-01, (real)-4.99999999999999944489e-01}, {(real)7.07106781186547572737e-01, (real)-7.07106781186547461715e-01}, {(real)5.00000000000000111022e-01, (real)-8.66025403784438596588e-01}, {(real)2.58819045102520739476e-01, (real)-9.65925826289068312214e-01}, {(real)6.12323399573676603587e-17, (real)-1.00000000000000000000e+00}, {(real)-2.58819045102520628454e-01, (real)-9.65925826289068312214e-01}, {(real)-4.99999999999999777955e-01, (real)-8.66025403784438707611e-01}, {(real)-7.07106781186547461715e-01, (real)-7.07106781186547572737e-01}, {(real)-8.66025403784438707611e-01, (real)-4.99999999999999944489e-01}, {(real)-9.65925826289068201191e-01, (real)-2.58819045102521017032e-01}, {(real)-1.00000000000000000000e+00, (real)-1.22464679914735320717e-16}, {(real)-9.65925826289068312214e-01, (real)2.58819045102520794988e-01}, {(real)-8.66025403784438818633e-01, (real)4.99999999999999722444e-01}, {(real)-7.07106781186547905804e-01, (real)7.07106781186547128648e-01}, {(real)-5.00000000000000444089e-01, (real)8.66025403784438374544e-01}, {(real)-2.58819045102520628454e-01, (real)9.65925826289068312214e-01}, {(real)-1.83697019872102968750e-16, (real)1.00000000000000000000e+00}, {(real)2.58819045102520295387e-01, (real)9.65925826289068423236e-01}, {(real)5.00000000000000111022e-01, (real)8.66025403784438596588e-01}, {(real)7.07106781186547350693e-01, (real)7.07106781186547683760e-01}, {(real)8.66025403784438374544e-01, (real)5.00000000000000444089e-01}, {(real)9.65925826289068090169e-01, (real)2.58819045102521572144e-01}}; };
 // v[n], n = j1*R2 + j2  ->  v[k], k = k1 + R1*k2  (X[k1 + R1 k2] = sum_j2 w_N^(j2 k1) [sum_j1 x[j1 R2 + j2] w_R1^(j1 k1)] w_R2^(j2 k2))
 template <int R1, int R2, bool INV>
 static __device__ __forceinline__ void dft_two_factor(real2* v) {
@@ -227,6 +231,12 @@ template <bool INV> struct Dft<30, INV> { static __device__ __forceinline__ void
 template <bool INV> struct Dft<18, INV> { static __device__ __forceinline__ void run(real2* v) { dft_two_factor<6, 3, INV>(v); } };
 template <bool INV> struct Dft<10, INV> { static __device__ __forceinline__ void run(real2* v) { dft_two_factor<5, 2, INV>(v); } };
 template <bool INV> struct Dft<9, INV> { static __device__ __forceinline__ void run(real2* v) { dft_two_factor<3, 3, INV>(v); } };
+// (radices the plan chooser does not use on its own: reachable through the options row_rad / passa_rad / mid_rad, for
+// three-stage plans of lengths like 1920 = 16.15.8 or 960 = 16.12.5 -- measured in profiles/r03_notes.md section 13)
+template <bool INV> struct Dft<12, INV> { static __device__ __forceinline__ void run(real2* v) { dft_two_factor<4, 3, INV>(v); } };
+template <bool INV> struct Dft<15, INV> { static __device__ __forceinline__ void run(real2* v) { dft_two_factor<5, 3, INV>(v); } };
+template <bool INV> struct Dft<20, INV> { static __device__ __forceinline__ void run(real2* v) { dft_two_factor<5, 4, INV>(v); } };
+template <bool INV> struct Dft<24, INV> { static __device__ __forceinline__ void run(real2* v) { dft_two_factor<8, 3, INV>(v); } };
 
 // v[m] *= w^m (m = 1..R-1), w = exp(-+ 2 pi i q1 / n) = tw[q1] (conjugated for the inverse).
 template <int R, bool INV>
