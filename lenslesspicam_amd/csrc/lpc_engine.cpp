@@ -247,6 +247,12 @@ static void choose_plan(Engine* e, bool allow_static) {
     override_radices(o.row_rad, n, rad);
     int nt = std::min(1024, std::max(64, round_up64(n / rad[0])));   // every lane owns a first-stage butterfly
     if (n == 2048 && admm && rad[0] == 16) nt = 256;
+    // twice the lanes for 4096 = 16.16.16 (512 x 8 points: every other lane has no butterfly, but the tangling, the
+    // loads and the stores get twice the waves): 12 MP FISTA 75.8 -> 73.4 ms per 40 iterations, ADMM 135.4 -> 134.3
+    // (r03v_ab.log; 1024 lanes: 81.4 / 148.2); likewise the gradient-descent family's 1024 = 8.8.8.2 on 256 lanes
+    // (1536 x 2048 frames: 4.43 -> 4.30 ms per 60 iterations); 2048-point rows are faster on 256 in both families
+    if (n == 4096 && rad[0] == 16) nt = 512;
+    if (n == 1024 && !admm) nt = 256;
     if (o.row_nt >= 64 && o.row_nt <= 1024 && o.row_nt % 64 == 0) nt = o.row_nt;
     set_static_fft(sp.row, n, rad, 1, nt, (n + nt - 1) / nt);
     if (sp.row.n && sp.row.em <= 16) {
