@@ -201,14 +201,18 @@ static void choose_plan(Engine* e, bool allow_static) {
   choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, (!admm || f32) && e->mid_reg);
   const bool st_cols = allow_static && !o.no_static_cols;
   // Single-pass ADMM columns whose two-spectra tile allows only 8 image columns (DiffuserCam-sized frames, 540 padded
-  // rows): the fused middle takes the two spectra one after the other through a 16-column tile (k_cols_mid_admm_seq)
-  // ... when the batch is large enough to fill the chip with half as many workgroups (measured, profiles/r02_notes.md:
-  // 64 frames 1.20 -> 0.96 ms per launch; ONE frame 0.032 -> 0.042 ms: 93 workgroups for 256 CUs)
+  // rows): the fused middle takes the two spectra one after the other through the tile (k_cols_mid_admm_seq), one
+  // parked in registers while the other is transformed ... when the batch is large enough to fill the chip with
+  // workgroups that each hold one spectrum (measured, profiles/r02_notes.md: 64 frames 1.20 -> 0.96 ms per launch with
+  // 16-column tiles; ONE frame 0.032 -> 0.042 ms: 93 workgroups for 256 CUs)
   bool seq = false;
   if (admm && f32 && st_cols && e->N1 == 1 && e->T == 8 && g.Wc > 8 && (long)g.Hp * 16 <= kMaxTilePoints &&
       o.col_t == 0 && o.mid_seq != 0 && ((long)e->P * ((g.Wc + 15) / 16) >= 512 || o.mid_seq == 1)) {
     seq = true;
-    e->T = 16;
+    // 8 columns per tile on 256 lanes x 17 points: four 39-KB workgroups per CU instead of two 73-KB ones of 512 lanes --
+    // same waves per CU, but barriers over 4 waves and four independent phases to overlap (C4, same box: middle
+    // 0.608 -> 0.550 ms, 20-iteration call 38.38 -> 35.73 ms; profiles/r03_notes.md section 15)
+    e->T = o.seq_t == 16 ? 16 : (o.seq_t == 4 ? 4 : 8);
   }
   // Row passes: one real row per half-length complex transform (k_r*_half kernels) once the
   // paired tile is so large that fewer than 5 workgroups fit a CU's 160 KiB of LDS.  Measured (r01b_notes.md):
@@ -314,14 +318,16 @@ static void choose_plan(Engine* e, bool allow_static) {
     if (n == 540) rad = seq ? std::vector<int>{6, 10, 9} : std::vector<int>{30, 18};
     override_radices(o.mid_rad, n, rad);
     const int pts = n * (seq ? T : 2 * T);
-    const int nt = pts <= 4096 ? 256 : (pts <= 9216 ? 512 : 1024);
+    int nt = pts <= 4096 ? 256 : (pts <= 9216 ? 512 : 1024);
+    if (seq) nt = pts <= 18 * 256 ? 256 : (pts <= 18 * 512 ? 512 : 1024);
+    if (o.mid_nt >= 64 && o.mid_nt <= 1024 && o.mid_nt % 64 == 0) nt = o.mid_nt;
     set_static_fft(sp.mid, n, rad, T, nt, (pts + nt - 1) / nt);
     if (sp.mid.n && sp.mid.em <= 18) {
       sp.mid_kind = seq ? LPC_MID_SEQ : LPC_MID_PAIR;
       if (seq) {   // waves per SIMD the register allocation must allow: as many workgroups as the LDS holds
         const size_t lds = (size_t)n * (T + 1) * sizeof(real2);
-        const int wgs = (int)std::max<size_t>(1, std::min<size_t>(2, (160 * 1024) / lds));
-        sp.mid_minw = std::min(8, std::max(1, wgs * nt / 256));
+        const int wgs = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
+        sp.mid_minw = std::min(4, std::max(1, (wgs * nt + 255) / 256));
       }
     } else {
       sp.mid = StaticFft{};

@@ -864,9 +864,12 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
 // k_cols_mid_admm keeps both spectra in one [N][2T] tile; when a whole column is long (540 rows for the
 // DiffuserCam-sized frames of C1 / C4) that tile allows only T = 8 columns per array -- 64-byte row segments, half a
 // cache line per access.  Here the transform of `a` is parked in registers (N*T/NT values per lane) while the same
-// LDS tile transforms `r_sp`: T = 16 columns per workgroup in the same 69 KiB, every row access a whole 128-byte
-// line, half as many workgroups.  H and |G| are shared by all frames of a batch (L2-resident) and are loaded where
-// they are used.  Compile-time plans only (SBT == cp.T).
+// LDS tile transforms `r_sp`: either T = 16 columns per workgroup in the same 69 KiB (every row access a whole 128-byte
+// line, half as many workgroups), or -- the default since round 3 -- T = 8 columns in 39 KiB on 256 lanes: four
+// workgroups per CU, each barrier over 4 waves instead of 8, and the frames-fastest block order below puts the two
+// tiles that share a cache line on the same XCD 1.5 MB apart (C4: 0.608 -> 0.550 ms per launch, r03_notes.md section 15).
+// H and |G| are shared by all frames of a batch (L2-resident) and are loaded where they are used.  Compile-time plans
+// only (SBT == cp.T).
 template <int NT, int EMAX, class PL, int SBT, int MINW = 1, bool TWLDS = false>
 __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL plan, ColPass cp, real2* LPC_RESTRICT SA,
                                                            real2* LPC_RESTRICT SB, const real2* LPC_RESTRICT Hs,

@@ -119,6 +119,7 @@ struct EngineOpts {
   int gd_rev = -1;            // gradient-descent family / operator, backwards: bit 0 residual rows, 1 update rows, 2 the
                               // register middle.  -1: the middle, when a work spectrum is larger than the memory-side
                               // cache (12 MP FISTA 80.3 -> 75.5 ms per 40 iterations; 152-MB spectra: +1 %, off)
+  int seq_t = 0, mid_nt = 0;  // tuning: columns per tile of the sequential middle (4 | 8 | 16), lanes per middle workgroup
   int seq_tiles_first = 0;    // sequential middle: workgroups handed out column tiles fastest instead of frames fastest
   int mid_swz = -1;           // side-by-side LDS middle: pairs of column tiles on one XCD (ColPass::swz); -1: when a tile
                               // row is narrower than a 128-byte line
@@ -164,6 +165,8 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "rev_order") o.rev_order = (int)iv;
       else if (k == "rev_rows") o.rev_rows = (int)iv;
       else if (k == "gd_rev") o.gd_rev = (int)iv;
+      else if (k == "seq_t") o.seq_t = (int)iv;
+      else if (k == "mid_nt") o.mid_nt = (int)iv;
       else if (k == "seq_tiles_first") o.seq_tiles_first = (int)iv;
       else if (k == "mid_swz") o.mid_swz = (int)iv;
       else if (k == "hv_full") o.hv_full = (int)iv;

@@ -598,13 +598,19 @@ def test_window_structure_with_a_per_iteration_schedule(backend, monkeypatch):
 
 
 def test_c4_sequential_middle_on_one_frame(backend, monkeypatch):
-    """C4's fused ADMM middle takes the two spectra one after the other through a 16-column tile
-    (k_cols_mid_admm_seq); the engine selects it for large batches only, the option mid_seq=1 forces it onto one
-    DiffuserCam-sized frame so that the CPU suite executes it.  Batches must equal single-frame runs either way."""
+    """C4's fused ADMM middle takes the two spectra one after the other through one column tile
+    (k_cols_mid_admm_seq: 8 columns on 256 lanes by default, 16 on 512 with seq_t=16); the engine selects it for large
+    batches only, the option mid_seq=1 forces it onto one DiffuserCam-sized frame so that the CPU suite executes it.
+    Batches must equal single-frame runs either way."""
+    psf = orc.synthetic_psf(1, 270, 480, 1, seed=1)
     engine_opts(monkeypatch, mid_seq=1)
     _admm_fista_vs_oracle(270, 480, 1, (540, 960), n_admm=2, n_fista=1)
-    psf = orc.synthetic_psf(1, 270, 480, 1, seed=1)
-    assert "T = 16" in lpa.ADMM(torch.from_numpy(psf))._handle.plan_info()
+    info = lpa.ADMM(torch.from_numpy(psf))._handle.plan_info()
+    assert "one spectrum at a time" in info and "T = 8" in info, info
+    engine_opts(monkeypatch, seq_t=16)
+    _admm_fista_vs_oracle(270, 480, 1, (540, 960), n_admm=2, n_fista=0)
+    info = lpa.ADMM(torch.from_numpy(psf))._handle.plan_info()
+    assert "one spectrum at a time" in info and "T = 16" in info, info
 
 
 def test_c4_sequential_middle_frames_fastest_block_order(backend):
