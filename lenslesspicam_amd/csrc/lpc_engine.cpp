@@ -199,7 +199,10 @@ static void choose_plan(Engine* e, bool allow_static) {
   e->mid_reg = !o.mid_lds;
   // (a 24-point register middle for ADMM in float32 only: 2 x 24 complex128 values do not fit a lane's registers)
   choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, (!admm || f32) && e->mid_reg);
-  const bool st_cols = allow_static && !o.no_static_cols;
+  // the column kernels of a plan module address their tiles with 24-bit row-index x row-step products (k_cols): the step
+  // between two rows of one column transform must stay below 2^24 bytes (12 MP: 48 rows x 32.8 KB = 1.6 MB)
+  const long col_step = (long)(e->N1 > 1 ? e->N2 : 1) * g.cpitch * (long)sizeof(real2);
+  const bool st_cols = allow_static && !o.no_static_cols && col_step < (1L << 24) && g.Hp < (1 << 24);
   // Single-pass ADMM columns whose two-spectra tile allows only 8 image columns (DiffuserCam-sized frames, 540 padded
   // rows): the fused middle takes the two spectra one after the other through the tile (k_cols_mid_admm_seq), one
   // parked in registers while the other is transformed ... when the batch is large enough to fill the chip with

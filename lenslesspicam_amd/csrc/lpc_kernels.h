@@ -490,6 +490,16 @@ struct ColPass {
   int rev;
 };
 
+// element at a 32-bit byte offset from a workgroup-uniform base (SGPR base + VGPR offset addressing)
+template <class T>
+static __device__ __forceinline__ T ld_off(const T* LPC_RESTRICT ubase, unsigned byte_off) {
+  return *(const T*)((const char*)ubase + byte_off);
+}
+template <class T>
+static __device__ __forceinline__ void st_off(T* LPC_RESTRICT ubase, unsigned byte_off, T v) {
+  *(T*)((char*)ubase + byte_off) = v;
+}
+
 // plain pass over ONE spectrum array, in place (global -> registers -> [LDS] -> registers -> global)
 // PL / SBT: run-time plan (SBT unused), or a compile-time plan with SBT == cp.T columns per tile (lpc_sfft.h)
 template <int NT, int EMAX, bool INV, class PL = Fft1dPlan, int SBT = 0, bool TWLDS = false>
@@ -504,11 +514,18 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
   const int c0 = ((int)bx - grp * cp.ntile_c) * cp.T;
   real2* base = S + (long)by * g.cplane + (long)grp * cp.gstride * g.cpitch + c0;
   const long rstep = (long)cp.istride * g.cpitch;
+  // compile-time plans address the tile with 32-bit byte offsets from the workgroup-uniform base, row index x row step
+  // as a 24-bit product (choose_plan() admits them only when the step is below 2^24 bytes): one full-rate v_mad_u32_u24
+  // per access instead of a quarter-rate 64-bit multiply-add and a 64-bit shift-add
+  constexpr bool O32 = is_static_plan<PL>::value;
+  constexpr unsigned c8 = (unsigned)sizeof(real2);
+  const unsigned r8 = (unsigned)rstep * c8;
   const int row0 = grp * cp.gstride;
   auto in = [&](int i, int c) {
     real2 x = make_real2((real)0., (real)0.);
     const int row = row0 + i * cp.istride;
-    if (c0 + c < g.Wc && (INV || (row >= cp.zr0 && row < cp.zr1))) x = base[i * rstep + c];
+    if (c0 + c < g.Wc && (INV || (row >= cp.zr0 && row < cp.zr1)))
+      x = O32 ? ld_off(base, mul24((unsigned)i, r8) + (unsigned)c * c8) : base[i * rstep + c];
     // (a select + an unconditional product instead of this branch measured slower: pass A 0.47 -> 0.50 ms, r02am)
     if (!INV && (int)by >= cp.sc_plane0 && (row < cp.sc_r0 || row >= cp.sc_r1)) x = cscale(x, cp.sc);
     return x;
@@ -536,7 +553,8 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
         d = d < 0 ? d + g.Hp : d;
         if (d >= cp.needn) return;
       }
-      base[i * rstep + c] = x;
+      if (O32) st_off(base, mul24((unsigned)i, r8) + (unsigned)c * c8, x);
+      else base[i * rstep + c] = x;
     }
   };
   if constexpr (is_static_plan<PL>::value) {
@@ -652,13 +670,16 @@ static __device__ __forceinline__ void reg_fft_inv(real2* x, const real2* LPC_RE
 #else
 #define LPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #endif
-template <class T>
-static __device__ __forceinline__ T ld_off(const T* LPC_RESTRICT ubase, unsigned byte_off) {
-  return *(const T*)((const char*)ubase + byte_off);
-}
-template <class T>
-static __device__ __forceinline__ void st_off(T* LPC_RESTRICT ubase, unsigned byte_off, T v) {
-  *(T*)((char*)ubase + byte_off) = v;
+// 1 / d for the ADMM middles' R_divmat (admm.py:186-190; d = mu1 |H|^2 + mu2 |G| + mu3 > 0, far from the overflow and
+// denormal ranges): the hardware reciprocal (1 ulp) + one Newton step = 3 VALU operations, against ~10 for the compiler's
+// IEEE division (v_div_scale x2, v_rcp, 4 fma, v_div_fmas, v_div_fixup) -- 170 of the sequential middle's 3100.
+static __device__ __forceinline__ real recip_pos(real d) {
+#if defined(LPC_SIMT_EMU) || defined(LPC_DOUBLE)
+  return (real)1.0 / d;
+#else
+  const float r = __builtin_amdgcn_rcpf(d);
+  return fmaf(fmaf(-d, r, 1.0f), r, r);
+#endif
 }
 // fused middle of a convolution, register-resident (same contract as k_cols_mid_mul; split passes only:
 // cp.istride == 1, every row valid).  grid = (ceil(Wc/64), groups, planes), 64 threads.
@@ -749,8 +770,8 @@ __global__ __launch_bounds__(64) void k_cols_mid_admm_reg(PlaneGeom g, Fft1dPlan
     for (int k2 = 0; k2 < R2; ++k2) {
       const int k = k1 + R1 * k2, sl = k1 * R2 + k2;
       const real2 hh = ld_off(hb, c8 + (unsigned)k * p8);
-      const real rdiv = rscale * ((real)1.0 / (mu1 * rabs(hh.x * hh.x + hh.y * hh.y) +
-                                               mu2 * ld_off(gb, c4 + (unsigned)k * p4) + mu3));
+      const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) +
+                                           mu2 * ld_off(gb, c4 + (unsigned)k * p4) + mu3);
       const real2 vh = cscale(cadd(r[sl], a[sl]), rdiv);
       r[sl] = vh;
       a[sl] = cmul(cmul(vh, hh), cmul(pr[k], pc));
@@ -786,7 +807,8 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
-  const int T = cp.T, T2 = 2 * cp.T;
+  // (compile-time plans: the tile width is a constant -- e / T, e % T are shifts, not reciprocal multiplies)
+  const int T = is_static_plan<PL>::value ? SBT2 / 2 : cp.T, T2 = 2 * T;
   unsigned bid = cp.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
   const unsigned by = cp.rev ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
   if (cp.swz && bid < (gridDim.x & ~15u)) bid = (bid & ~15u) + ((bid & 7u) << 1) + ((bid >> 3) & 1u);   // ColPass::swz
@@ -801,6 +823,9 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   const int npair = cp.N * T;
   const long rstep = (long)cp.istride * g.cpitch;
   constexpr int EP = (EMAX + 1) / 2;
+  constexpr bool O32 = is_static_plan<PL>::value;      // 32-bit byte offsets, see k_cols
+  constexpr unsigned c8 = (unsigned)sizeof(real2), c4 = (unsigned)sizeof(real);
+  const unsigned r8 = (unsigned)rstep * c8, r4 = (unsigned)rstep * c4;
   real2 h[EP];
   real rd[EP];
 #pragma unroll
@@ -809,9 +834,16 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
     h[k] = make_real2((real)0., (real)0.);
     rd[k] = (real)0.;
     if (e < npair) {
-      const int i = (int)fd_div((unsigned)e, cp.tdiv);
+      const int i = (is_static_plan<PL>::value ? e / T : (int)fd_div((unsigned)e, cp.tdiv));
       const int j = e - i * T;
-      if (c0 + j < g.Wc) { h[k] = hb[i * rstep + j]; rd[k] = rb[i * rstep + j]; }   // rd: |G| for now
+      if (c0 + j < g.Wc) {                      // rd: |G| for now
+        if (O32) {
+          h[k] = ld_off(hb, mul24((unsigned)i, r8) + (unsigned)j * c8);
+          rd[k] = ld_off(rb, mul24((unsigned)i, r4) + (unsigned)j * c4);
+        } else {
+          h[k] = hb[i * rstep + j]; rd[k] = rb[i * rstep + j];
+        }
+      }
     }
   }
   // sb_outside_scale != 0 (AdmmScalars::skipa, single-pass columns only): the rows of SB outside the sensor window were
@@ -819,7 +851,9 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   const real sb_k = sb_outside_scale != (real)0. ? sb_outside_scale : (real)1.;
   auto in = [&](int i, int c) {
     const int j = c < T ? c : c - T;
-    const real2 x = (c0 + j < g.Wc) ? (c < T ? ba : bb)[i * rstep + j] : make_real2((real)0., (real)0.);
+    real2 x = make_real2((real)0., (real)0.);
+    if (c0 + j < g.Wc)
+      x = O32 ? ld_off(c < T ? ba : bb, mul24((unsigned)i, r8) + (unsigned)j * c8) : (c < T ? ba : bb)[i * rstep + j];
     return cscale(x, (c >= T && (unsigned)(i - g.sh) >= (unsigned)g.H) ? sb_k : (real)1.);
   };
   if constexpr (is_static_plan<PL>::value && TWLDS) plan = twiddles_to_lds<NT>(plan, s + PL::n * SBT2, tid);
@@ -831,13 +865,13 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   for (int k = 0; k < EP; ++k) {
     const int e = tid + k * NT;
     if (e < npair) {
-      const int i = (int)fd_div((unsigned)e, cp.tdiv);
+      const int i = (is_static_plan<PL>::value ? e / T : (int)fd_div((unsigned)e, cp.tdiv));
       const int j = e - i * T;
       if (c0 + j < g.Wc) {
         const real2 hh = h[k];
         // R_divmat = 1 / (mu1 |H* H| + mu2 |PsiT Psi| + mu3)  (admm.py:186-190), formed on the fly so
         // that per-iteration step sizes cost nothing; rscale folds the inverse FFT's 1/(Hp*Wp)
-        const real rdiv = rscale * ((real)1.0 / (mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * rd[k] + mu3));
+        const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * rd[k] + mu3);
         const real2 ph = cmul(phr[grp * cp.gstride + i * cp.istride], phc[c0 + j]);
         const real2 rh = s[i * T2 + j];
         const real2 ah = s[i * T2 + T + j];
@@ -852,7 +886,10 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   __syncthreads();
   auto out = [&](int i, int c, real2 x) {
     const int j = c < T ? c : c - T;
-    if (c0 + j < g.Wc) (c < T ? ba : bb)[i * rstep + j] = x;
+    if (c0 + j < g.Wc) {
+      if (O32) st_off(c < T ? ba : bb, mul24((unsigned)i, r8) + (unsigned)j * c8, x);
+      else (c < T ? ba : bb)[i * rstep + j] = x;
+    }
   };
   if constexpr (is_static_plan<PL>::value)
     fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL, SBT2>(s, plan, T2, t2div, tid, LdsNatural{}, out);
@@ -900,16 +937,26 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   real2* bb = SB + pl * g.cplane + c0;
   const real2* hb = Hs + (long)pp * g.cplane + c0;
   const real* rb = Gabs + c0;
-  const long rstep = g.cpitch;
-  const real2 zero = make_real2((real)0., (real)0.);
+  // 32-bit byte offsets from workgroup-uniform bases (a plane is < 4 GB): one v_mad_u32 per access instead of a
+  // 64-bit multiply-add (quarter rate) + 64-bit shift-add
+  const unsigned r8 = (unsigned)g.cpitch * (unsigned)sizeof(real2), r4 = (unsigned)g.cpitch * (unsigned)sizeof(real);
+  constexpr unsigned c8 = (unsigned)sizeof(real2), c4 = (unsigned)sizeof(real);
   // sb_outside_scale != 0 (AdmmScalars::skipa): the rows of SB outside the sensor window were not re-transformed; they
   // hold rfft(H V row) / Wp from the last inverse row pass, and a = mu1 H V there
   const real sb_k = sb_outside_scale != (real)0. ? sb_outside_scale : (real)1.;
-  auto inB = [&](int i, int j) {
-    const real2 x = (c0 + j < g.Wc) ? bb[i * rstep + j] : zero;
-    return cscale(x, (unsigned)(i - g.sh) >= (unsigned)g.H ? sb_k : (real)1.);   // one compare, one select, one product
+  // (the closures copy what they use: captured by reference they end up in scratch and every access through them
+  // becomes a flat_load that also counts against the LDS wait counter)
+  const int wc = g.Wc - c0, sh = g.sh, hwin = g.H;
+  auto inB = [=](int i, int j) {
+    real2 x = make_real2((real)0., (real)0.);      // (not `cond ? bb[..] : zero`: that selects between two ADDRESSES)
+    if (j < wc) x = ld_off(bb, mul24((unsigned)i, r8) + (unsigned)j * c8);
+    return cscale(x, (unsigned)(i - sh) >= (unsigned)hwin ? sb_k : (real)1.);   // one compare, one select, one product
   };
-  auto inA = [&](int i, int j) { return (c0 + j < g.Wc) ? ba[i * rstep + j] : zero; };
+  auto inA = [=](int i, int j) {
+    real2 x = make_real2((real)0., (real)0.);
+    if (j < wc) x = ld_off(ba, mul24((unsigned)i, r8) + (unsigned)j * c8);
+    return x;
+  };
   // the twiddle table moves into LDS behind the tile (lpc_sfft.h twiddles_to_lds)
   if (TWLDS) plan = twiddles_to_lds<NT>(plan, s + NELEM, tid);
   // 1. Ah = FFT(a), parked in registers in tile order e = tid + k NT
@@ -918,7 +965,8 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
 #pragma unroll
   for (int k = 0; k < EM; ++k) {
     const int e = tid + k * NT;
-    a[k] = e < NELEM ? s[e] : zero;
+    a[k] = make_real2((real)0., (real)0.);
+    if (e < NELEM) a[k] = s[e];
   }
   __syncthreads();
   // 2. Rh = FFT(r_sp) in the same tile
@@ -930,8 +978,9 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
     if (e < NELEM) {
       const int i = e / T, j = e % T;
       if (c0 + j < g.Wc) {
-        const real2 hh = hb[i * rstep + j];
-        const real rdiv = rscale * ((real)1.0 / (mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * rb[i * rstep + j] + mu3));
+        const real2 hh = ld_off(hb, mul24((unsigned)i, r8) + (unsigned)j * c8);
+        const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) +
+                                             mu2 * ld_off(rb, mul24((unsigned)i, r4) + (unsigned)j * c4) + mu3);
         const real2 ph = cmul(phr[i], phc[c0 + j]);
         const real2 t = cmul(cmul_conj(a[k], hh), ph);
         const real2 vh = cscale(cadd(s[e], t), rdiv);
@@ -942,7 +991,7 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   }
   __syncthreads();
   // 4. V-hat back through the inverse transform, straight to SA
-  auto outA = [&](int i, int j, real2 x) { if (c0 + j < g.Wc) ba[i * rstep + j] = x; };
+  auto outA = [=](int i, int j, real2 x) { if (j < wc) st_off(ba, mul24((unsigned)i, r8) + (unsigned)j * c8, x); };
   fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, outA);
   __syncthreads();
   // 5. H V-hat: registers -> tile -> inverse transform -> SB
@@ -952,7 +1001,7 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
     if (e < NELEM) s[e] = a[k];
   }
   __syncthreads();
-  auto outB = [&](int i, int j, real2 x) { if (c0 + j < g.Wc) bb[i * rstep + j] = x; };
+  auto outB = [=](int i, int j, real2 x) { if (j < wc) st_off(bb, mul24((unsigned)i, r8) + (unsigned)j * c8, x); };
   fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, outB);
 }
 
@@ -1212,13 +1261,18 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
   const long poff = pl * g.rplane;
   const real* v = V + poff;
   const real* vo = Vold + poff;
-  auto wrap_r = [&](int r) { r = r < 0 ? r + g.Hp : r; return r >= g.Hp ? r % g.Hp : r; };
-  auto wrap_c = [&](int c) { c = c < 0 ? c + g.Wp : c; return c >= g.Wp ? c % g.Wp : c; };
+  // circular neighbours: -1 -> n - 1 and n -> 0 are the only wraps a VALID pixel ever needs (its neighbours lie in
+  // [-1, n]); indices further out belong to the overhang of the last tile, whose values no valid pixel reads -- they are
+  // clamped to a safe address.  (A general `% n` here was 8 integer divisions per lane: a third of the kernel's VALU.)
+  auto wrap = [](int x, int n) { x = x < 0 ? x + n : x; x = x >= n ? x - n : x; return x < n ? x : n - 1; };
+  auto wrap_r = [&](int r) { return wrap(r, g.Hp); };
+  auto wrap_c = [&](int c) { return wrap(c, g.Wp); };
+  auto wrap_c4 = [&](int c) { c = c >= g.Wp ? c - g.Wp : c; return c < g.Wp ? c : g.Wp - 4; };   // quads: c, Wp multiples of 4
 
   // ---- stage V, V_old: body as real4, the two halo columns as scalars ----
   for (int e = tid; e < VH * (TW / 4); e += NT) {
     const int ly = e / (TW / 4), l4 = e - ly * (TW / 4);
-    const long o = (long)wrap_r(r0 + ly - 1) * g.rpitch + wrap_c(c0 + 4 * l4);
+    const long o = (long)wrap_r(r0 + ly - 1) * g.rpitch + wrap_c4(c0 + 4 * l4);
     st4(sV + ly * LP + 4 + 4 * l4, ld4(v + o));
     st4(sO + ly * LP + 4 + 4 * l4, p.first ? make_real4((real)0., (real)0., (real)0., (real)0.) : ld4(vo + o));
   }

@@ -52,7 +52,9 @@ def main():
     cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-x", "hip", "-S", "--cuda-device-only",
            "-I", os.path.join(ROOT, "include"), "-I", csrc, '-DLPC_SRC_FP="asm"'] + defines(key) + [
                os.path.join(csrc, "lpc_module.cpp"), "-o", out]
-    subprocess.run(cmd, check=True, stderr=subprocess.DEVNULL)
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        sys.exit(r.stderr[-3000:])
     print(out)
 
 
