@@ -742,3 +742,23 @@ def test_random_small_shapes_through_plan_modules(backend, monkeypatch, seed):
     of = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
     of.set_data(y)
     assert rel(f.apply(n_iter=6, disp_iter=None), of.apply(6)) <= 5e-6, (H, W, C, f._handle.plan_info())
+
+
+@pytest.mark.parametrize("shape", [(2, 4, 3), (3, 150, 1), (5, 70, 1), (130, 2, 1), (2, 2, 1)])
+def test_tiny_frames_circular_neighbours(backend, shape):
+    """The tiled image-domain kernel takes its circular TV neighbours without an integer division: -1 -> n - 1 and
+    n -> 0 exactly, anything further out (the overhang of the last 4 x 256 tile) clamped to a safe address.  Frames of
+    two to five rows, and a 300-column padded width that ends 44 columns into its second tile, with the TV term active,
+    against the float64 oracle."""
+    H, W, C = shape
+    rng = np.random.default_rng(H * 1000 + W)
+    psf = orc.synthetic_psf(1, H, W, C, seed=H + W)
+    y = rng.random((H, W, C), dtype=np.float32)
+    kw = dict(tau=5e-3, mu1=1e-2, mu2=1e-2, mu3=1e-2)
+    rec = lpa.ADMM(torch.from_numpy(psf), **kw)
+    rec.set_data(torch.from_numpy(y))
+    o = orc.ADMMOracle(psf, dtype=torch.float64, **kw)
+    o.set_data(y)
+    want = np.asarray(o.apply(8))
+    assert float(np.abs(want).max()) > 0
+    assert rel(rec.apply(n_iter=8, disp_iter=None), want) <= 1e-5, rec._handle.plan_info()
