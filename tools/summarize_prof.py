@@ -77,8 +77,12 @@ def kid_of(k):
         return "row_fwd"
     if k.startswith(("k_rinv_half", "k_rinv_arrays")) and "SPlan" in k:
         return "row_inv"
-    if k.startswith("k_cols_mid_admm"):
+    if k.startswith(("k_cols_mid_admm", "k_cols_mid_mul")):
         return "col_mid"
+    if k.startswith("k_rinv_gd_update"):          # gradient-descent family: inverse rows + update (+ next forward rows)
+        return "spatial"
+    if k.startswith("k_rinv_gd_mid"):             # ... inverse rows + residual + forward rows
+        return "row_inv"
     if k.startswith("k_cols<") and "SPlan" in k:
         return "col_a_inv" if k.split(",")[2].strip() == "true" else "col_a_fwd"
     return None
