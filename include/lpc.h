@@ -86,6 +86,8 @@ typedef struct lpc_config {
  *                      register-resident middles; short paired rows on 128 threads (defaults: by batch size)
  *   seq_tiles_first=1  that sequential middle hands its workgroups out column tiles fastest instead of frames fastest
  *   seq_t=4|8|16 mid_nt=N   columns per tile of the sequential middle (default 8); lanes per LDS-middle workgroup
+ *   g_plane=0|1        ADMM middles read |PsiT Psi| as a row term + a column term when it separates (0) / from its plane
+ *                      (1); default: the terms when the plane exceeds 8 MB
  *   rev_order=BITS     which ADMM kernels walk their grids backwards (1 tiled kernel, 2 / 4 forward / inverse pass A,
  *                      8 LDS middle; default 9);  rev_rows=BITS (1 / 2 forward / inverse ADMM rows; default 0);
  *                      gd_rev=BITS (gradient-descent family / operator: 1 residual rows, 2 update rows, 4 register middle;

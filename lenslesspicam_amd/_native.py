@@ -174,7 +174,7 @@ class Lib:
         """Key of the plan module ``create(**kw)`` would use ('' = run-time plans); ``build``: compile it if missing.
         Needs no device (lpc_plan_module)."""
         cfg = self._config(kw)
-        buf = C.create_string_buffer(512)
+        buf = C.create_string_buffer(1024)
         self.check(self.dll.lpc_plan_module(C.byref(cfg), int(bool(build)), buf, 512))
         return buf.value.decode()
 
@@ -290,7 +290,7 @@ class Handle:
         return b.value
 
     def plan_info(self):
-        buf = C.create_string_buffer(512)
+        buf = C.create_string_buffer(1024)
         self._c(self.lib.dll.lpc_plan_info(self.h, buf, 512))
         return buf.value.decode()
 

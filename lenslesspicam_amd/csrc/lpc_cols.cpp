@@ -92,6 +92,8 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
     // pairs of column tiles on one XCD: measured (profiles/r03_notes.md) -6 % on the 5-iteration C1 call, whose 8-column
     // tiles read half cache lines (middle 0.0278 -> 0.0228 ms); at 12 MP (16 columns = whole lines) it removes a third of
     // the middle's excess HBM reads (2.44 -> 2.28 GB against 1.91 GB asked for) but runs 3 % slower -- off there
+    cp.ga = e->g_sep ? e->Ga : nullptr;
+    cp.gb = e->g_sep ? e->Gb : nullptr;
     cp.rev = (e->opt.rev_order & 8) ? 1 : 0;
     cp.swz = e->opt.mid_swz >= 0 ? e->opt.mid_swz : ((size_t)cp.T * sizeof(real2) < 128 ? 1 : 0);
     const dim3 grid(cp.G * cp.ntile_c, e->P);

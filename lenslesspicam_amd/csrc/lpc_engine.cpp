@@ -414,6 +414,7 @@ static int setup_geometry(Engine* e) {
   A.tdiv = make_fastdiv((unsigned)e->T); A.tcdiv = make_fastdiv((unsigned)ntc);
   A.swz = 0;
   A.rev = 0;
+  A.ga = A.gb = nullptr;
   ColPass& B = e->passB;
   B = A;
   B.N = e->N2; B.G = e->N1; B.istride = 1; B.gstride = e->N2;
@@ -528,6 +529,7 @@ static AdmmScalars admm_scalars(const Engine* e, const double cur[4]) {
   return p;
 }
 
+static const int kGsepBlocks = 512;
 static int admm_alloc(Engine* e) {
   const PlaneGeom& g = e->g;
   const size_t rp = (size_t)g.rplane * e->P;
@@ -535,6 +537,34 @@ static int admm_alloc(Engine* e) {
                     &e->eta1[1], &e->rho, &e->Rsp, &e->Aarr};
   for (real** b : bufs) LPC_OK(dev_alloc(e, b, rp));
   LPC_OK(dev_alloc(e, &e->Gabs, (size_t)g.cplane));
+  LPC_OK(dev_alloc(e, &e->Ga, (size_t)g.Hp));
+  LPC_OK(dev_alloc(e, &e->Gb, (size_t)g.cpitch));
+  LPC_OK(dev_alloc(e, &e->Gpart, (size_t)2 * kGsepBlocks));
+  return 0;
+}
+
+// |PsiT Psi| as row term + column term (ColPass::ga): taken when the plane in e->Gabs separates to float32 round-off
+// (the reference's finite-difference gram does, admm.py:385-397; a caller's psi_gram in general does not)
+static int admm_split_gram(Engine* e) {
+  const PlaneGeom& g = e->g;
+  e->g_sep = 0;
+  // Measured (r03z_ab.log): at 12 MP (100-MB plane, 64-byte tile rows fetched as whole lines once per colour plane) the
+  // terms take 0.5 GB off the middle's HBM traffic, 0.622 -> 0.563 ms; on DiffuserCam-sized frames the 1-MB plane lives
+  // in the L2 and one load beats two (C1 middle 0.0206 -> 0.0221 ms with the terms)
+  const int want = e->opt.g_plane >= 0 ? !e->opt.g_plane : ((size_t)g.cplane * sizeof(real) > ((size_t)8 << 20));
+  if (!want) return 0;
+  const int n = (int)std::max<long>(g.Hp, g.cpitch);
+  LPC_OK(launch_k(e, -1, k_gsep_extract, grid1d((long)n, 256), 256, 0, (const real*)e->Gabs, g.Hp, g.Wc,
+                  (long)g.cpitch, e->Ga, e->Gb));
+  LPC_OK(launch_k(e, -1, k_gsep_check<256>, dim3(kGsepBlocks), 256, 2 * 256 * sizeof(real), (const real*)e->Gabs, g.Hp,
+                  g.Wc, (long)g.cpitch, (const real*)e->Ga, (const real*)e->Gb, e->Gpart));
+  std::vector<real> part((size_t)2 * kGsepBlocks);
+  LPC_RT(rt::copy_d2h_async(part.data(), e->Gpart, part.size() * sizeof(real), e->stream));
+  LPC_RT(rt::stream_sync(e->stream));
+  double err = 0., top = 0.;
+  for (int b = 0; b < kGsepBlocks; ++b) { err = std::max(err, (double)part[2 * b]); top = std::max(top, -(double)part[2 * b + 1]); }
+  const double eps = sizeof(real) == 4 ? 1e-6 : 1e-13;        // a few ulp of the largest entry: FFT round-off of the gram
+  e->g_sep = (top > 0. && err <= eps * top) ? 1 : 0;
   return 0;
 }
 
@@ -557,7 +587,7 @@ static int admm_setup_constants(Engine* e) {
   LPC_OK(fft2_forward_setup(e, src_padded(e, stencil), Gs, 1));
   LPC_OK(launch_k(e, -1, k_abs_complex<256>, grid1d((long)g.cplane, 256), 256, 0, (const real2*)Gs, e->Gabs,
                   (long)g.cplane));
-  return 0;
+  return admm_split_gram(e);
 }
 
 static int admm_reset(Engine* e) {
@@ -1011,8 +1041,9 @@ int lpc_set_psi_gram(lpc_handle e, const real* dev_gabs, void* stream) {
   e->stream = (lpcStream_t)stream;
   const PlaneGeom& g = e->g;
   LPC_RT(rt::memset_async(e->Gabs, 0, (size_t)g.cplane * sizeof(real), e->stream));
-  return launch_k(e, -1, k_permute_spectrum_rows<256>, grid1d((long)g.Hp * g.Wc, 256), 256, 0, dev_gabs, e->Gabs, g.Hp,
-                  g.Wc, g.cpitch, e->N1, e->N2);
+  LPC_OK(launch_k(e, -1, k_permute_spectrum_rows<256>, grid1d((long)g.Hp * g.Wc, 256), 256, 0, dev_gabs, e->Gabs, g.Hp,
+                  g.Wc, g.cpitch, e->N1, e->N2));
+  return admm_split_gram(e);
 }
 
 int lpc_admm_psi_step(lpc_handle e, const real* dev_psit, void* stream) {
@@ -1354,7 +1385,7 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
                                   : e->xi_window ? 2.0 * R + 3.0 * eb * g.H * g.W * e->P + R0 + 2.0 * S
                                   : e->xhalf_rows ? 5.0 * R + R0 + 2.0 * S : 2.0 * R + 2.0 * S); break;
       case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
-      case LPC_K_COL_MID: b = 4.0 * S + Sc + eb * g.Hp * g.Wc; break;  // + H (complex) + |G| (real, one plane)
+      case LPC_K_COL_MID: b = 4.0 * S + Sc + (e->g_sep ? 0. : eb * g.Hp * g.Wc); break;  // + H (complex) + |G| (real, one plane; two vectors when it separates)
       case LPC_K_COL_A_INV: b = split ? 4.0 * S : 0.0; break;
       case LPC_K_ROW_INV: b = e->hv_skip ? (1.0 + fr) * (S + R) : 2.0 * S + 2.0 * R; break;
       default: return fail("bad kernel id");
@@ -1393,6 +1424,7 @@ int lpc_plan_info(lpc_handle e, char* buf, size_t n) {
     if (e->xi_window) s += e->hv_skip ? " (xi inside the sensor window only, H V row transforms skipped outside it)"
                                       : " (xi inside the sensor window only)";
   }
+  if (e->cfg.algo == LPC_ALGO_ADMM && e->g_sep) s += "; gram as row + column terms";
   s += e->mod ? "; plan module " + plan_spec_key(sp) : "; run-time plans (" + e->mod_note + ")";
   std::snprintf(buf, n, "%s", s.c_str());
   return 0;

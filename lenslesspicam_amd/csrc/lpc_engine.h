@@ -104,6 +104,12 @@ struct lpc_engine {
   // spectral constants
   real2* Hs = nullptr;     // [Ppsf] PSF spectrum, permuted row order, norm applied
   real* Gabs = nullptr;    // ADMM: |PsiT Psi| spectrum, ONE plane (identical for every channel)
+  // ... and, when that plane is a sum of a row term and a column term (the reference's finite-difference gram is:
+  // (2 - 2 cos th_r) + (2 - 2 cos th_c)), the two vectors the middles read instead of it: Ga[row] + Gb[col]
+  real* Ga = nullptr;      // [Hp], the engine's (permuted) spectrum row order
+  real* Gb = nullptr;      // [cpitch]
+  real* Gpart = nullptr;   // partial maxima of the separability check
+  int g_sep = 0;
   std::vector<double> sched[4];  // optional per-iteration mu1, mu2, mu3, tau (unrolled ADMM)
   double last_par[4] = {0, 0, 0, 0};  // parameters of the most recent iteration
   real2* phr = nullptr;    // [Hp] ifftshift phase, stored row order

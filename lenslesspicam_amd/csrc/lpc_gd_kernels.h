@@ -370,6 +370,34 @@ __global__ __launch_bounds__(NT) void k_plane_minmax(PlaneGeom g, const real2* L
   }
 }
 
+// ---- is a real spectrum plane G[r][c] the sum of a row term and a column term?  (ADMM set-up, ColPass::ga) -----
+// ga[r] = G[r][0], gb[c] = G[0][c] - G[0][0]
+static __global__ void k_gsep_extract(const real* LPC_RESTRICT G, int Hp, int Wc, long cpitch, real* LPC_RESTRICT ga,
+                                      real* LPC_RESTRICT gb) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < Hp) ga[e] = G[e * cpitch];
+  if (e < cpitch) gb[e] = e < Wc ? G[e] - G[0] : (real)0.;
+}
+// partial[2 b] = max |G - ga - gb|, partial[2 b + 1] = -max |G| over the block's share of the plane
+template <int NT>
+__global__ __launch_bounds__(NT) void k_gsep_check(const real* LPC_RESTRICT G, int Hp, int Wc, long cpitch,
+                                                    const real* LPC_RESTRICT ga, const real* LPC_RESTRICT gb,
+                                                    real* LPC_RESTRICT partial) {
+  LPC_DYN_SMEM(smem);
+  real* scratch = (real*)smem;
+  const int tid = threadIdx.x;
+  real mx = (real)0., mn = (real)0.;
+  const long n = (long)Hp * Wc;
+  for (long e = (long)blockIdx.x * NT + tid; e < n; e += (long)gridDim.x * NT) {
+    const int r = (int)(e / Wc), c = (int)(e - (long)r * Wc);
+    const real v = G[(long)r * cpitch + c];
+    mx = rmax(mx, rabs(v - (ga[r] + gb[c])));
+    mn = rmin(mn, -rabs(v));
+  }
+  block_minmax<NT>(mx, mn, scratch, tid);
+  if (tid == 0) { partial[2 * blockIdx.x] = mx; partial[2 * blockIdx.x + 1] = mn; }
+}
+
 // final per-channel combine over depth planes and blocks (gd.py:100-112 flatten (D,H,W) per channel):
 // mode 0: out[c] = lip_fact / max;  mode 1: out[c] = (max + min) / 2
 static __global__ void k_channel_finish(const real* LPC_RESTRICT partial, int nblk, int D, int C, int mode, real lip,

@@ -485,6 +485,11 @@ struct ColPass {
   // segments: single-pass columns of one DiffuserCam-sized frame) the two tiles share every cache line, and on one L2 the
   // second one's loads are hits.
   int swz;
+  // ADMM middles: |PsiT Psi| = ga[spectrum row] + gb[column] (null: read it from the plane).  The reference's gram
+  // separates; read as a plane its 64-byte tile rows are fetched as whole lines once per colour plane -- 0.5 GB of the
+  // 12-MP middle's 3.65 GB (profiles/r03_notes.md section 17)
+  const real* ga;
+  const real* gb;
   // walk the grid backwards (planes and blocks): a pass that starts where the previous kernel finished finds the last
   // ~256 MB that one wrote still in the memory-side cache (MI355X: 256 MB Infinity Cache in front of HBM)
   int rev;
@@ -739,6 +744,9 @@ __global__ __launch_bounds__(64) void k_cols_mid_admm_reg(PlaneGeom g, Fft1dPlan
   real2* bb = SB + (long)blockIdx.z * g.cplane + urow;
   const real2* hb = Hs + (long)((int)blockIdx.z % g.DC) * g.cplane + urow;
   const real* gb = Gabs + urow;
+  const bool gsep = cp.ga != nullptr;
+  const real* gar = gsep ? cp.ga + row0 : Gabs;          // wave-uniform row terms (scalar loads, like the row phases)
+  const real gcol = gsep ? cp.gb[col] : (real)0.;
   const real2* pr = phr + row0;
   const real2 pc = phc[col];
   const unsigned c8 = (unsigned)col * (unsigned)sizeof(real2), c4 = (unsigned)col * (unsigned)sizeof(real);
@@ -770,8 +778,8 @@ __global__ __launch_bounds__(64) void k_cols_mid_admm_reg(PlaneGeom g, Fft1dPlan
     for (int k2 = 0; k2 < R2; ++k2) {
       const int k = k1 + R1 * k2, sl = k1 * R2 + k2;
       const real2 hh = ld_off(hb, c8 + (unsigned)k * p8);
-      const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) +
-                                           mu2 * ld_off(gb, c4 + (unsigned)k * p4) + mu3);
+      const real gk = gsep ? gar[k] + gcol : ld_off(gb, c4 + (unsigned)k * p4);
+      const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * gk + mu3);
       const real2 vh = cscale(cadd(r[sl], a[sl]), rdiv);
       r[sl] = vh;
       a[sl] = cmul(cmul(vh, hh), cmul(pr[k], pc));
@@ -837,12 +845,11 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
       const int i = (is_static_plan<PL>::value ? e / T : (int)fd_div((unsigned)e, cp.tdiv));
       const int j = e - i * T;
       if (c0 + j < g.Wc) {                      // rd: |G| for now
-        if (O32) {
-          h[k] = ld_off(hb, mul24((unsigned)i, r8) + (unsigned)j * c8);
-          rd[k] = ld_off(rb, mul24((unsigned)i, r4) + (unsigned)j * c4);
-        } else {
-          h[k] = hb[i * rstep + j]; rd[k] = rb[i * rstep + j];
-        }
+        if (O32) h[k] = ld_off(hb, mul24((unsigned)i, r8) + (unsigned)j * c8);
+        else h[k] = hb[i * rstep + j];
+        if (cp.ga) rd[k] = cp.ga[grp * cp.gstride + i * cp.istride] + cp.gb[c0 + j];
+        else if (O32) rd[k] = ld_off(rb, mul24((unsigned)i, r4) + (unsigned)j * c4);
+        else rd[k] = rb[i * rstep + j];
       }
     }
   }
@@ -979,8 +986,8 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
       const int i = e / T, j = e % T;
       if (c0 + j < g.Wc) {
         const real2 hh = ld_off(hb, mul24((unsigned)i, r8) + (unsigned)j * c8);
-        const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) +
-                                             mu2 * ld_off(rb, mul24((unsigned)i, r4) + (unsigned)j * c4) + mu3);
+        const real gk = cp.ga ? cp.ga[i] + cp.gb[c0 + j] : ld_off(rb, mul24((unsigned)i, r4) + (unsigned)j * c4);
+        const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * gk + mu3);
         const real2 ph = cmul(phr[i], phc[c0 + j]);
         const real2 t = cmul(cmul_conj(a[k], hh), ph);
         const real2 vh = cscale(cadd(s[e], t), rdiv);

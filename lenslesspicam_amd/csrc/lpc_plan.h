@@ -120,6 +120,8 @@ struct EngineOpts {
                               // register middle.  -1: the middle, when a work spectrum is larger than the memory-side
                               // cache (12 MP FISTA 80.3 -> 75.5 ms per 40 iterations; 152-MB spectra: +1 %, off)
   int seq_t = 0, mid_nt = 0;  // tuning: columns per tile of the sequential middle (4 | 8 | 16), lanes per middle workgroup
+  int g_plane = -1;           // ADMM middles read |PsiT Psi| from its plane (1) / as row + column terms when it separates (0);
+                              // -1: the terms when the plane is larger than 8 MB (it then misses the L2 once per colour plane)
   int seq_tiles_first = 0;    // sequential middle: workgroups handed out column tiles fastest instead of frames fastest
   int mid_swz = -1;           // side-by-side LDS middle: pairs of column tiles on one XCD (ColPass::swz); -1: when a tile
                               // row is narrower than a 128-byte line
@@ -168,6 +170,7 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "seq_t") o.seq_t = (int)iv;
       else if (k == "mid_nt") o.mid_nt = (int)iv;
       else if (k == "seq_tiles_first") o.seq_tiles_first = (int)iv;
+      else if (k == "g_plane") o.g_plane = (int)iv;
       else if (k == "mid_swz") o.mid_swz = (int)iv;
       else if (k == "hv_full") o.hv_full = (int)iv;
       else if (k == "xi_full") o.xi_full = (int)iv;

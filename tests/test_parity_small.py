@@ -762,3 +762,41 @@ def test_tiny_frames_circular_neighbours(backend, shape):
     want = np.asarray(o.apply(8))
     assert float(np.abs(want).max()) > 0
     assert rel(rec.apply(n_iter=8, disp_iter=None), want) <= 1e-5, rec._handle.plan_info()
+
+
+def test_gram_as_row_and_column_terms(backend, monkeypatch):
+    """The reference's finite-difference gram |PsiT Psi| (admm.py:385-397) is a row term plus a column term; the engine
+    detects that at set-up and its fused middles read two vectors instead of the plane (option g_plane=1: the plane).
+    Both forms against the float64 oracle, on a single-pass and on a split column plan; a caller's psi_gram that does not
+    separate keeps the plane."""
+    for opts, shape in (({}, (40, 56, 3)), ({"tile_budget": 512, "col_t": 4, "jit_min_points": 0}, (33, 50, 1))):
+        H, W, C = shape
+        rng = np.random.default_rng(H)
+        psf = orc.synthetic_psf(1, H, W, C, seed=3)
+        y = rng.random((H, W, C), dtype=np.float32)
+        kw = dict(tau=2e-4, mu2=1e-3)
+        o = orc.ADMMOracle(psf, dtype=torch.float64, **kw)
+        o.set_data(y)
+        want = np.asarray(o.apply(6))
+        outs = {}
+        for g_plane in (0, 1):
+            rec = lpa.ADMM(torch.from_numpy(psf), engine_options={**opts, "g_plane": g_plane}, **kw)
+            info = rec._handle.plan_info()
+            assert ("gram as row + column terms" in info) == (g_plane == 0), info
+            rec.set_data(torch.from_numpy(y))
+            outs[g_plane] = rec.apply(n_iter=6, disp_iter=None)
+            assert rel(outs[g_plane], want) <= 5e-6, info
+        assert rel(outs[0], outs[1]) <= 5e-6
+
+    def gram(shape):                        # a gram that is NOT separable: r * c term
+        D, Hp, Wp, Cc = shape
+        gsp = np.zeros(shape, dtype=np.float32)
+        gsp[0, 0, 0] = 4.0
+        gsp[0, 1 % Hp, 1 % Wp] = gsp[0, -1, -1] = -1.0
+        gsp[0, 0, 1] = gsp[0, 0, -1] = -1.0
+        return torch.fft.rfft2(torch.from_numpy(gsp), dim=(-3, -2))
+
+    psf = orc.synthetic_psf(1, 24, 32, 1, seed=5)
+    rec = lpa.ADMM(torch.from_numpy(psf), psi=lambda x: torch.stack([x, x], dim=-1), psi_adj=lambda u: u.sum(-1),
+                   psi_gram=gram)
+    assert "gram as row + column terms" not in rec._handle.plan_info()
