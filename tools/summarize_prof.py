@@ -52,6 +52,7 @@ cols = ["FETCH_SIZE", "WRITE_SIZE", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_IN
 lines.append("| kernel | wg | LDS B | VGPR | SGPR | n | HBM GB | " + " | ".join(cols) + " |")
 lines.append("|---|---|---|---|---|---|---|" + "---|" * len(cols))
 traffic = {}
+ndisp = {}
 for k in sorted(agg):
     if not k.startswith("k_"):
         continue
@@ -62,6 +63,7 @@ for k in sorted(agg):
     if mean.get("FETCH_SIZE") is not None and mean.get("WRITE_SIZE") is not None:
         hbm = (2 * mean["FETCH_SIZE"] + mean["WRITE_SIZE"]) * 1024
         traffic[k] = hbm
+        ndisp[k] = n
     wg, lds, vg, sg = meta[k]
     lines.append(f"| {k} | {wg} | {lds} | {vg} | {sg} | {n} | {hbm / 1e9:.3f} | " if hbm else
                  f"| {k} | {wg} | {lds} | {vg} | {sg} | {n} | - | ")
@@ -100,9 +102,9 @@ if plan and "plan module " in plan:
     key = plan.split("plan module ")[1].strip()
     entry = {"plan_module": key, "workload": workload, "snapshot": tag, "n_iter": 40, "source": f"profiles/{tag}_counters.md",
              "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, median per dispatch", "kernels": {}}
-    for k, v in traffic.items():
-        kid = kid_of(k)
-        if kid:
+    for k, v in sorted(traffic.items(), key=lambda kv: ndisp.get(kv[0], 0)):      # the hot-loop kernel of an id is the
+        kid = kid_of(k)                                                              # one dispatched most often (set-up
+        if kid:                                                                      # transforms share some ids)
             entry["kernels"][kid] = {"kernel": k, "hbm_bytes_per_launch": v}
     tf = os.path.join(out, "traffic.json")
     tj = json.load(open(tf)) if os.path.exists(tf) else {"plans": []}
