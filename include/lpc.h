@@ -189,7 +189,9 @@ int lpc_admm_pnp_end(lpc_handle h, int use_dual, const lpc_real* dev_U, void* st
  * soft-threshold itself; the engine does everything else of `_update` (admm.py:252-329) in one call:
  *   lpc_set_psi_gram   |psi_gram(padded_shape)| (real, (Hp, Wc), NATURAL frequency order, one plane shared by all
  *                      channels) replaces the finite-difference gram in R_divmat (admm.py:186-190).  Call after
- *                      lpc_set_psf (which restores the default gram).
+ *                      lpc_set_psf (which restores the default gram).  Synchronises `stream` once: the engine checks
+ *                      on the device whether the plane is a row term + a column term (the finite-difference gram is)
+ *                      and, for planes above 8 MB, lets its fused middles read the two vectors instead (option g_plane).
  *   lpc_admm_psi_step  dev_psit = Psi^T(mu2 U - eta) as (B,D,Hp,Wp,C): X and W updates, r_k = (mu3 W - rho) + dev_psit +
  *                      H^T(mu1 X - xi), the spectral image update, the xi and rho updates.  The new estimate is
  *                      lpc_get_state("image_est"); the caller then updates Psi(V) and eta (admm.py:302-308).
