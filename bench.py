@@ -20,7 +20,9 @@ Rank 0 prints ONE JSON line.  On top of the driver's contract it carries:
                 V_old, eta0, eta1, rho, writes eta0, eta1, rho, r_sp -- DESIGN.md section 4; the X half rides in the
                 forward row kernel, listed under `kernels`) / mean launch duration from HIP events recorded inside the
                 timed region; `traffic` = HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/traffic.json)
+                (only this kernel's launches are bracketed there: events around all of them cost 1.4-3.4 % of the rate)
   kernels       every kernel of the iteration: mean ms, algorithmic GB, GB/s, and the PMC traffic / algorithmic ratio
+                (rows other than the roofline kernel's: one extra step after the timed region, all launches bracketed)
   cpu_baseline  the CPU oracle (torch-CPU float32 restatement of the reference, kind "port")
                 timed on this host for a bounded sample of the same workload
   parity        full size (12 MP): engine vs the float32 oracle after >= 30 iterations (default AND TV-active
@@ -407,7 +409,10 @@ def main():
     wait_gather()
     torch.cuda.synchronize()
     log("timed region")
-    rec._handle.profile_enable(True)
+    # HIP events inside the timed region only around the kernel the roofline reports: bracketing all six to eight launches
+    # of an iteration costs the timed rate 1.4 % (ADMM) to 3.4 % (FISTA) (tools/probe/event_overhead.py); the other kernels'
+    # rows of `kernels` come from one more step after the clock has stopped
+    rec._handle.profile_enable(True, kernels=["spatial"])
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -433,9 +438,14 @@ def main():
         ev1.record()
         torch.cuda.synchronize()
         gather_ms = ev0.elapsed_time(ev1) / 3
+    prof_live = rec._handle.profile_read()
+    log(f"timed region done: {elapsed:.3f} s for {args.steps} step(s)")
+    rec._handle.profile_enable(True)
+    step()
+    wait_gather()
     prof = rec._handle.profile_read()
     rec._handle.profile_enable(False)
-    log(f"timed region done: {elapsed:.3f} s for {args.steps} step(s)")
+    prof["spatial"] = prof_live["spatial"]          # the roofline kernel: the timed region's own launches
 
     # achievable-HBM yardstick measured in the same run: plain device-to-device copy
     copy_gbps = None
@@ -501,6 +511,8 @@ def main():
                 "traffic": traffic, "traffic_source": traffic_src,
             },
             "kernels": kernels,
+            "kernels_note": "spatial: HIP events inside the timed region (the roofline kernel); the other rows: one more "
+                            "step after the timed region with every launch bracketed",
             "alg_GB_per_iteration": round(sum(v["alg_GB"] for v in kernels.values()), 3),
             "survey_model_GB_per_iteration": round(rec._handle.model_bytes() / 1e9, 3),
             "whole_iteration_frac_of_peak": round(rec._handle.model_bytes() * total_iters / world / elapsed / 1e9

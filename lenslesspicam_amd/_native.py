@@ -275,8 +275,13 @@ class Handle:
     def reconstruction_error(self, pred_ptr, data_ptr, normalize, out_ptr, stream=0):
         self._c(self.lib.dll.lpc_reconstruction_error(self.h, pred_ptr, data_ptr, int(normalize), out_ptr, stream))
 
-    def profile_enable(self, on=True):
-        self._c(self.lib.dll.lpc_profile_enable(self.h, int(on)))
+    def profile_enable(self, on=True, kernels=None):
+        """HIP events around the hot-loop launches: all of them, or only the kernel ids named in ``kernels``
+        (names from KERNEL_NAMES) -- what a timed region can afford (include/lpc.h)."""
+        flag = int(bool(on))
+        if on and kernels is not None:
+            flag = sum(2 << KERNEL_NAMES.index(k) for k in kernels)
+        self._c(self.lib.dll.lpc_profile_enable(self.h, flag))
 
     def profile_read(self):
         ms = (C.c_double * K_COUNT)()

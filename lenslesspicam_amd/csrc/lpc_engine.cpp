@@ -1335,6 +1335,7 @@ int lpc_profile_enable(lpc_handle e, int on) {
   for (int k = 0; k < LPC_K_COUNT; ++k) e->timer.used[k] = 0;
 #endif
   e->timer.on = on != 0;
+  e->timer.mask = on > 1 ? (unsigned)on >> 1 : ~0u;      // 1: every hot-loop kernel; otherwise bit k + 1 selects kernel id k
   return 0;
 }
 

@@ -76,6 +76,7 @@ struct KernelTimer {
   size_t used[LPC_K_COUNT] = {0};
 #endif
   bool on = false;
+  unsigned mask = ~0u;      // bit k: launches of kernel id k are bracketed (lpc_profile_enable)
 };
 
 struct lpc_engine {
@@ -181,7 +182,7 @@ static inline int launch_k(Engine* e, int kid, K kernel, dim3 grid, int nt, size
     }
   }
 #if !defined(LPC_SIMT_EMU)
-  const bool timed = e->timer.on && kid >= 0;
+  const bool timed = e->timer.on && kid >= 0 && ((e->timer.mask >> kid) & 1u);
   size_t slot = 0;
   if (timed) {
     auto& v = e->timer.ev[kid];
