@@ -202,7 +202,8 @@ static void choose_plan(Engine* e, bool allow_static) {
   // the column kernels of a plan module address their tiles with 24-bit row-index x row-step products (k_cols): the step
   // between two rows of one column transform must stay below 2^24 bytes (12 MP: 48 rows x 32.8 KB = 1.6 MB)
   const long col_step = (long)(e->N1 > 1 ? e->N2 : 1) * g.cpitch * (long)sizeof(real2);
-  const bool st_cols = allow_static && !o.no_static_cols && col_step < (1L << 24) && g.Hp < (1 << 24);
+  const bool st_cols = allow_static && !o.no_static_cols && col_step < (1L << 24) && g.Hp < (1 << 24) &&
+                       (unsigned long long)g.Hp * g.cpitch * sizeof(real2) < (1ULL << 32);   // ... and offsets are 32-bit
   // Single-pass ADMM columns whose two-spectra tile allows only 8 image columns (DiffuserCam-sized frames, 540 padded
   // rows): the fused middle takes the two spectra one after the other through the tile (k_cols_mid_admm_seq), one
   // parked in registers while the other is transformed ... when the batch is large enough to fill the chip with
