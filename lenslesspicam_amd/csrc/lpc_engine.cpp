@@ -199,6 +199,10 @@ static void choose_plan(Engine* e, bool allow_static) {
   e->mid_reg = !o.mid_lds;
   // (a 24-point register middle for ADMM in float32 only: 2 x 24 complex128 values do not fit a lane's registers)
   choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, (!admm || f32) && e->mid_reg);
+  // 6144 rows (12 MP), ADMM: 96 x 64 ties with 128 x 48 in choose_split's cost and measures 1.1 % faster per iteration
+  // (same box, three instances each: pass A 0.466 / 0.460 -> 0.448 / 0.434 ms, 64-point middle +0.012 ms; r03z_ab.log);
+  // the gradient-descent family keeps 128 x 48 (its 48-point middle lives in registers)
+  if (admm && f32 && o.split_n2 == 0 && e->N1 == 128 && e->N2 == 48) { e->N1 = 96; e->N2 = 64; }
   // the column kernels of a plan module address their tiles with 24-bit row-index x row-step products (k_cols): the step
   // between two rows of one column transform must stay below 2^24 bytes (12 MP: 48 rows x 32.8 KB = 1.6 MB)
   const long col_step = (long)(e->N1 > 1 ? e->N2 : 1) * g.cpitch * (long)sizeof(real2);

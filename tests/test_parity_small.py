@@ -414,9 +414,10 @@ def test_8192_column_rows_static_plan(backend, monkeypatch, static):
 
 @pytest.mark.parametrize("static", [True, False], ids=["static_plan", "runtime_plan"])
 def test_6144_row_columns_static_plan(backend, monkeypatch, static):
-    """12 MP's COLUMN shape on a frame only 9 columns wide: 3072 rows pad to 6144 = 128 x 48, 16-column tiles -- pass A
-    (128 points = 8.8.2, forward and inverse) and ADMM's fused middle (48 points = 8.6 over both spectra) run on
-    compile-time plans; no_static=1 is the same frame on the run-time plans."""
+    """12 MP's COLUMN shape on a frame only 9 columns wide: 3072 rows pad to 6144 = 96 x 64 for ADMM (pass A 96 points =
+    8.4.3, fused middle 64 points = 8.8 over both spectra) and 128 x 48 for the gradient-descent family (pass A 8.8.2,
+    48-point middle in registers), 16-column tiles -- on compile-time plans; no_static=1 is the same frame on the
+    run-time plans."""
     engine_opts(monkeypatch, jit_min_points=0, no_static=0 if static else 1)
     H, W, C = 3072, 9, 1
     rng = np.random.default_rng(12)
