@@ -123,7 +123,8 @@ static bool radices_skew_ok(int n, const std::vector<int>& rad) {
 }
 
 // choose the column split Hp = N1*N2 and the tile width
-static void choose_split(const EngineOpts& opt, int Hp, int Wc, int* N1, int* N2, int* T, bool prefer24 = false) {
+static void choose_split(const EngineOpts& opt, int Hp, int Wc, int* N1, int* N2, int* T, bool prefer24 = false,
+                         bool admm_f32 = false) {
   int t = 16;
   if (opt.col_t > 0) t = opt.col_t;  // option col_t
   while (t > 1 && t / 2 >= Wc) t /= 2;  // tiny images: do not waste lanes on empty columns
@@ -139,12 +140,16 @@ static void choose_split(const EngineOpts& opt, int Hp, int Wc, int* N1, int* N2
     const int n2 = d, n1 = Hp / d;
     if ((long)n2 * 2 * t > budget / 2 || (long)n1 * t > budget / 2) continue;
     const int cost = std::max(n1, 2 * n2);
-    if (cost < bestcost) { bestcost = cost; best1 = n1; best2 = n2; }
+    // ADMM (float32), equal cost: the shorter pass A and the longer LDS middle -- 6144 rows as 96 x 64 instead of 128 x 48:
+    // pass A 0.466 / 0.460 -> 0.448 / 0.434 ms, middle +0.012 ms, iteration -1.1 % (same box, three instances each)
+    if (cost < bestcost || (admm_f32 && cost == bestcost && n2 > best2)) { bestcost = cost; best1 = n1; best2 = n2; }
   }
   // A 24-point pass B runs the fused middle in registers (k_cols_mid_admm_reg / k_cols_mid_mul_reg<8,3>) with the
   // fewest registers; worth it as long as pass A stays short.  Measured (r01b_notes.md): 2160 rows, 90 x 24 vs
   // 72 x 30: ADMM 72.8 vs 68.3 it/s, FISTA 2134 vs 2013 it/s; 6144 rows, 256 x 24 vs 128 x 48: ADMM 191 vs 204 it/s.
-  if (prefer24 && Hp % 24 == 0 && Hp / 24 <= 128 && Hp / 24 >= 2 && (long)(Hp / 24) * t <= budget / 2) {
+  // (ADMM: up to a 96-point pass A only -- 3072 rows run 1.6 % faster as 64 x 48 with the LDS middle than as 128 x 24,
+  // 82.1 against 83.4-83.7 ms per 100 iterations of a 1520 x 2028 x 3 frame, r03z_ab.log)
+  if (prefer24 && Hp % 24 == 0 && Hp / 24 <= (admm_f32 ? 96 : 128) && Hp / 24 >= 2 && (long)(Hp / 24) * t <= budget / 2) {
     best2 = 24; best1 = Hp / 24;
   }
   if (opt.split_n2 > 0) {  // option split_n2: force the length of the fused middle transform
@@ -198,11 +203,8 @@ static void choose_plan(Engine* e, bool allow_static) {
   e->spec.f64 = f32 ? 0 : 1;
   e->mid_reg = !o.mid_lds;
   // (a 24-point register middle for ADMM in float32 only: 2 x 24 complex128 values do not fit a lane's registers)
-  choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, (!admm || f32) && e->mid_reg);
-  // 6144 rows (12 MP), ADMM: 96 x 64 ties with 128 x 48 in choose_split's cost and measures 1.1 % faster per iteration
-  // (same box, three instances each: pass A 0.466 / 0.460 -> 0.448 / 0.434 ms, 64-point middle +0.012 ms; r03z_ab.log);
-  // the gradient-descent family keeps 128 x 48 (its 48-point middle lives in registers)
-  if (admm && f32 && o.split_n2 == 0 && e->N1 == 128 && e->N2 == 48) { e->N1 = 96; e->N2 = 64; }
+  // (the gradient-descent family keeps 128 x 48 at 6144 rows: its 48-point middle lives in registers)
+  choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, (!admm || f32) && e->mid_reg, admm && f32);
   // the column kernels of a plan module address their tiles with 24-bit row-index x row-step products (k_cols): the step
   // between two rows of one column transform must stay below 2^24 bytes (12 MP: 48 rows x 32.8 KB = 1.6 MB)
   const long col_step = (long)(e->N1 > 1 ? e->N2 : 1) * g.cpitch * (long)sizeof(real2);
