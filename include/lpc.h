@@ -91,7 +91,7 @@ typedef struct lpc_config {
  *   rev_order=BITS     which ADMM kernels walk their grids backwards (1 tiled kernel, 2 / 4 forward / inverse pass A,
  *                      8 LDS middle; default 9);  rev_rows=BITS (1 / 2 forward / inverse ADMM rows; default 0);
  *                      gd_rev=BITS (gradient-descent family / operator: 1 residual rows, 2 update rows, 4 register middle;
- *                      default: the middle when a work spectrum exceeds the 256-MB memory-side cache)
+ *                      default: all three when a work spectrum exceeds the 256-MB memory-side cache)
  *   mid_swz=0|1        side-by-side middle: adjacent column tiles on one XCD (default: when a tile row is < 128 bytes)
  *   xi_full=1 hv_full=1 no_xhalf=1 k1_scalar=1      ADMM without the sensor-window structure of xi / of the H V row
  *                      transforms; with the stand-alone image-domain kernel; ... in its scalar-lane form
