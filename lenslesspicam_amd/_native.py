@@ -42,6 +42,22 @@ def _options_dict(opts) -> dict:
     return out
 
 
+PATH_OPTIONS = ("module_dir", "compiler")
+
+
+def _option_value(key, v) -> str:
+    """one value of the option string; the separators of the option syntax inside a path travel as %XX escapes
+    (csrc/lpc_plan.h: unescape_opt_path)"""
+    if isinstance(v, bool):
+        return str(int(v))
+    v = str(v)
+    if key in PATH_OPTIONS:
+        return "".join(f"%{ord(ch):02X}" if ch in "%,; \t\n" else ch for ch in v)
+    if any(ch in v for ch in ",; \t\n"):
+        raise ValueError(f"engine option {key}={v!r}: separators are only allowed in path-valued options")
+    return v
+
+
 class Config(C.Structure):
     _fields_ = [
         ("algo", C.c_int),
@@ -164,7 +180,7 @@ class Lib:
                         nesterov_p=0.0, fista_tk=1.0, options=None)
         defaults.update(kw)
         opts = {**DEFAULT_OPTIONS, **_options_dict(defaults["options"])}    # {"hv_full": 1} -> "hv_full=1"
-        opts = ",".join(f"{k}={int(v) if isinstance(v, bool) else v}" for k, v in opts.items())
+        opts = ",".join(f"{k}={_option_value(k, v)}" for k, v in opts.items())
         defaults["options"] = opts.encode() if opts else None
         for k, v in defaults.items():
             setattr(cfg, k, v)
@@ -175,14 +191,22 @@ class Lib:
         Needs no device (lpc_plan_module)."""
         cfg = self._config(kw)
         buf = C.create_string_buffer(1024)
-        self.check(self.dll.lpc_plan_module(C.byref(cfg), int(bool(build)), buf, 512))
+        self.check(self.dll.lpc_plan_module(C.byref(cfg), int(bool(build)), buf, len(buf)))
         return buf.value.decode()
 
     def create(self, **kw) -> "Handle":
         cfg = self._config(kw)
         h = C.c_void_p()
         self.check(self.dll.lpc_create(C.byref(cfg), C.byref(h)))
-        return Handle(self, h, cfg)
+        handle = Handle(self, h, cfg)
+        reason = handle.fallback_reason()
+        if reason and reason not in _warned:           # a frame that SHOULD run on a plan module and does not
+            _warned.add(reason)
+            import warnings
+
+            warnings.warn("lenslesspicam_amd: compile-time plans unavailable, this solver runs on the slower run-time "
+                          f"plans ({reason[:300]})", RuntimeWarning, stacklevel=3)
+        return handle
 
 
 class Handle:
@@ -295,9 +319,18 @@ class Handle:
         return b.value
 
     def plan_info(self):
-        buf = C.create_string_buffer(1024)
-        self._c(self.lib.dll.lpc_plan_info(self.h, buf, 512))
+        buf = C.create_string_buffer(8192)       # (may carry a compiler log when a module failed to build)
+        self._c(self.lib.dll.lpc_plan_info(self.h, buf, len(buf)))
         return buf.value.decode()
+
+    def fallback_reason(self) -> str:
+        """'' when the handle runs the plan it asked for; else why its plan module is missing (no compiler, a failed
+        build, jit=0 ...).  Frames below jit_min_points and no_static=1 never ask for a module."""
+        info = self.plan_info()
+        if "; run-time plans (" not in info:
+            return ""
+        reason = info.split("; run-time plans (", 1)[1].rsplit(")", 1)[0]
+        return "" if reason in ("no_static", "small frame") else reason
 
     def model_bytes(self):
         b = C.c_double()
@@ -311,6 +344,7 @@ class Handle:
 
 
 _default = {}
+_warned = set()
 
 
 def default_lib(dtype: str = "float32") -> Lib:

@@ -43,6 +43,19 @@ def fingerprint():
     return h.hexdigest()[:12]
 
 
+def sources_crc():
+    """CRC-32 the library carries of its own sources (csrc/lpc_jit.cpp: sources_crc recomputes it before it compiles a
+    plan module, so that a module can never come from sources edited after the library was built)"""
+    import zlib
+
+    crc = 0
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".cpp", ".inc")))
+    for path in [os.path.join(CSRC, f) for f in names] + [os.path.join(ROOT, "include", "lpc.h")]:
+        crc = zlib.crc32(os.path.basename(path).encode(), crc)
+        crc = zlib.crc32(open(path, "rb").read(), crc)
+    return crc & 0xFFFFFFFF
+
+
 FP_FILE = os.path.join(HERE, "_lib", "BUILD_FP")
 
 
@@ -61,8 +74,10 @@ def build_hip(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     fp = fingerprint()
     base = [hipcc, "-std=c++17", "-O3", "--offload-arch=gfx950", "-fPIC", "-x", "hip",
-            "-I", os.path.join(ROOT, "include"), "-I", CSRC, f'-DLPC_SRC_FP="{fp}"']
+            "-I", os.path.join(ROOT, "include"), "-I", CSRC, f'-DLPC_SRC_FP="{fp}"', f"-DLPC_SRC_CRC=0x{sources_crc():08x}u"]
     extra_defs = os.environ.get("LPC_EXTRA_DEFS", "").split()    # e.g. -DLPC_DEBUG_KNOBS for timing experiments
+    if extra_defs:                                               # ... which the library hands on to its plan modules
+        base.append('-DLPC_MODULE_EXTRA_DEFS="' + " ".join(extra_defs) + '"')
     flavours = (("f32", OUT, extra_defs), ("f64", OUT_F64, ["-DLPC_DOUBLE"] + extra_defs))
     for stale in os.listdir(OBJ):                                 # objects of units that no longer exist
         if stale.rsplit(".", 2)[0] + ".cpp" not in {os.path.basename(u) for u in units()}:
@@ -114,8 +129,13 @@ def build_modules(verbose=True):
 
     os.makedirs(MODULES, exist_ok=True)
     jobs = [(_native.Lib(OUT), kw) for kw in PREBUILT] + [(_native.Lib(OUT_F64), kw) for kw in PREBUILT_F64]
+    keys = [lib.plan_module(build=False, **kw) for lib, kw in jobs]
+    todo = {}                        # several configurations may share one module (C4's batch sizes, C5 and its planes)
+    for (lib, kw), key in zip(jobs, keys):
+        if key:
+            todo.setdefault((lib.path, key), (lib, kw))
     with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as pool:      # ctypes releases the GIL
-        keys = list(pool.map(lambda j: j[0].plan_module(build=True, **j[1]), jobs))
+        list(pool.map(lambda j: j[0].plan_module(build=True, **j[1]), todo.values()))   # (no-op for modules on disk)
     if verbose:
         for (lib, kw), key in zip(jobs, keys):
             print(f"plan module {lib.real} {kw}: {key or '(run-time plans)'}", flush=True)

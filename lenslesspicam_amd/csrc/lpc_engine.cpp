@@ -773,6 +773,8 @@ int lpc_destroy(lpc_handle e) {
   if (!e) return 0;
   (void)rt::stream_sync(e->stream);
   for (void* p : e->allocs) (void)rt::dev_free(p);
+  release_plan_module(e->mod);
+  e->mod = nullptr;
 #if !defined(LPC_SIMT_EMU)
   for (auto& v : e->timer.ev)
     for (auto& pr : v) { (void)hipEventDestroy(pr.first); (void)hipEventDestroy(pr.second); }

@@ -258,7 +258,8 @@ struct LpcModule {
 };
 // lpc_jit.cpp: the module of `spec` -- from the process cache, from disk, or (allow_compile) compiled now; null + `why`
 const LpcModule* get_plan_module(const PlanSpec& spec, const EngineOpts& opt, bool allow_compile, std::string* why);
-int build_plan_module(const PlanSpec& spec, const EngineOpts& opt, std::string* path_or_error);   // compile only (no load)
+void release_plan_module(const LpcModule* mod);     // a handle that got a module from get_plan_module is done with it
+int build_plan_module(const PlanSpec& spec, const EngineOpts& opt, std::string* path_or_error);   // compile only (no load); no-op when the module is on disk
 
 // ---- host functions that cross translation units ------------------------------------------------------------
 // lpc_rows.cpp

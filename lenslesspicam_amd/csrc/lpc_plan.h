@@ -11,6 +11,7 @@
 //     5-smooth frame (the reference accepts them all, rfft_convolve.py:110-117) gets the same kernels on first use.
 // PlanSpec is everything that is a template argument in a module; its key names the file.
 #pragma once
+#include <cctype>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -137,7 +138,23 @@ struct EngineOpts {
                               // product is the transform length and every radix has a butterfly
   std::string module_dir;     // where plan modules are looked for and written first (default: <libdir>/modules)
   std::string compiler;       // hipcc to compile a missing module with (default: $ROCM_PATH/bin/hipcc, /opt/rocm/bin/hipcc)
+  int module_max = 256;       // module files kept in a directory this library writes to (least recently used go first)
+  int module_loaded_max = 64; // modules kept dlopen()ed by a process once no handle uses them
 };
+
+// path-valued options (module_dir, compiler) may contain the separators below as %XX escapes ("%2C" = ','; "%25" = '%')
+static inline std::string unescape_opt_path(const std::string& v) {
+  std::string r;
+  for (size_t i = 0; i < v.size(); ++i) {
+    if (v[i] == '%' && i + 2 < v.size() && std::isxdigit((unsigned char)v[i + 1]) && std::isxdigit((unsigned char)v[i + 2])) {
+      r += (char)std::strtol(v.substr(i + 1, 2).c_str(), nullptr, 16);
+      i += 2;
+    } else {
+      r += v[i];
+    }
+  }
+  return r;
+}
 
 // parses "k=v,k=v" (also ';' or whitespace as separators) into o; returns "" or an error message
 static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
@@ -183,8 +200,10 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "row_rad") o.row_rad = v;
       else if (k == "passa_rad") o.passa_rad = v;
       else if (k == "mid_rad") o.mid_rad = v;
-      else if (k == "module_dir") o.module_dir = v;
-      else if (k == "compiler") o.compiler = v;
+      else if (k == "module_dir") o.module_dir = unescape_opt_path(v);
+      else if (k == "compiler") o.compiler = unescape_opt_path(v);
+      else if (k == "module_max") o.module_max = (int)iv;
+      else if (k == "module_loaded_max") o.module_loaded_max = (int)iv;
       else return "unknown engine option '" + k + "'";
     }
     i = j + 1;

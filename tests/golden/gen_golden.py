@@ -433,6 +433,86 @@ def custom_psi_case(name):
           float(np.count_nonzero(out["state_U"]) / out["state_U"].size))
 
 
+
+# ---- every legal `norm` and PSF scale (rfft_convolve.py:27,121; admm.py:50,101; recon.py:203-329 never normalises) ----
+LADDER = (
+    # tag, norm, PSF scale rule
+    ("backward_l2", "backward", "l2"),        # the loaders' convention (io.py:375): unit l2 norm
+    ("ortho_l2", "ortho", "l2"),
+    ("forward_l2", "forward", "l2"),
+    ("backward_l2_1em3", "backward", "l2*1e-3"),
+    ("backward_max1", "backward", "max"),     # psf / psf.max()
+    ("backward_0_255", "backward", "255"),    # an 8-bit PSF left as it came
+)
+
+
+def scale_psf(psf, rule):
+    psf = psf.astype(np.float64)
+    psf = psf / np.linalg.norm(psf.ravel())
+    if rule == "l2*1e-3":
+        psf = psf * 1e-3
+    elif rule == "max":
+        psf = psf / psf.max()
+    elif rule == "255":
+        psf = np.round(psf / psf.max() * 255.0)
+    return psf.astype(np.float32)
+
+
+def norm_scale_case(name, shapes=((36, 52, 3), (37, 53, 3))):
+    """ADMM (defaults and TV-active), FISTA and the bare operator for every legal `norm` and a ladder of PSF scales.
+    Stored per entry: the FLOAT64 run (the truth a float32 implementation is measured against; sensor-window crop of
+    the padded ADMM estimate, taken by slicing -- no in-place clamp) and, as scalars, how far the reference's own
+    float32 run is from it (max |difference| / max |truth|): the yardstick of tests/test_norm_scale.py.  The second
+    (odd-sized) shape carries a shorter ladder to keep the fixture small."""
+    ladders = (LADDER, tuple(l for l in LADDER if l[0] in ("backward_l2", "forward_l2", "backward_max1")))
+    out = {"admm_iters": np.array([6, 20]), "fista_iters": np.array([40]), "tv_params": np.array([2e-6, 1e-4])}
+
+    def dist(a, b):
+        return float(np.abs(a.astype(np.float64) - b).max() / np.abs(b).max())
+
+    for si, (h, w, c) in enumerate(shapes):
+        rng = np.random.default_rng(300 + si)
+        base = rng.random((1, h, w, c)) ** 6
+        data = rng.random((h, w, c)).astype(np.float32)
+        data /= data.max()
+        x = rng.random((1, 1, h, w, c)).astype(np.float32)
+        out[f"s{si}_shape"] = np.array([h, w, c])
+        out[f"s{si}_data"], out[f"s{si}_x"] = data, x
+        out[f"s{si}_tags"] = np.array([l[0] for l in ladders[si]])
+        out[f"s{si}_norms"] = np.array([l[1] for l in ladders[si]])
+        for tag, norm, rule in ladders[si]:
+            psf = scale_psf(base, rule)
+            out[f"s{si}_{tag}_psf"] = psf
+            res = {}
+            for dt, tdt in (("f32", torch.float32), ("f64", torch.float64)):
+                dtype = "float32" if dt == "f32" else "float64"
+                r = res.setdefault(dt, {})
+                cv = RealFFTConvolve2D(t(psf).to(tdt), dtype=tdt, pad=True, norm=norm)
+                r["conv"] = cv.convolve(t(x).to(tdt)).numpy()
+                for ptag, kw in (("dflt", {}), ("tv", dict(tau=2e-6, mu2=1e-4))):
+                    rec = ADMM(t(psf).to(tdt), dtype=dtype, norm=norm, **kw)
+                    rec.set_data(t(data).to(tdt))
+                    rec.reset()
+                    s0, s1 = [int(v) for v in rec._convolver._start_idx]
+                    for i in range(20):
+                        rec._update(i)
+                        if i + 1 in (6, 20) and (ptag == "dflt" or i + 1 == 20):
+                            r[f"admm_{ptag}_it{i + 1}"] = rec._image_est.numpy()[0, :, s0:s0 + h, s1:s1 + w].copy()
+                            if i + 1 == 6:
+                                r[f"admm_{ptag}_it6_HV"] = rec._forward_out.numpy()[0, :, s0:s0 + h, s1:s1 + w].copy()
+                fis = FISTA(t(psf).to(tdt), dtype=dtype, norm=norm)
+                fis.set_data(t(data).to(tdt))
+                fis.reset()
+                for i in range(40):
+                    fis._update(i)
+                r["fista_it40"] = fis._image_est.numpy()[0].copy()
+            for k, v in res["f64"].items():
+                out[f"s{si}_{tag}_{k}"] = v
+                out[f"s{si}_{tag}_{k}_ref32"] = np.array(dist(res["f32"][k], v))
+            print(name, si, tag, {k: f"{float(out[f's{si}_{tag}_{k}_ref32']):.1e}" for k in res["f64"]})
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **out)
+
+
 def operator_case():
     rng = np.random.default_rng(5)
     out = {}
@@ -498,6 +578,9 @@ def return_fft_case(name):
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(4)
+    if len(sys.argv) > 1 and sys.argv[1] == "norm_scale":
+        norm_scale_case("norm_scale_ladder")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "return_fft":
         return_fft_case("return_fft")
         sys.exit(0)
@@ -561,5 +644,7 @@ if __name__ == "__main__":
     display_case("apply_display")
     custom_psi_case("custom_psi_admm")
     caller_flow_case("caller_flow")
+    norm_scale_case("norm_scale_ladder")
+    return_fft_case("return_fft")
     # profile/gradient_descent.py settings (n_iter=300, gray, float32) at reduced size
     gd_case("fista_profile_gray", FISTA, 38, 50, 1, seed=18, iters=[300])

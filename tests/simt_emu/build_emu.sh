@@ -8,6 +8,8 @@ mkdir -p _build/o32 _build/o64 _build/modules
 CSRC=../../lenslesspicam_amd/csrc
 FP=$(cat $CSRC/*.h $CSRC/*.cpp $CSRC/*.inc ../../include/lpc.h emu.cpp | sha1sum | cut -c1-12)
 CXX="g++ -std=c++17 -O2 -fPIC -DLPC_SIMT_EMU -I$CSRC -I../../include -DLPC_SRC_FP=\"$FP\""
+CRC=$(python3 -c "import sys; sys.path.insert(0, '../..'); from lenslesspicam_amd import build; print('0x%08xu' % build.sources_crc())")
+CXX="$CXX -DLPC_SRC_CRC=$CRC"
 CXX="$CXX -DLPC_CSRC_REL=\"../../../lenslesspicam_amd/csrc\" -DLPC_INCLUDE_REL=\"../../../include\""
 pids=""
 for f in $CSRC/*.cpp emu.cpp; do

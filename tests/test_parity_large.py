@@ -282,3 +282,73 @@ def test_random_shapes_get_plan_modules_and_match_the_oracle(seed):
     oc = orc.ConvolverOracle(psf, pad=True)
     x = torch.from_numpy(rng.standard_normal((1, D, H, W, C)).astype(np.float32))
     assert rel(cv.convolve(x.cuda()), oc.convolve(x)) <= 5e-6 and rel(cv.deconvolve(x.cuda()), oc.deconvolve(x)) <= 5e-6
+
+
+def test_no_compiler_on_the_gpu(tmp_path):
+    """A deployment box without hipcc: a shape whose module is not on disk runs on the run-time
+    plans of the core library -- identical results to float32 round-off, `plan_info` says so, exactly one warning."""
+    import warnings
+
+    from lenslesspicam_amd import _native
+
+    torch.set_num_threads(16)
+    H, W, C = 333, 517, 3                          # on nobody's list
+    rng = np.random.default_rng(77)
+    psf = orc.synthetic_psf(1, H, W, C, seed=7)
+    y = rng.random((H, W, C), dtype=np.float32)
+    kw = dict(tau=2e-6, mu2=1e-4)
+    opts = {"compiler": "/nonexistent/hipcc", "module_dir": str(tmp_path / "none")}
+    _native._warned.clear()
+    with warnings.catch_warnings(record=True) as caught:
+        warnings.simplefilter("always")
+        rec = lpa.ADMM(torch.from_numpy(psf).cuda(), engine_options=opts, **kw)
+        fis = lpa.FISTA(torch.from_numpy(psf).cuda(), engine_options=opts)
+        rec_again = lpa.ADMM(torch.from_numpy(psf).cuda(), engine_options=opts, **kw)
+    info = rec._handle.plan_info()
+    assert "run-time plans (" in info and "no hipcc" in info and "plan module" not in info, info
+    assert rec_again._handle.fallback_reason() and fis._handle.fallback_reason()
+    mine = [str(w.message) for w in caught if "run-time plans" in str(w.message)]
+    assert len(mine) == 1, mine                    # one reason, reported once
+    rec.set_data(torch.from_numpy(y).cuda())
+    got = rec.apply(n_iter=6, disp_iter=None)
+    with_module = lpa.ADMM(torch.from_numpy(psf).cuda(), engine_options={"module_dir": str(tmp_path / "mods")}, **kw)
+    assert "plan module" in with_module._handle.plan_info()
+    with_module.set_data(torch.from_numpy(y).cuda())
+    want = with_module.apply(n_iter=6, disp_iter=None)
+    assert rel(got, want) <= 3e-6
+    o = orc.ADMMOracle(psf, dtype=torch.float64, **kw)
+    o.set_data(y)
+    assert rel(got, o.apply(6)) <= 1e-5
+    fis.set_data(torch.from_numpy(y).cuda())
+    of = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
+    of.set_data(y)
+    assert rel(fis.apply(n_iter=6, disp_iter=None), of.apply(6)) <= 1e-5
+
+
+def test_modules_unload_on_the_gpu(tmp_path):
+    """option module_loaded_max: HIP plan modules nobody uses are dlclose()d (their code objects unregistered) and load
+    again from disk when the shape returns -- bit-identical results, other handles unaffected."""
+    torch.set_num_threads(16)
+    opts = {"module_dir": str(tmp_path / "m"), "module_loaded_max": 1}
+    rng = np.random.default_rng(5)
+
+    def run(h, w, keep=False):
+        psf = torch.from_numpy(orc.synthetic_psf(1, h, w, 1, seed=h)).cuda()
+        y = torch.from_numpy(rng.random((h, w, 1), dtype=np.float32)).cuda()
+        rec = lpa.ADMM(psf, tau=2e-6, mu2=1e-4, engine_options=opts)
+        assert "plan module" in rec._handle.plan_info()
+        rec.set_data(y)
+        out = rec.apply(n_iter=3, disp_iter=None).clone()
+        torch.cuda.synchronize()
+        if not keep:
+            rec._handle.close()
+        return psf, y, out, rec
+
+    a = run(300, 400)
+    b = run(310, 410, keep=True)                  # stays referenced: must survive the unloading around it
+    run(320, 420)
+    run(330, 430)
+    again = lpa.ADMM(a[0], tau=2e-6, mu2=1e-4, engine_options=opts)
+    again.set_data(a[1])
+    assert torch.equal(again.apply(n_iter=3, disp_iter=None), a[2])
+    assert torch.equal(b[3].apply(n_iter=3, disp_iter=None), b[2])
