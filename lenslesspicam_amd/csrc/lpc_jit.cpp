@@ -270,7 +270,7 @@ struct Slot {
   std::atomic<int> refs{0};
   unsigned long last_use = 0;
   bool failed = false, compile_tried = false;
-  std::string note;
+  std::string note, fail_env;          // fail_env: compiler + module directory of the handle that failed
   std::chrono::steady_clock::time_point failed_at;
 };
 std::mutex g_table_mu;
@@ -316,9 +316,9 @@ const LpcModule* get_plan_module(const PlanSpec& spec, const EngineOpts& opt, bo
     Slot& s = *slot;
     if (!s.mod && s.failed) {
       // a failure is remembered (and reported once) -- but not for ever: a handle that may compile retries what an
-      // earlier jit=0 handle could not, and a failed compile / load is retried after a minute (full disk, a module
-      // half-written by a dying neighbour, ...)
-      const bool retry = (allow_compile && !s.compile_tried) ||
+      // earlier jit=0 handle could not, one that names another compiler or module directory retries at once, and a
+      // failed compile / load is retried after a minute (full disk, a module half-written by a dying neighbour, ...)
+      const bool retry = (allow_compile && !s.compile_tried) || s.fail_env != opt.compiler + "|" + opt.module_dir ||
                          std::chrono::steady_clock::now() - s.failed_at > std::chrono::seconds(60);
       if (!retry) { if (why) *why = s.note; return nullptr; }
       s.failed = false;
@@ -354,6 +354,7 @@ const LpcModule* get_plan_module(const PlanSpec& spec, const EngineOpts& opt, bo
       }
       if (!s.mod) {
         s.failed = true;
+        s.fail_env = opt.compiler + "|" + opt.module_dir;
         s.failed_at = std::chrono::steady_clock::now();
         s.note = note;
         std::fprintf(stderr, "lenslesspicam_amd: compile-time plans unavailable, using run-time plans (%s)\n", note.c_str());

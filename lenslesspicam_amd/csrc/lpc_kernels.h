@@ -159,7 +159,34 @@ static __device__ __forceinline__ void tangle_r2_load(real2* s, int Wp, const re
   }
 }
 
-// ---- forward, ADMM: row r of array A and row r of array B -> spectra SA, SB ------------
+// ---- ADMM, paired rows: which two rows a workgroup transforms ------------------------------------------------------
+// Two real rows share one complex transform of length Wp -- always two rows of the SAME array (rows r, r + 1 of r_sp; of
+// `a`; of V; of H V).  Round 3 paired row r of one array with row r of the other (r_sp with a, V with H V): the smaller
+// signal then inherits eps x |larger signal| of rounding noise through the Hermitian separation, which the reference
+// does not have (it transforms every array on its own) -- 2e-5 instead of 4e-7 after six iterations with norm="forward"
+// or a PSF scaled to l2 = 1e-3, where a and H V sit 3-6 decades below r_sp and V (tests/test_norm_scale.py).  Two
+// adjacent rows of one array are of one magnitude, like the rows of the reference's own 2-D transform.
+// Array 0 always has all its rows transformed: pairs (2j, 2j + 1), j < nA = ceil(Hp / 2).  Array 1 either likewise
+// (nB = nA) or on the rows of the sensor window alone: pairs (sh + 2j, sh + 2j + 1), j < nB = ceil(H / 2)
+// (AdmmScalars::skipa / skiphv).  grid.x = nA + nB; the first 2 nB blocks alternate between the arrays (block b runs on
+// XCD b % 8, flipped every eighth block so that every XCD gets both kinds), the rest are array 0.
+struct PairedRows { int arr, r0; bool second; };
+static inline int paired_rows_count(int rows) { return (rows + 1) >> 1; }
+static inline int paired_rows_grid(const PlaneGeom& g, bool window_b) {
+  return paired_rows_count(g.Hp) + paired_rows_count(window_b ? g.H : g.Hp);
+}
+static __device__ __forceinline__ PairedRows paired_rows_of(const PlaneGeom& g, unsigned bx, bool window_b) {
+  const int nB = ((window_b ? g.H : g.Hp) + 1) >> 1;
+  PairedRows r;
+  int idx;
+  if ((int)bx < 2 * nB) { r.arr = (int)((bx ^ (bx >> 3)) & 1u); idx = (int)(bx >> 1); }
+  else { r.arr = 0; idx = (int)bx - nB; }
+  if (r.arr == 1 && window_b) { r.r0 = g.sh + 2 * idx; r.second = r.r0 + 1 < g.sh + g.H; }
+  else { r.r0 = 2 * idx; r.second = r.r0 + 1 < g.Hp; }
+  return r;
+}
+
+// ---- forward, ADMM: rows (r, r + 1) of array A -> SA, of array B -> SB ------------
 template <int NT, int EMAX, bool SK, bool R2, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, PL plan,
                                                      const real* LPC_RESTRICT A,
@@ -168,20 +195,22 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, PL plan,
                                                      real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, row = blockIdx.x;
+  const int tid = threadIdx.x;
   const long pl = blockIdx.y;
-  const real* a = A + pl * g.rplane + (long)row * g.rpitch;
-  const real* b = B + pl * g.rplane + (long)row * g.rpitch;
-  auto src = [&](int i, int) { return make_real2(a[i], b[i]); };
+  const PairedRows pr = paired_rows_of(g, blockIdx.x, false);
+  const real* a = (pr.arr ? B : A) + pl * g.rplane + (long)pr.r0 * g.rpitch;
+  const real* b = a + g.rpitch;
+  const bool v1 = pr.second;
+  auto src = [&](int i, int) { return make_real2(a[i], v1 ? b[i] : (real)0.); };
   if constexpr (is_static_plan<PL>::value)     // compile-time plans: no radix-2 folding (R2 == false)
     fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
   else
     fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{}, NoFix{}, 0,
                                                R2 ? 1 : 0);
-  real2* oa = SA + pl * g.cplane + (long)row * g.cpitch;
-  real2* ob = SB + pl * g.cplane + (long)row * g.cpitch;
-  if (R2) untangle_r2_store<NT, SK>(s, g.Wp, plan.tw, oa, ob, true, tid);
-  else untangle_store<NT, SK>(s, g.Wp, g.Wc, oa, ob, true, tid);
+  real2* oa = (pr.arr ? SB : SA) + pl * g.cplane + (long)pr.r0 * g.cpitch;
+  real2* ob = oa + g.cpitch;
+  if (R2) untangle_r2_store<NT, SK>(s, g.Wp, plan.tw, oa, ob, v1, tid);
+  else untangle_store<NT, SK>(s, g.Wp, g.Wc, oa, ob, v1, tid);
 }
 
 // ---- ADMM rows, one real row per HALF-length complex transform ---------------------------------------
@@ -332,23 +361,10 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows_half(PlaneGeom g, PL plan, con
   untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, S + pl * g.cplane + (long)(src.out_row0 + r) * g.cpitch, tid);
 }
 
-// ---- inverse, ADMM: spectra SA, SB -> real arrays A, B (no shift, padded) ---------------
+// ---- inverse, ADMM: spectra SA, SB -> real arrays A, B (no shift, padded), two rows of one array per transform -------
 // R2: `plan` is the inverse-row plan whose FIRST stage is the radix-2 one (fused into the tangling); SK is
 // false in that case (the skew is not affine for ns = 2).
-// Rows outside the sensor window taken two at a time (paired-row kernels, AdmmScalars::skipa / skiphv): pair index q ->
-// first row; the rows above the window [0, sh) come first, then the rows below it [sh + H, Hp); an odd count leaves a
-// last pair whose second row is not valid.
-static __device__ __forceinline__ int outside_pair_row(const PlaneGeom& g, int q, bool& second_valid) {
-  const int n0 = g.sh, n1 = g.Hp - (g.sh + g.H), np0 = (n0 + 1) >> 1;
-  const bool below = q >= np0;
-  const int pi = below ? q - np0 : q;
-  second_valid = 2 * pi + 1 < (below ? n1 : n0);
-  return (below ? g.sh + g.H : 0) + 2 * pi;
-}
-static inline int outside_pair_count(const PlaneGeom& g) {
-  return ((g.sh + 1) >> 1) + ((g.Hp - (g.sh + g.H) + 1) >> 1);
-}
-
+// window_only (AdmmScalars::skiphv): B (= H V) is produced on the rows of the sensor window alone (paired_rows_of).
 template <int NT, int EMAX, bool SK, bool R2, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, PL plan,
                                                      const real2* LPC_RESTRICT SA,
@@ -358,20 +374,15 @@ __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, PL plan,
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
   const long pl = LPC_BY(g);
-  const unsigned bx = LPC_BX(g);
-  // window_only (AdmmScalars::skiphv; grid.x = H + outside_pair_count): blocks [0, H) = the rows of the sensor window,
-  // both arrays; the others = two rows of A (= V) outside the window per transform, B (= H V) is not produced there
-  const bool pairs = window_only && (int)bx >= g.H;
-  bool vb = true;
-  const int row = !window_only ? (int)bx
-                               : (pairs ? outside_pair_row(g, (int)bx - g.H, vb) : g.sh + (int)bx);
-  const real2* ia = SA + pl * g.cplane + (long)row * g.cpitch;
-  const real2* ib = pairs ? ia + g.cpitch : SB + pl * g.cplane + (long)row * g.cpitch;
+  const PairedRows pr = paired_rows_of(g, LPC_BX(g), window_only != 0);
+  const bool vb = pr.second;
+  const real2* ia = (pr.arr ? SB : SA) + pl * g.cplane + (long)pr.r0 * g.cpitch;
+  const real2* ib = ia + g.cpitch;
   if (R2) tangle_r2_load<NT>(s, g.Wp, ia, ib, vb, tid);
   else tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, ia, ib, vb, tid);
   __syncthreads();
-  real* a = A + pl * g.rplane + (long)row * g.rpitch;
-  real* b = pairs ? a + g.rpitch : B + pl * g.rplane + (long)row * g.rpitch;
+  real* a = (pr.arr ? B : A) + pl * g.rplane + (long)pr.r0 * g.rpitch;
+  real* b = a + g.rpitch;
   auto out = [&](int i, int, real2 v) { a[i] = v.x; if (vb) b[i] = v.y; };
   if constexpr (is_static_plan<PL>::value)
     fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
@@ -1369,6 +1380,66 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
   }
 }
 
+// ---- the X half of the image-domain work on four adjacent pixels of one row (k_rfwd_half_x, k_rfwd_arrays_x) ---------
+// Loads first (xhalf_load: up to four 16-byte loads, all independent -- callers issue the loads of every quad they own
+// before the arithmetic of the first), then the statements of the X part of k_admm_spatial_v4 (xhalf_apply).
+struct XQuad { real4 hv, xi, ho; real ys[4]; bool ins[4]; bool skip; };
+// row_in: the row lies inside the sensor window; y: that row of the measurement (dereferenced only when row_in);
+// y4: window offset and width allow 16-byte loads of y
+static __device__ __forceinline__ XQuad xhalf_load(const PlaneGeom& g, const AdmmScalars& p, const real* LPC_RESTRICT HV,
+                                                   const real* LPC_RESTRICT HVold, const real* xi,
+                                                   const real* LPC_RESTRICT y, long o_row, bool row_in, bool y4, int q) {
+  XQuad c;
+  const int gc = 4 * q;
+  // the whole quad lies outside the sensor window: HV is all it needs (see AdmmScalars::xiw)
+  c.skip = p.xiw && !(row_in && gc + 4 > g.sw && gc < g.sw + g.W);
+  c.hv = ld4(HV + o_row + gc);
+  c.xi = c.ho = make_real4((real)0., (real)0., (real)0., (real)0.);
+  if (!c.skip) c.xi = ld4(xi + o_row + gc);
+  if (!p.first && (!c.skip || p.xi_store)) c.ho = ld4(HVold + o_row + gc);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { c.ys[i] = (real)0.; c.ins[i] = false; }
+  if (row_in) {
+    if (y4) {
+      if (gc >= g.sw && gc < g.sw + g.W) {
+        const real4 yv = ld4(y + (gc - g.sw));
+        c.ys[0] = yv.x; c.ys[1] = yv.y; c.ys[2] = yv.z; c.ys[3] = yv.w;
+        c.ins[0] = c.ins[1] = c.ins[2] = c.ins[3] = true;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int cc = gc + i;
+        c.ins[i] = (cc >= g.sw) && (cc < g.sw + g.W);
+        if (c.ins[i]) c.ys[i] = y[cc - g.sw];
+      }
+    }
+  }
+  return c;
+}
+// xin: the updated xi (stored by the caller unless c.skip && !p.xi_store); as: a = mu1 X - xi'
+static __device__ __forceinline__ void xhalf_apply(const AdmmScalars& p, const XQuad& c, real xin[4], real as[4]) {
+  const real hvs[4] = {c.hv.x, c.hv.y, c.hv.z, c.hv.w}, xis[4] = {c.xi.x, c.xi.y, c.xi.z, c.xi.w};
+  const real hos[4] = {c.ho.x, c.ho.y, c.ho.z, c.ho.w};
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    real xiv = xis[i];
+    const real hv = hvs[i], yv = c.ys[i];
+    if (p.xiw && !c.ins[i]) {      // outside the window: a = mu1 HV, xi = mu1p (HV - HV_old) (stored on request only)
+      xin[i] = p.first ? (real)0. : p.mu1p * (hv - hos[i]);
+      as[i] = p.mu1 * hv;
+      continue;
+    }
+    if (!p.first) {
+      const real xo = (c.ins[i] ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
+      xiv = xiv + p.mu1p * (hv - xo);
+    }
+    const real xnew = (c.ins[i] ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
+    xin[i] = xiv;
+    as[i] = p.mu1 * xnew - xiv;
+  }
+}
+
 // ---- forward rows of r_sp and a, with the X half of the image-domain work (wide frames: one real row per half-length
 // transform) -------------------------------------------------------------------------------------------------------
 // The image-domain work of an ADMM iteration separates cleanly:
@@ -1416,65 +1487,14 @@ __global__ __launch_bounds__(NT) void k_rfwd_half_x(PlaneGeom g, AdmmScalars p, 
     const bool row_in = (gr >= g.sh) && (gr < g.sh + g.H);
     const real* y = Y + (long)dpl * g.uplane + (long)(gr - g.sh) * g.W;     // dereferenced only when row_in
     const bool y4 = ((g.sw | g.W) & 3) == 0;                                 // window and pitch allow real4 loads of y
-    struct QuadX { real4 hv, xi, ho; real ys[4]; bool ins[4]; bool skip; };
-    auto load_quadx = [&](int q) {
-      QuadX c;
-      const int gc = 4 * q;
-      // the whole quad lies outside the sensor window: HV is all it needs (see AdmmScalars::xiw)
-      c.skip = p.xiw && !(row_in && gc + 4 > g.sw && gc < g.sw + g.W);
-      c.hv = ld4(HV + o_row + gc);
-      c.xi = c.ho = make_real4((real)0., (real)0., (real)0., (real)0.);
-      if (!c.skip) c.xi = ld4(xi + o_row + gc);
-      if (!p.first && (!c.skip || p.xi_store)) c.ho = ld4(HVold + o_row + gc);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) { c.ys[i] = (real)0.; c.ins[i] = false; }
-      if (row_in) {
-        if (y4) {
-          if (gc >= g.sw && gc < g.sw + g.W) {
-            const real4 yv = ld4(y + (gc - g.sw));
-            c.ys[0] = yv.x; c.ys[1] = yv.y; c.ys[2] = yv.z; c.ys[3] = yv.w;
-            c.ins[0] = c.ins[1] = c.ins[2] = c.ins[3] = true;
-          }
-        } else {
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const int cc = gc + i;
-            c.ins[i] = (cc >= g.sw) && (cc < g.sw + g.W);
-            if (c.ins[i]) c.ys[i] = y[cc - g.sw];
-          }
-        }
-      }
-      return c;
-    };
-    QuadX nxt = load_quadx(tid < n4 ? tid : 0);
+    XQuad nxt = xhalf_load(g, p, HV, HVold, xi, y, o_row, row_in, y4, tid < n4 ? tid : 0);
 #pragma unroll 1
     for (int q = tid; q < n4; q += NT) {
       const int gc = 4 * q;
-      const QuadX c = nxt;
-      if (q + NT < n4) nxt = load_quadx(q + NT);
-      const real4 hv4 = c.hv, xi4 = c.xi, ho4 = c.ho;
-      const real* ys = c.ys;
-      const bool* ins = c.ins;
-      const real hvs[4] = {hv4.x, hv4.y, hv4.z, hv4.w}, xis[4] = {xi4.x, xi4.y, xi4.z, xi4.w};
-      const real hos[4] = {ho4.x, ho4.y, ho4.z, ho4.w};
+      const XQuad c = nxt;
+      if (q + NT < n4) nxt = xhalf_load(g, p, HV, HVold, xi, y, o_row, row_in, y4, q + NT);
       real xin[4], as[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        real xiv = xis[i];
-        const real hv = hvs[i], yv = ys[i];
-        if (p.xiw && !ins[i]) {      // outside the window: a = mu1 HV, xi = mu1p (HV - HV_old) (stored on request only)
-          xin[i] = p.first ? (real)0. : p.mu1p * (hv - hos[i]);
-          as[i] = p.mu1 * hv;
-          continue;
-        }
-        if (!p.first) {
-          const real xo = (ins[i] ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
-          xiv = xiv + p.mu1p * (hv - xo);
-        }
-        const real xnew = (ins[i] ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
-        xin[i] = xiv;
-        as[i] = p.mu1 * xnew - xiv;
-      }
+      xhalf_apply(p, c, xin, as);
       if (!c.skip || p.xi_store) st4(xi + o_row + gc, make_real4(xin[0], xin[1], xin[2], xin[3]));
       s[lds_slot<SK>(2 * q)] = make_real2(as[0], as[1]);
       s[lds_slot<SK>(2 * q + 1)] = make_real2(as[2], as[3]);
@@ -1486,10 +1506,12 @@ __global__ __launch_bounds__(NT) void k_rfwd_half_x(PlaneGeom g, AdmmScalars p, 
 }
 
 // ---- paired forward rows with the X half computed on the fly (narrow frames: C1 / C4, 760 x 1014) ---------------
-// Same split of the image-domain work as k_rfwd_half_x, for frames whose rows ride in pairs:
-// row r of r_sp (stored by k_admm_spatial_v4<.., XHALF = false>) is the real part, and the imaginary part
-// a = mu1 X - xi' is formed element by element from xi, HV, HV_old and y inside the source functor of the first FFT
-// stage (which also stores xi').  Compile-time plans only.
+// Same split of the image-domain work as k_rfwd_half_x, for frames whose rows ride in pairs (paired_rows_of: two rows of
+// ONE array per transform).  Blocks of array 0 transform two stored rows of r_sp (k_admm_spatial_v4<.., XHALF = false>
+// wrote them); blocks of array 1 form two rows of a = mu1 X - xi' element by element from xi, HV, HV_old and y inside
+// the source functor of the first FFT stage (which also stores xi').  p.skipa: `a` on the rows of the sensor window
+// alone -- outside it a = mu1 HV needs no transform, SB keeps the row spectra the last inverse row pass read and the
+// fused middle rescales them (AdmmScalars::skipa).  Compile-time plans only.
 template <int NT, int EMAX, bool SK, class PL>
 __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p, PL plan, const real* LPC_RESTRICT Rsp,
                                                        const real* LPC_RESTRICT HV, const real* LPC_RESTRICT HVold,
@@ -1499,47 +1521,53 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p
   real2* s = (real2*)smem;
   const int tid = threadIdx.x;
   const long pl = LPC_BY(g);
-  const unsigned bx = LPC_BX(g);
-  // p.skipa (grid.x = H + outside_pair_count): blocks [0, H) = the rows of the sensor window as below; the others
-  // transform two rows of r_sp outside the window at once -- `a` = mu1 HV needs no transform there, SB keeps the row
-  // spectra the last inverse row pass read and the fused middle rescales them (AdmmScalars::skipa)
-  if (p.skipa && (int)bx >= g.H) {
-    bool v1;
-    const int r0 = outside_pair_row(g, (int)bx - g.H, v1);
-    const real* ra = Rsp + pl * g.rplane + (long)r0 * g.rpitch;
+  const PairedRows pr = paired_rows_of(g, LPC_BX(g), p.skipa != 0);
+  const bool v1 = pr.second;
+  const long o_row = pl * g.rplane + (long)pr.r0 * g.rpitch;
+  if (pr.arr == 0) {
+    const real* ra = Rsp + o_row;
     const real* rb = ra + g.rpitch;
     auto two = [&](int i, int) { return make_real2(ra[i], v1 ? rb[i] : (real)0.); };
     fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, two, LdsNatural{});
-    real2* o0 = SA + pl * g.cplane + (long)r0 * g.cpitch;
+    real2* o0 = SA + pl * g.cplane + (long)pr.r0 * g.cpitch;
     untangle_store<NT, SK>(s, g.Wp, g.Wc, o0, o0 + g.cpitch, v1, tid);
     return;
   }
-  const int row = p.skipa ? g.sh + (int)bx : (int)bx;
-  const long o_row = pl * g.rplane + (long)row * g.rpitch;
+  // two rows of a = mu1 X - xi' (xhalf_load / xhalf_apply): every 16-byte load of both rows is in flight before the
+  // first statement that needs one, the pair of rows goes into the tile as z = a_r0 + i a_r1, then the transform runs
+  // from LDS.  (The first form of this kernel formed `a` inside the source functor of the first FFT stage -- one load,
+  // one wait, one store at a time behind four data-dependent branches per element; with two rows per block that chain
+  // was the whole kernel: C1 0.272 -> 0.293 ms per 5 iterations, r04a/ab_pairing.log.)
   const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
-  const bool row_in = (row >= g.sh) && (row < g.sh + g.H);
-  const real* y = Y + (long)dpl * g.uplane + (long)(row - g.sh) * g.W;     // dereferenced only when row_in
-  auto src = [&](int i, int) {
-    const long o = o_row + i;
-    const bool inside = row_in && (i >= g.sw) && (i < g.sw + g.W);
-    const real hv = HV[o];
-    if (p.xiw && !inside) {        // outside the sensor window (see AdmmScalars::xiw)
-      if (p.xi_store) xi[o] = p.first ? (real)0. : p.mu1p * (hv - HVold[o]);
-      return make_real2(Rsp[o], p.mu1 * hv);
+  const int r1 = pr.r0 + 1, n4 = g.Wp >> 2;
+  const bool in0 = (pr.r0 >= g.sh) && (pr.r0 < g.sh + g.H), in1 = v1 && (r1 >= g.sh) && (r1 < g.sh + g.H);
+  const real* y0 = Y + (long)dpl * g.uplane + (long)(pr.r0 - g.sh) * g.W;    // dereferenced only inside the window
+  const real* y1 = y0 + g.W;
+  const long o_row1 = o_row + g.rpitch;
+  const bool y4 = ((g.sw | g.W) & 3) == 0;
+  const int q0 = tid < n4 ? tid : 0;
+  XQuad n0 = xhalf_load(g, p, HV, HVold, xi, y0, o_row, in0, y4, q0);
+  XQuad n1 = xhalf_load(g, p, HV, HVold, xi, y1, v1 ? o_row1 : o_row, in1, y4, q0);
+#pragma unroll 1
+  for (int q = tid; q < n4; q += NT) {
+    const int gc = 4 * q;
+    const XQuad c0 = n0, c1 = n1;
+    if (q + NT < n4) {
+      n0 = xhalf_load(g, p, HV, HVold, xi, y0, o_row, in0, y4, q + NT);
+      n1 = xhalf_load(g, p, HV, HVold, xi, y1, v1 ? o_row1 : o_row, in1, y4, q + NT);
     }
-    const real yv = inside ? y[i - g.sw] : (real)0.;
-    real xiv = xi[o];
-    if (!p.first) {
-      const real xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * HVold[o] + yv);   // previous X
-      xiv = xiv + p.mu1p * (hv - xo);
-    }
-    const real xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
-    xi[o] = xiv;
-    return make_real2(Rsp[o], p.mu1 * xnew - xiv);
-  };
-  fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
-  untangle_store<NT, SK>(s, g.Wp, g.Wc, SA + pl * g.cplane + (long)row * g.cpitch,
-                         SB + pl * g.cplane + (long)row * g.cpitch, true, tid);
+    real x0[4], a0[4], x1[4], a1[4];
+    xhalf_apply(p, c0, x0, a0);
+    xhalf_apply(p, c1, x1, a1);
+    if (!c0.skip || p.xi_store) st4(xi + o_row + gc, make_real4(x0[0], x0[1], x0[2], x0[3]));
+    if (v1 && (!c1.skip || p.xi_store)) st4(xi + o_row1 + gc, make_real4(x1[0], x1[1], x1[2], x1[3]));
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s[lds_slot<SK>(gc + i)] = make_real2(a0[i], v1 ? a1[i] : (real)0.);
+  }
+  __syncthreads();
+  fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
+  real2* o1 = SB + pl * g.cplane + (long)pr.r0 * g.cpitch;
+  untangle_store<NT, SK>(s, g.Wp, g.Wc, o1, o1 + g.cpitch, v1, tid);
 }
 
 // ---- plug-and-play ADMM: the U-prox is an external denoiser (admm.py:126-133,235-243,266-275,300-311) ----------

@@ -95,14 +95,14 @@ static int m_admm_rows_fwd(Engine* e) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
-  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<RNT, REM, RSK, false, RowPA>, dim3(g.Hp, e->P), RNT, kRowSmem, g,
+  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<RNT, REM, RSK, false, RowPA>, dim3(paired_rows_grid(g, false), e->P), RNT, kRowSmem, g,
                   row_arg(e), (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
 }
 static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outside) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
-  const int irows = skip_hv_outside ? g.H + outside_pair_count(g) : g.Hp;
+  const int irows = paired_rows_grid(g, skip_hv_outside != 0);
   return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<RNT, REM, RSK, false, RowPA>, dim3(irows, e->P), RNT, kRowSmem,
                   geom_rev(e, e->opt.rev_rows & 2),
                   row_arg(e), (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
@@ -112,8 +112,8 @@ static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
-  // sc->skipa: the window rows as usual + the rows of r_sp outside it two per transform
-  const int xrows = sc->skipa ? g.H + outside_pair_count(g) : g.Hp;
+  // sc->skipa: `a` on the rows of the sensor window alone
+  const int xrows = paired_rows_grid(g, sc->skipa != 0);
   return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA>, dim3(xrows, e->P), RNT, kRowSmem,
                   geom_rev(e, e->opt.rev_rows & 1), *sc,
                   row_arg(e), (const real*)e->Rsp, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1],

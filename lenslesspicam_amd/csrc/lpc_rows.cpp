@@ -59,7 +59,7 @@ int admm_rows_fwd(Engine* e) {
   return dispatch_row(g.Wp, e->planW.skew_ok, e->rows_r2, [&](auto NTc, auto EM, auto SK, auto R2) {
     constexpr int nt = decltype(NTc)::value, em = decltype(EM)::value;
     constexpr bool sk = decltype(SK)::value, r2 = decltype(R2)::value;
-    return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<nt, em, sk, r2>, dim3(g.Hp, e->P), nt,
+    return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<nt, em, sk, r2>, dim3(paired_rows_grid(g, false), e->P), nt,
                     LPC_ROW_SMEM_BYTES(g.Wp, sk), g, e->planW, (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
   });
 }
@@ -76,7 +76,7 @@ int admm_rows_inv(Engine* e, real* Vout, real* HVout, bool skip_hv_outside) {
   if (e->mod && e->mod->admm_rows_inv) return e->mod->admm_rows_inv(e, Vout, HVout, skip_hv_outside ? 1 : 0);
   if (skip_hv_outside) return fail("internal: skipping H V rows needs the plan module's row kernels");
   const PlaneGeom& g = e->g;
-  const int irows = g.Hp, hrows = 2 * g.Hp, wo = 0;
+  const int irows = paired_rows_grid(g, false), hrows = 2 * g.Hp, wo = 0;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const Fft1dPlan& pinv = e->rows_r2 ? e->planWi : e->planW;

@@ -96,6 +96,10 @@ def run_entry(backend, si, tag):
 @pytest.mark.parametrize("plan", list(PLANS))
 @pytest.mark.parametrize("si,tag", entries())
 def test_engine_is_as_accurate_as_the_reference_float32(backend, monkeypatch, si, tag, plan):
+    # the CPU suite (SIMT emulator) runs the ladder on the plan that needed the fix and the two ends of it on the
+    # others; the GPU suite runs all 27 combinations
+    if backend.kind == "emu" and not (tag == "forward_l2" or (plan == "module_paired" and si == 0)):
+        pytest.skip("full ladder: -m gpu")
     engine_opts(monkeypatch, **PLANS[plan])
     res = run_entry(backend, si, tag)
     bad = {}
