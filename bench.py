@@ -143,7 +143,9 @@ def run_c4(args, rank, world, dev, dist):
 
     from lenslesspicam_amd.dist import ShardedReconstructor, shard_bounds
 
-    sharded = ShardedReconstructor(lpa.ADMM, psf)      # the solver (handle, PSF spectrum, workspace) is built ONCE
+    # the solver (handle, PSF spectrum, workspace) is built ONCE; reuse_output: the gathered batch is handed out in the
+    # receive buffer itself (valid until the call after the next), as a steady-state pipeline would run it
+    sharded = ShardedReconstructor(lpa.ADMM, psf, reuse_output=True)
     elapsed, out = timed_steps(args, dist, lambda: sharded(frames, n_iter=n_iter))
     lo, hi = shard_bounds(B, world, rank)
     elapsed, stats = rank_stats(dist, dev, elapsed, (hi - lo) * n_iter * args.steps)

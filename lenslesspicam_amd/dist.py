@@ -35,13 +35,16 @@ class ShardedReconstructor:
     rank's block of ``frames`` (B,H,W,C) and returns the full (B,D,H,W,C) result on every rank (same kind
     as ``psf``).  The native handle is re-created only when the local shard size changes.
 
-    No copy rides on the collective: the solver writes its shard straight into the send buffer, and for even shards on
-    the engine's device the result IS the receive buffer -- two of them alternate, so a returned batch stays valid until
-    the call after the next one (the reference's ``apply()`` likewise returns a view of solver state, recon.py:594).
+    The solver writes its shard straight into the send buffer.  What comes back is a FRESH tensor the caller owns
+    (``outs = [sharded(f, n) for f in batches]`` is safe), whatever the shard sizes, PSF kind or world size.
+    ``reuse_output=True`` opts into the zero-copy form for steady-state pipelines: with even shards on the engine's
+    device the result then IS the receive buffer -- two of them alternate, so a returned batch stays valid only until the
+    call after the next one (the reference's ``apply()`` likewise returns a view of solver state, recon.py:594).
     ``gather_ms()``: duration of the most recent all-gather (HIP events on the current stream)."""
 
-    def __init__(self, algo_cls, psf, group=None, solver=None, **algo_kwargs):
+    def __init__(self, algo_cls, psf, group=None, solver=None, reuse_output=False, **algo_kwargs):
         self.group = group
+        self.reuse_output = bool(reuse_output)
         self.rec = solver if solver is not None else algo_cls(psf, **algo_kwargs)
         self.psf = psf
         self.is_torch = isinstance(psf, torch.Tensor)
@@ -87,7 +90,9 @@ class ShardedReconstructor:
         if dev.type == "cuda":
             self._ev[1].record()
         if B == world * cap:
-            full = recv                           # even shards: the receive buffer already is the batch
+            # even shards: the receive buffer already is the batch (handed out as it is only on request: the other
+            # buffer of the pair is overwritten by the next call, this one by the call after that)
+            full = recv if self.reuse_output else recv.clone()
         else:
             full = torch.cat([recv[r * cap: r * cap + (b - a)]
                               for r in range(world) for a, b in [shard_bounds(B, world, r)]], dim=0)
@@ -99,7 +104,8 @@ class ShardedReconstructor:
 def reconstruct_sharded(algo_cls, psf, frames, n_iter, group=None, solver=None, **algo_kwargs):
     """One-shot form of ``ShardedReconstructor``.  ``solver``: an existing ``algo_cls`` instance built from
     ``psf`` (skips handle creation, the PSF FFT and the workspace allocation)."""
-    return ShardedReconstructor(algo_cls, psf, group=group, solver=solver, **algo_kwargs)(frames, n_iter)
+    # (the reconstructor dies with this call, so its receive buffer can be the result)
+    return ShardedReconstructor(algo_cls, psf, group=group, solver=solver, reuse_output=True, **algo_kwargs)(frames, n_iter)
 
 
 class PlaneShardedReconstructor:
@@ -109,13 +115,16 @@ class PlaneShardedReconstructor:
     Why this is exact: no kernel of the path couples planes -- the FFTs, the TV stencil and every prox act inside one
     (depth, channel) plane; the gradient-descent family takes its step size and its default start value per channel
     ACROSS depth (gd.py:100-112), so it is split by channel only.  Each rank runs single-plane (gray) solvers for its
-    units one after the other, and one ``all_gather_into_tensor`` of the finished planes closes the frame: the
-    result equals the un-sharded ``algo_cls(psf).apply()`` bit for bit (tests/test_dist.py).
+    units, and one ``all_gather_into_tensor`` of the finished planes closes the frame: the result equals the un-sharded
+    ``algo_cls(psf).apply()`` -- bit for bit wherever both run the same launch plan (tests/test_dist.py), to float32
+    round-off where the plan depends on the number of planes in flight.
 
     ``__call__(data, n_iter)``: ``data`` (H, W, C) or (1, H, W, C), same kind as ``psf``; returns (D, H, W, C) on
-    every rank.  Solvers (handle, PSF spectrum, workspace) are built once per unit and kept.  ``algo_kwargs`` must be
-    scalar solver keywords (mu1, tau, n_iter, ...): array-valued ones (``initial_est``) and custom ``psi*`` callables
-    describe the whole frame and raise ``ValueError``."""
+    every rank.  A rank's units are solved by as few solvers as the engine's shapes allow (handle, PSF spectrum and
+    workspace built once and kept): ONE (D', H, W, C) solver when the units are whole depth planes (C5 over 8 ranks:
+    6 units = 2 planes x 3 channels = one D' = 2 RGB handle), else one gray (D', H, W, 1) solver per channel.
+    ``algo_kwargs`` must be scalar solver keywords (mu1, tau, n_iter, ...): array-valued ones (``initial_est``) and
+    custom ``psi*`` callables describe the whole frame and raise ``ValueError``."""
 
     def __init__(self, algo_cls, psf, group=None, **algo_kwargs):
         from .admm import ADMM
@@ -137,18 +146,40 @@ class PlaneShardedReconstructor:
         D, H, W, C = (int(v) for v in psf.shape)
         self.shape = (D, H, W, C)
         by_depth = issubclass(algo_cls, ADMM) and D > 1
+        self.by_depth = by_depth
         # unit = (first depth plane, number of depth planes, channel)
         self.units = [(d, 1, c) for d in range(D) for c in range(C)] if by_depth else [(0, D, c) for c in range(C)]
         self._solvers = {}
         self._recv = None
 
-    def _solver(self, u):
-        if u not in self._solvers:
-            d0, nd, c = self.units[u]
-            sub = self.psf[d0:d0 + nd, :, :, c:c + 1]
+    def _groups(self, lo, hi):
+        """the rank's units [lo, hi) as solver groups: [(depth planes, channels, unit indices in solver-output order)]"""
+        D, H, W, C = self.shape
+        mine = list(range(lo, hi))
+        if not mine:
+            return []
+        if self.units[0][1] > 1 or not self.by_depth:     # channel units that span all depth planes: one gray solver each
+            return [(list(range(self.units[u][0], self.units[u][0] + self.units[u][1])), [self.units[u][2]], [u])
+                    for u in mine]
+        by_d = {}
+        for u in mine:
+            by_d.setdefault(self.units[u][0], []).append(u)
+        if C > 1 and all(len(v) == C for v in by_d.values()):       # whole depth planes: one RGB solver
+            ds = sorted(by_d)
+            return [(ds, list(range(C)), [u for d in ds for u in sorted(by_d[d], key=lambda k: self.units[k][2])])]
+        groups = []
+        for c in range(C):                                          # else one gray solver per channel
+            us = [u for u in mine if self.units[u][2] == c]
+            if us:
+                groups.append(([self.units[u][0] for u in us], [c], us))
+        return groups
+
+    def _solver(self, key, ds, cs):
+        if key not in self._solvers:
+            sub = self.psf[ds][:, :, :, cs] if len(cs) == 1 else self.psf[ds]
             sub = sub.contiguous() if self.is_torch else np.ascontiguousarray(sub)
-            self._solvers[u] = self.algo_cls(sub, **self.kw)
-        return self._solvers[u]
+            self._solvers[key] = self.algo_cls(sub, **self.kw)
+        return self._solvers[key]
 
     def __call__(self, data, n_iter):
         world, rank = _world(self.group)
@@ -159,20 +190,28 @@ class PlaneShardedReconstructor:
         assert tuple(data.shape) == (H, W, C), "data must match the PSF's (H, W, C)"
         lo, hi = shard_bounds(len(self.units), world, rank)
         nd = self.units[0][1]                      # depth planes per unit (the same for every unit)
-        planes, dev, tdtype = [], torch.device("cpu"), torch.float32
-        for u in range(lo, hi):
-            rec = self._solver(u)
+        planes, dev, tdtype = {}, torch.device("cpu"), torch.float32
+        for ds, cs, us in self._groups(lo, hi):
+            rec = self._solver((tuple(ds), tuple(cs)), ds, cs)
             dev, tdtype = rec._device, rec._tdtype
-            ch = self.units[u][2]
-            y = data[:, :, ch:ch + 1]
+            y = data if len(cs) == C and C > 1 else data[:, :, cs[0]:cs[0] + 1]
             rec.set_data(y.contiguous() if self.is_torch else np.ascontiguousarray(y))
-            out = rec.apply(n_iter=n_iter, disp_iter=None, plot=False)          # (nd, H, W, 1)
-            out = out if self.is_torch else torch.from_numpy(out)
-            planes.append(out.reshape(nd, H, W).to(dev))
+            out = rec.apply(n_iter=n_iter, disp_iter=None, plot=False)          # (len(ds), H, W, len(cs))
+            out = (out if self.is_torch else torch.from_numpy(out)).to(dev)
+            if nd > 1:                             # channel unit over all depth planes
+                planes[us[0]] = out.reshape(nd, H, W)
+            else:                                  # output order: depth-major, channel-minor == the order of `us`
+                flat = out.permute(0, 3, 1, 2).reshape(len(ds) * len(cs), 1, H, W) if len(cs) > 1 else out.reshape(len(ds), 1, H, W)
+                for i, u in enumerate(us):
+                    planes[u] = flat[i]
+        planes = [planes[u] for u in range(lo, hi)]
         if world > 1:
             if not planes:                         # more ranks than units: take part in the gather only
-                probe = self._solver(0)            # (device / dtype of the receive buffer)
-                dev, tdtype = probe._device, probe._tdtype
+                from . import recon                # (device / dtype of the receive buffer: dtype=None means float32)
+
+                f64 = self.kw.get("dtype") in ("float64", torch.float64, np.float64)
+                dev = recon.runtime("float64" if f64 else "float32")[1]
+                tdtype = torch.float64 if f64 else torch.float32
             cap = -(-len(self.units) // world)
             if self._recv is None:
                 self._recv = torch.empty((world * cap, nd, H, W), dtype=tdtype, device=dev)

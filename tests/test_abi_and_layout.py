@@ -38,6 +38,22 @@ def test_emulator_build_exports_the_same_abi(emu_lib):
     assert "emu" in emu_lib.backend()
 
 
+def test_norm_enumerators_match_the_binding_and_the_reference_strings():
+    """enum lpc_norm (include/lpc.h) <-> _native.NORM <-> the three strings rfft_convolve.py:27,121 hands to rfft2"""
+    from lenslesspicam_amd import _native
+
+    hdr = open(os.path.join(ROOT, "include", "lpc.h")).read()
+    enum = dict(re.findall(r"(LPC_NORM_[A-Z]+)\s*=\s*(\d+)", hdr))
+    assert enum == {"LPC_NORM_BACKWARD": "0", "LPC_NORM_ORTHO": "1", "LPC_NORM_FORWARD": "2"}
+    assert _native.NORM == {"backward": int(enum["LPC_NORM_BACKWARD"]), "ortho": int(enum["LPC_NORM_ORTHO"]),
+                            "forward": int(enum["LPC_NORM_FORWARD"])}
+    # every one of them is exercised against the reference: tests/test_norm_scale.py (ADMM, FISTA, operator)
+    import test_norm_scale
+
+    norms = {str(n) for si in (0, 1) for n in test_norm_scale.ladder()[f"s{si}_norms"]}
+    assert norms == set(_native.NORM)
+
+
 @pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful without a GPU")
 def test_product_path_fails_loudly_without_gpu():
     import lenslesspicam_amd as lpa

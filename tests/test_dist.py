@@ -51,6 +51,21 @@ def _worker(rank, world, port, emu_path, out_dir):
             single = lpa.ADMM(psf, tau=2e-6, mu2=1e-4)
             single.set_data(more[b])
             assert np.array_equal(got[b], single.apply(n_iter=3, disp_iter=None)), (rank, nb, b)
+    # lifetime of a result: by default every call hands out a tensor the caller owns -- collecting the results
+    # of consecutive calls is safe; reuse_output=True is the documented zero-copy ring (valid until the call after the next)
+    tp, tf = torch.from_numpy(psf), torch.from_numpy(more[:4])
+    own = ShardedReconstructor(lpa.ADMM, tp, tau=2e-6, mu2=1e-4)
+    outs = [own(tf * s, n_iter=2) for s in (1.0, 0.5, 0.25)]
+    assert len({o.data_ptr() for o in outs}) == 3
+    for o, s in zip(outs, (1.0, 0.5, 0.25)):
+        assert torch.equal(o, own(tf * s, n_iter=2))
+    ring = ShardedReconstructor(lpa.ADMM, tp, reuse_output=True, tau=2e-6, mu2=1e-4)
+    r0 = ring(tf, n_iter=2)
+    keep = r0.clone()
+    r1 = ring(tf * 0.5, n_iter=2)
+    assert torch.equal(r0, keep) and r1.data_ptr() != r0.data_ptr()      # still valid after ONE more call ...
+    r2 = ring(tf * 0.25, n_iter=2)
+    assert r2.data_ptr() == r0.data_ptr() and not torch.equal(r0, keep)  # ... and overwritten by the one after that
     reused = reconstruct_sharded(lpa.ADMM, psf, frames, n_iter=6, solver=sr.rec)      # solver= skips construction
     assert np.array_equal(reused, full)
     np.save(os.path.join(out_dir, f"rank{rank}.npy"), full)
@@ -92,6 +107,8 @@ def _plane_worker(rank, world, port, emu_path, out_dir):
         sharded = PlaneShardedReconstructor(cls, psf, **kw)
         assert len(sharded.units) == n_units
         got = sharded(y, n_iter=5)
+        if cls is lpa.ADMM:       # 6 units over 2 ranks = one whole depth plane each: ONE RGB solver per rank
+            assert list(sharded._solvers) == [((rank,), (0, 1, 2))], list(sharded._solvers)
         whole = cls(psf, **kw)
         whole.set_data(y)
         ref = whole.apply(n_iter=5, disp_iter=None, plot=False)
@@ -100,6 +117,14 @@ def _plane_worker(rank, world, port, emu_path, out_dir):
         again = sharded(y[None] * np.float32(0.5), n_iter=2)      # the solvers are kept; (1, H, W, C) accepted
         whole.set_data(y * np.float32(0.5))
         assert np.array_equal(again, whole.apply(n_iter=2, disp_iter=None, plot=False))
+    # 3 depth planes: 9 units = 5 + 4 -- neither rank holds whole planes only, so each runs one gray solver per channel
+    psf3 = rng.random((3, 12, 16, 3), dtype=np.float32) ** 4
+    sh3 = PlaneShardedReconstructor(lpa.ADMM, psf3, tau=2e-6, mu2=1e-4)
+    got3 = sh3(y, n_iter=4)
+    assert len(sh3._solvers) == 3 and all(k[1] in ((0,), (1,), (2,)) for k in sh3._solvers), list(sh3._solvers)
+    whole3 = lpa.ADMM(psf3, tau=2e-6, mu2=1e-4)
+    whole3.set_data(y)
+    assert np.array_equal(got3, whole3.apply(n_iter=4, disp_iter=None, plot=False))
     gray = psf[:1, :, :, :1].copy()                               # one unit, two ranks: rank 1 only gathers
     one = PlaneShardedReconstructor(lpa.ADMM, torch.from_numpy(gray))(torch.from_numpy(y[:, :, :1].copy()), n_iter=3)
     solo = lpa.ADMM(torch.from_numpy(gray))
