@@ -9,8 +9,10 @@ Oracle parity AT BASELINE.json's sizes (GPU only; ~4-6 minutes of host time, mos
       itself anchored to the float64 oracle at 12 MP (5 iterations, <= 1e-10)
   C3  the same frame, FISTA 6 iterations vs the float64 oracle (gd.py:235-241); 30 iterations float32 vs the float64
       build, which is anchored to the float64 oracle for 6
+  C3  ... and its own length: 300 iterations in one call, float32 vs the float64 build (<= 5e-4, 0.01 dB)
   C5  one depth plane (d = 7) of the 16 x 1080x1920x3 stack, 12 iterations in one call, vs the per-plane float64 oracle
-      
+      (SURVEY.md section 8 row A9); and its own length and width: 50 iterations, all 16 planes, float32 vs the float64
+      build, plane 7 of which is anchored to the oracle
   C4  batch of 64 DiffuserCam-sized frames (270x480x3), ADMM 20 iterations: 4 frames vs per-frame oracle apply(),
       all 64 bitwise vs single-frame runs (test/test_algos.py:198-229: batch == singles), and the same batch through
       lenslesspicam_amd.dist.reconstruct_sharded on an RCCL ("nccl") process group of world size 1
@@ -219,6 +221,69 @@ def test_c3_fista_30_iterations_vs_float64_build(c2_inputs):
           f"PSNR delta {d:+.2e} dB")
     assert e6 <= 1e-10, e6
     assert e30 <= 1e-4 and abs(d) <= 0.01, (e30, d)
+
+
+def test_c3_fista_300_iterations_at_12mp(c2_inputs):
+    """C3 at its own length: FISTA 300 iterations at 3040 x 4056 x 3 in one call, float32 engine against the float64 build
+    (which test_c3_fista_30_iterations_vs_float64_build anchors to the float64 oracle).  SURVEY section 8(c): <= 5e-4 of
+    max |ref| after 300 iterations, PSNR vs the scene within 0.01 dB (north_star).  Reference loop: gd.py:235-241 under
+    recon.py:575-576."""
+    psf, scene, y = c2_inputs
+    psf_d, y_d = torch.from_numpy(psf).cuda(), torch.from_numpy(y).cuda()
+    r64 = lpa.FISTA(psf_d.double(), dtype="float64")
+    r64.set_data(y_d.double())
+    t300 = r64.apply(n_iter=300, disp_iter=None).cpu().numpy()
+    del r64
+    torch.cuda.empty_cache()
+    rec = lpa.FISTA(psf_d)
+    assert "plan module" in rec._handle.plan_info()
+    rec.set_data(y_d)
+    g300 = rec.apply(n_iter=300, disp_iter=None).cpu().numpy()
+    del rec
+    torch.cuda.empty_cache()
+    e = rel(g300, t300)
+    p32, p64 = orc.psnr(g300[0], scene), orc.psnr(t300[0].astype(np.float32), scene)
+    print(f"C3 FISTA-300 at 12 MP: float32 vs float64 build {e:.2e}, PSNR {p32:.3f} dB ({p32 - p64:+.2e} dB)")
+    assert e <= 5e-4 and abs(p32 - p64) <= 0.01, (e, p32 - p64)
+
+
+def test_c5_all_16_planes_50_iterations():
+    """C5 at its own length and width: ADMM 50 iterations of the whole 16 x 1080 x 1920 x 3 stack in one call, float32
+    engine (half rows of 1920 points, 90 x 24 split, register middle, sensor-window structure for 46 of the 50) against the
+    float64 build WITHOUT the window structure, every one of the 16 planes; plane 7 of that float64 build is anchored
+    to the per-plane float64 oracle (12 iterations, <= 1e-10)."""
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    D, H, W, C, d = 16, 1080, 1920, 3, 7
+    psf = orc.synthetic_psf(D, H, W, C, seed=3)
+    scene = orc.synthetic_scene(H, W, C, seed=4)
+    y = orc.synthetic_measurement(psf[d:d + 1], scene)
+    kw = dict(tau=2e-6, mu2=1e-4)
+    r64 = lpa.ADMM(torch.from_numpy(psf).cuda().double(), dtype="float64", engine_options=PLAIN, **kw)
+    r64.set_data(torch.from_numpy(y).cuda().double())
+    a12 = r64.apply(n_iter=12, disp_iter=None)[d].cpu().numpy()
+    o = orc.ADMMOracle(psf[d:d + 1].astype(np.float64), dtype=torch.float64, **kw)
+    o.set_data(y.astype(np.float64))
+    e_anchor = rel(a12, o.apply(12)[0].numpy())
+    del o
+    t50 = r64.apply(n_iter=50, disp_iter=None).cpu().numpy()
+    del r64
+    torch.cuda.empty_cache()
+    rec = lpa.ADMM(torch.from_numpy(psf).cuda(), **kw)
+    info = rec._handle.plan_info()
+    assert "H V row transforms skipped" in info and "plan module" in info, info
+    rec.set_data(torch.from_numpy(y).cuda())
+    g50 = rec.apply(n_iter=50, disp_iter=None).cpu().numpy()
+    nz = float((rec._U != 0).float().mean())
+    del rec
+    torch.cuda.empty_cache()
+    errs = [rel(g50[k], t50[k]) for k in range(D)]
+    dps = [orc.psnr(g50[k], scene) - orc.psnr(t50[k].astype(np.float32), scene) for k in range(D)]
+    print(f"C5 ADMM-50, 16 planes: float64 build vs oracle (plane {d}, 12 it) {e_anchor:.2e}; float32 vs float64 build "
+          f"max {max(errs):.2e} (plane {int(np.argmax(errs))}), median {float(np.median(errs)):.2e}; |PSNR delta| max "
+          f"{max(abs(v) for v in dps):.2e} dB; U non-zero {100 * nz:.1f} %")
+    assert e_anchor <= 1e-10, e_anchor
+    assert 0.005 < nz < 0.999, nz          # the soft-threshold branch is live (1.6 % of U over the 16 planes after 50)
+    assert max(errs) <= 3e-4 and max(abs(v) for v in dps) <= 0.01, (errs, dps)
 
 
 def test_c5_one_plane_of_the_depth_stack_vs_oracle():
