@@ -122,9 +122,27 @@ static bool radices_skew_ok(int n, const std::vector<int>& rad) {
   return true;
 }
 
+// LDS layout of a compile-time row plan (lpc_fft.h: lds_slot)
+static int row_layout(const EngineOpts& o, int n, const std::vector<int>& rad) {
+  // Default: i + i/8 where the plan keeps it affine.  The xor layout (row_lay=2) removes the bank conflicts that layout
+  // causes on every contiguous access -- tools/lds_model.py: 3844 -> 2116 LDS array cycles per 4096-point row against
+  // 1924 conflict-free -- and buys nothing: same-box A/B (profiles/r04f_ab_rowlay.log) C2 130.68 -> 130.29 ms per 40
+  // iterations, C4 35.11 -> 35.05, C1 0.270 -> 0.274, C3 (FISTA) 74.01 -> 74.60, C5 182.6 -> 189.7.  The row kernels run
+  // at 4.85-5.05 TB/s against 5.25 TB/s for a plain device copy on the same box: they wait for HBM, not for LDS
+  // (round 1 found the same when it first removed the conflicts of the natural layout: -2 %).
+  const int skew = radices_skew_ok(n, rad) ? 1 : 0;
+  if (o.no_skew || o.row_lay == 0) return 0;
+  if (o.row_lay == 2) return n % 16 == 0 ? 2 : skew;
+  return skew;
+}
+
 // choose the column split Hp = N1*N2 and the tile width
 static void choose_split(const EngineOpts& opt, int Hp, int Wc, int* N1, int* N2, int* T, bool prefer24 = false,
-                         bool admm_f32 = false) {
+                         bool admm_f32 = false, bool single_launch = false) {
+  if (single_launch) {   // whole columns, kSingleT of them per tile (choose_plan: the sequential ADMM middle)
+    *N1 = 1; *N2 = Hp; *T = (opt.seq_t == 1 || opt.seq_t == 2 || opt.seq_t == 4) && (long)Hp * opt.seq_t <= kMaxTilePoints ? opt.seq_t : 2;
+    return;
+  }
   int t = 16;
   if (opt.col_t > 0) t = opt.col_t;  // option col_t
   while (t > 1 && t / 2 >= Wc) t /= 2;  // tiny images: do not waste lanes on empty columns
@@ -204,7 +222,16 @@ static void choose_plan(Engine* e, bool allow_static) {
   e->mid_reg = !o.mid_lds;
   // (a 24-point register middle for ADMM in float32 only: 2 x 24 complex128 values do not fit a lane's registers)
   // (the gradient-descent family keeps 128 x 48 at 6144 rows: its 48-point middle lives in registers)
-  choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, (!admm || f32) && e->mid_reg, admm && f32);
+  // Single-launch column transform (option col_single): a frame whose columns would be split four-step (pass A + fused
+  // middle + inverse pass A = 12 S + Sc of HBM traffic per iteration) but still fit LDS two columns at a time takes the
+  // sequential middle over WHOLE columns instead: 4 S + Sc in one launch.  Needs the module's compile-time plans, 24-bit
+  // row offsets and a padded height that has a three- or four-stage plan on 1024 lanes.
+  bool single = false;
+  if (admm && f32 && allow_static && !o.no_static_cols && o.col_single != 0 && (long)g.Hp * 2 <= kMaxTilePoints &&
+      (long)g.Hp * 2 * 16 > kMaxTilePoints && g.Wc > 8) {
+    single = o.col_single == 1;      // (-1: not yet a default anywhere -- see profiles/r04_notes.md)
+  }
+  choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, (!admm || f32) && e->mid_reg, admm && f32, single);
   // the column kernels of a plan module address their tiles with 24-bit row-index x row-step products (k_cols): the step
   // between two rows of one column transform must stay below 2^24 bytes (12 MP: 48 rows x 32.8 KB = 1.6 MB)
   const long col_step = (long)(e->N1 > 1 ? e->N2 : 1) * g.cpitch * (long)sizeof(real2);
@@ -216,13 +243,19 @@ static void choose_plan(Engine* e, bool allow_static) {
   // workgroups that each hold one spectrum (measured, profiles/r02_notes.md: 64 frames 1.20 -> 0.96 ms per launch with
   // 16-column tiles; ONE frame 0.032 -> 0.042 ms: 93 workgroups for 256 CUs)
   bool seq = false;
-  if (admm && f32 && st_cols && e->N1 == 1 && e->T == 8 && g.Wc > 8 && (long)g.Hp * 16 <= kMaxTilePoints &&
+  if (single && st_cols) {
+    seq = true;                    // (e->T already is the tile width: 2 columns, option seq_t = 1 | 2 | 4)
+  } else if (admm && f32 && st_cols && e->N1 == 1 && e->T == 8 && g.Wc > 8 && (long)g.Hp * 16 <= kMaxTilePoints &&
       o.col_t == 0 && o.mid_seq != 0 && ((long)e->P * ((g.Wc + 15) / 16) >= 512 || o.mid_seq == 1)) {
     seq = true;
     // 8 columns per tile on 256 lanes x 17 points: four 39-KB workgroups per CU instead of two 73-KB ones of 512 lanes --
     // same waves per CU, but barriers over 4 waves and four independent phases to overlap (C4, same box: middle
     // 0.608 -> 0.550 ms, 20-iteration call 38.38 -> 35.73 ms; profiles/r03_notes.md section 15)
     e->T = o.seq_t == 16 ? 16 : (o.seq_t == 4 ? 4 : 8);
+  }
+  if (single && !seq) {            // no compile-time column plans after all: back to the four-step split
+    single = false;
+    choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, (!admm || f32) && e->mid_reg, admm && f32, false);
   }
   // Row passes: one real row per half-length complex transform (k_r*_half kernels) once the
   // paired tile is so large that fewer than 5 workgroups fit a CU's 160 KiB of LDS.  Measured (r01b_notes.md):
@@ -271,7 +304,7 @@ static void choose_plan(Engine* e, bool allow_static) {
     set_static_fft(sp.row, n, rad, 1, nt, (n + nt - 1) / nt);
     if (sp.row.n && sp.row.em <= 16) {
       sp.row_kind = LPC_ROWS_HALF;
-      sp.row_sk = radices_skew_ok(n, rad) && !o.no_skew;
+      sp.row_sk = row_layout(o, n, rad);
       sp.row_x = xhalf;
     }
   } else if (admm) {    // paired rows: ADMM's own kernels only (set-up transforms keep the run-time plan)
@@ -295,7 +328,7 @@ static void choose_plan(Engine* e, bool allow_static) {
     set_static_fft(sp.row, n, rad, 1, nt, (n + nt - 1) / nt);
     if (sp.row.n && sp.row.em <= 16) {
       sp.row_kind = LPC_ROWS_PAIRED;
-      sp.row_sk = radices_skew_ok(n, rad) && !o.no_skew;
+      sp.row_sk = row_layout(o, n, rad);
       sp.row_x = xhalf;
     }
   }
@@ -326,6 +359,13 @@ static void choose_plan(Engine* e, bool allow_static) {
     // one spectrum at a time: 6.10.9 inside a 128-register budget = TWO workgroups per CU overlapping one another's
     // loads and barriers -- 0.650 ms per launch at 64 frames against 0.84 ms for 30.18 and 0.95 ms for 6.6.5.3
     if (n == 540) rad = seq ? std::vector<int>{6, 10, 9} : std::vector<int>{30, 18};
+    if (single) {                  // long columns: fat stages (plan_radices stops at radix 8)
+      rad.clear();
+      int r = n;
+      while (r % 16 == 0 && r / 16 >= 16) { rad.push_back(16); r /= 16; }
+      std::vector<int> tail;
+      if (plan_radices(r, tail)) rad.insert(rad.end(), tail.begin(), tail.end());
+    }
     override_radices(o.mid_rad, n, rad);
     const int pts = n * (seq ? T : 2 * T);
     int nt = pts <= 4096 ? 256 : (pts <= 9216 ? 512 : 1024);
@@ -335,7 +375,8 @@ static void choose_plan(Engine* e, bool allow_static) {
     if (sp.mid.n && sp.mid.em <= 18) {
       sp.mid_kind = seq ? LPC_MID_SEQ : LPC_MID_PAIR;
       if (seq) {   // waves per SIMD the register allocation must allow: as many workgroups as the LDS holds
-        const size_t lds = (size_t)n * (T + 1) * sizeof(real2);
+        sp.mid_twg = o.mid_twg ? 1 : 0;
+        const size_t lds = (size_t)n * (T + (sp.mid_twg ? 0 : 1)) * sizeof(real2);
         const int wgs = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
         sp.mid_minw = std::min(4, std::max(1, (wgs * nt + 255) / 256));
       }

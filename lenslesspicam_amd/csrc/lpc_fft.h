@@ -265,14 +265,38 @@ static __device__ __forceinline__ void twiddle_mul(real2* v, const real2* LPC_RE
 // early Stockham stages write with a lane stride of R real2 (an 8- or 16-way conflict on the
 // 32 x 4-byte banks of ds_write_b64).  Only used when it stays AFFINE inside every stage
 // (plan.skew_ok, checked on the host) so that a butterfly's R accesses are base + m*stride'.
-template <bool SKEW>
+// LDS layout of a row tile (the template parameter named SK / SKEW everywhere): where element i of the tile lives.
+//   0  natural
+//   1  i + i/8  (rounds 1-3): removes the 8- / 16-way conflicts of the first stage's stride-R stores, but every
+//      CONTIGUOUS access then spans 36 slots per 32 lanes and wraps onto its own banks -- ds_read_b64 2 -> 4 array cycles,
+//      ds_write_b64 4 -> 8: half of all LDS cycles of the row kernels were conflicts (SQ_LDS_BANK_CONFLICT /
+//      SQ_LDS_IDX_ACTIVE = 0.44-0.50 in profiles/r03fin_c2_counters.md; tools/lds_model.py reproduces the factor)
+//   2  i ^ ((i >> 4) & 15): a permutation inside every aligned block of 16 elements (128 bytes), so contiguous accesses
+//      stay conflict-free, and the 16 lanes of a store group that write elements 16 apart (stride-R stores of the first
+//      stage, stride-NS stores of the next) land in 16 different 8-byte bank pairs.  No padding.  Needs n % 16 == 0.
+//      Model, array cycles per 4096-point workgroup: natural 5764, i + i/8 3844, this 2116, conflict-free 1924.
+#define LPC_LAY_NONE 0
+#define LPC_LAY_SKEW8 1
+#define LPC_LAY_XOR16 2
+template <int SKEW>
 static __device__ __forceinline__ int lds_slot(int i) {
-  return SKEW ? i + (i >> 3) : i;
+  return SKEW == LPC_LAY_SKEW8 ? i + (i >> 3) : (SKEW == LPC_LAY_XOR16 ? (i ^ ((i >> 4) & 15)) : i);
+}
+// slot(i + m * stride) == slot(i) + m * lds_stride(stride) for every i, m?  (then a stage addresses its R elements with
+// immediates from one base)
+template <int SKEW>
+static __host__ __device__ constexpr bool lds_affine(int stride) {
+  return SKEW == LPC_LAY_SKEW8 ? stride % 8 == 0 : (SKEW == LPC_LAY_XOR16 ? stride % 256 == 0 : true);
+}
+template <int SKEW>
+static __host__ __device__ constexpr int lds_stride(int stride) {
+  return SKEW == LPC_LAY_SKEW8 ? stride + (stride >> 3) : stride;
 }
 static __host__ __device__ __forceinline__ int lds_slots_skewed(int n) { return n + (n >> 3) + 1; }
+static __host__ __device__ __forceinline__ int lds_slots_of(int n, int layout) { return layout == LPC_LAY_SKEW8 ? lds_slots_skewed(n) : n; }
 
 // One Stockham stage over a tile of BT transforms held in LDS (in place).  Ends with a barrier.
-template <int R, int NT, int EMAX, bool INV, bool SKEW>
+template <int R, int NT, int EMAX, bool INV, int SKEW>
 static __device__ __forceinline__ void fft_stage(real2* s, int n, int BT, FastDiv btdiv, int ns,
                                                   FastDiv nsdiv, int twstep,
                                                   const real2* LPC_RESTRICT tw, int tid) {
@@ -321,7 +345,7 @@ static __device__ __forceinline__ void fft_stage(real2* s, int n, int BT, FastDi
 // In-place FFT of BT interleaved transforms of length plan.n held in LDS (natural order,
 // element (i, c) at slot(i*BT + c)).  Precondition: tile written and a barrier passed.
 // Postcondition: result in natural order, barrier passed.  Unnormalised in both directions.
-template <int NT, int EMAX, bool INV, bool SKEW = false>
+template <int NT, int EMAX, bool INV, int SKEW = false>
 static __device__ __forceinline__ void lds_fft(real2* s, const Fft1dPlan& p, int BT, FastDiv btdiv,
                                                 int tid, int first_stage = 0, int skip_last = 0) {
   for (int st = first_stage; st < p.nst - skip_last; ++st) {
@@ -358,7 +382,7 @@ struct LdsNatural {};
 // R inputs of its own butterflies (element j + m*n/R, still coalesced across lanes), transforms them
 // in the staging registers and writes the stage OUTPUT to LDS -- one LDS round trip and two barriers
 // less per transform.  Register need = the EMAX staging registers the plain fill uses anyway.
-template <int R, int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, class Src, class Fix>
+template <int R, int NT, int EMAX, bool INV, int SKEW, bool SRC_LDS, class Src, class Fix>
 static __device__ __forceinline__ void fft_first_stage_fused(real2* s, int n, int BT, FastDiv btdiv, int tid,
                                                               Src& src, Fix& fix) {
   constexpr int MAXB = (EMAX + R - 1) / R;
@@ -401,7 +425,7 @@ static __device__ __forceinline__ void fft_first_stage_fused(real2* s, int n, in
 // Last Stockham stage fused into the drain: outputs go from the butterfly registers straight to the sink
 // (coalesced: consecutive lanes hold consecutive output elements) -- again one LDS round trip and two
 // barriers less.  The tile must have passed a barrier after the previous stage's writes.
-template <int R, int NT, int EMAX, bool INV, bool SKEW, class Dst>
+template <int R, int NT, int EMAX, bool INV, int SKEW, class Dst>
 static __device__ __forceinline__ void fft_last_stage_fused(real2* s, int n, int BT, FastDiv btdiv, int ns,
                                                              FastDiv nsdiv, int twstep,
                                                              const real2* LPC_RESTRICT tw, int tid, Dst& dst) {
@@ -447,7 +471,7 @@ struct NoFix {
 // on MI355X (profiles/r01b_notes.md): it pays for the forward row pass (-10 %) and the inverse column
 // pass A (-13 %), costs +25 % on the forward pass A, and compiling BOTH paths slows the fused middle.
 // FUSEL: fuse the last stage into the drain (fft_last_stage_fused); same per-call-site rule.
-template <int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, bool FUSE1 = false, bool FUSEL = false, class Src,
+template <int NT, int EMAX, bool INV, int SKEW, bool SRC_LDS, bool FUSE1 = false, bool FUSEL = false, class Src,
           class Dst, class Fix = NoFix>
 // skip_first / skip_last: the caller has fused that many stages at the front / back itself (row kernels
 // fold a radix-2 stage into the Hermitian tangling): only stages [skip_first, nst - skip_last) run here.

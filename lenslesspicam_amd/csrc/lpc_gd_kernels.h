@@ -16,7 +16,7 @@
 // ---- inverse rows -> residual -> forward rows, all inside the workgroup -------------------------
 // R2: plan_inv is the inverse-row plan with the radix-2 stage first (fused into the tangling, un-skewed
 // tile); the forward transform keeps the skewed tile (SK) and folds its last radix-2 stage into the untangling.
-template <int NT, int EMAX, bool SK, bool R2>
+template <int NT, int EMAX, int SK, bool R2>
 __global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan, Fft1dPlan plan_inv,
                                                      const real2* LPC_RESTRICT Sin,
                                                      real2* LPC_RESTRICT Sout,
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan,
   const int sr0 = wrap_add(g.sh + u0, hh, g.Hp);
   const int sr1 = wrap_add(g.sh + (v1 ? u1 : u0), hh, g.Hp);
   const real2* sp = Sin + pl * g.cplane;
-  constexpr bool SKI = R2 ? false : SK;    // tile layout of the inverse transform's result
+  constexpr int SKI = R2 ? 0 : SK;    // tile layout of the inverse transform's result
   if (R2) tangle_r2_load<NT>(s, g.Wp, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
   else tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, sp + (long)sr0 * g.cpitch, sp + (long)sr1 * g.cpitch, v1, tid);
   __syncthreads();
@@ -134,7 +134,7 @@ static __device__ __forceinline__ real2 gd_update_pair(real* LPC_RESTRICT X, rea
   return xs;
 }
 
-template <int NT, int EMAX, bool SK, bool R2>
+template <int NT, int EMAX, int SK, bool R2>
 __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan plan,
                                                         const real2* LPC_RESTRICT Sin,
                                                         real* LPC_RESTRICT X, real* LPC_RESTRICT AUX,
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan pl
 }
 
 // ---- the same two kernels with one real row per half-length transform (wide frames, see k_rfwd_half) ----
-template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rinv_gd_mid_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                           const real2* LPC_RESTRICT Sin,
                                                           real2* LPC_RESTRICT Sout,
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid_half(PlaneGeom g, PL plan, c
   untangle_half_store<NT, SK>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
 }
 
-template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rinv_gd_update_half(PlaneGeom g, PL plan,
                                                              const real2* LPC_RESTRICT twW,
                                                              const real2* LPC_RESTRICT Sin, real* LPC_RESTRICT X,
@@ -247,7 +247,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update_half(PlaneGeom g, PL plan
 // straight back through the forward row transform: the next iteration finds the row spectra of its iterate already in
 // `Sout` and skips its forward row pass (one launch and one read of x less per iteration).  Same structure as
 // k_rinv_gd_mid_half: the update is the source functor of the forward transform's first stage.
-template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rinv_gd_update_fwd_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                                  const real2* LPC_RESTRICT Sin,
                                                                  real2* LPC_RESTRICT Sout, real* LPC_RESTRICT X,

@@ -48,10 +48,10 @@ static __device__ __forceinline__ int wrap_add(int i, int d, int n) {  // (i + d
 // The first FFT stage pulls its inputs straight from global memory (source lambda) and the last
 // stage pushes its outputs straight out (sink lambda); LDS only carries the tile between stages
 // and the Hermitian (un)tangling, which pairs bins k and Wp-k held by different lanes.
-#define LPC_ROW_SMEM_BYTES(Wp, skew) ((size_t)((skew) ? lds_slots_skewed(Wp) : (Wp)) * sizeof(real2))
+#define LPC_ROW_SMEM_BYTES(Wp, skew) ((size_t)lds_slots_of((Wp), (int)(skew)) * sizeof(real2))
 
 // s[] holds Z = FFT(a + i b) in natural order; writes A[k], B[k] for k in [0, Wc)
-template <int NT, bool SK>
+template <int NT, int SK>
 static __device__ __forceinline__ void untangle_store(const real2* s, int Wp, int Wc, real2* outA,
                                                        real2* outB, bool validB, int tid) {
   for (int k = tid; k < Wc; k += NT) {
@@ -65,7 +65,7 @@ static __device__ __forceinline__ void untangle_store(const real2* s, int Wp, in
 // builds Z[k] = A[k] + i B[k] over the full length from two half spectra (irfft semantics:
 // imaginary parts of the DC and Nyquist bins are ignored).  All loads are issued before the
 // first LDS write (unrolled to the compile-time bound) so they overlap in flight.
-template <int NT, int EMAX, bool SK>
+template <int NT, int EMAX, int SK>
 static __device__ __forceinline__ void tangle_load(real2* s, int Wp, int Wc, const real2* inA,
                                                     const real2* inB, bool validB, int tid) {
   constexpr int EH = EMAX / 2 + 1;
@@ -99,7 +99,7 @@ static __device__ __forceinline__ void tangle_load(real2* s, int Wp, int Wc, con
 // never makes its own trip through LDS.
 //
 // forward: s[] holds the tile BEFORE the last (radix-2, ns = nb) stage; writes A[k], B[k], k in [0, nb]
-template <int NT, bool SK>
+template <int NT, int SK>
 static __device__ __forceinline__ void untangle_r2_store(const real2* s, int Wp, const real2* LPC_RESTRICT tw,
                                                           real2* outA, real2* outB, bool validB, int tid) {
   const int nb = Wp >> 1;
@@ -187,7 +187,7 @@ static __device__ __forceinline__ PairedRows paired_rows_of(const PlaneGeom& g, 
 }
 
 // ---- forward, ADMM: rows (r, r + 1) of array A -> SA, of array B -> SB ------------
-template <int NT, int EMAX, bool SK, bool R2, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, bool R2, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, PL plan,
                                                      const real* LPC_RESTRICT A,
                                                      const real* LPC_RESTRICT B,
@@ -221,7 +221,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, PL plan,
 // row passes are bound by compute that two workgroups per CU cannot hide (profiles/r01b_notes.md).
 // blockIdx.x = 2*row + array.  `plan` has length M, `twW` is the length-Wp table.  Needs Wp even.
 // s[] holds Z = FFT_M(z) in natural order; writes X[0 .. M] (M = Wp/2) to o
-template <int NT, bool SK>
+template <int NT, int SK>
 static __device__ __forceinline__ void untangle_half_store(const real2* s, int M, const real2* LPC_RESTRICT twW,
                                                             real2* LPC_RESTRICT o, int tid) {
   for (int k = tid; k <= M / 2; k += NT) {
@@ -236,7 +236,7 @@ static __device__ __forceinline__ void untangle_half_store(const real2* s, int M
   }
 }
 
-template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rfwd_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                    const real* LPC_RESTRICT A, const real* LPC_RESTRICT B,
                                                    real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB) {
@@ -254,7 +254,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_half(PlaneGeom g, PL plan, const re
 // O' = (X[k] - conj X[M-k]) conj(w^k); the unnormalised inverse FFT_M of Z is (x[2j], x[2j+1]).
 // irfft semantics: the imaginary parts of the DC and Nyquist bins are ignored.
 // builds Z (natural order, length M) in LDS from one half-spectrum row; ends WITHOUT a barrier
-template <int NT, int EMAX, bool SK>
+template <int NT, int EMAX, int SK>
 static __device__ __forceinline__ void tangle_half_load(real2* s, int M, const real2* LPC_RESTRICT twW,
                                                          const real2* LPC_RESTRICT in, int tid) {
   constexpr int EH = EMAX / 2 + 1;
@@ -281,7 +281,7 @@ static __device__ __forceinline__ void tangle_half_load(real2* s, int M, const r
   }
 }
 
-template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                    const real2* LPC_RESTRICT SA, const real2* LPC_RESTRICT SB,
                                                    real* LPC_RESTRICT A, real* LPC_RESTRICT B, int skip_b_outside) {
@@ -320,7 +320,7 @@ struct RealSrc {
   int out_row0;       // source row r lands in spectrum row out_row0 + r
 };
 
-template <int NT, int EMAX, bool SK, bool R2>
+template <int NT, int EMAX, int SK, bool R2>
 __global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, RealSrc src,
                                                    real2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
@@ -344,7 +344,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, R
 }
 
 // one real row per half-length transform (see k_rfwd_half), generic source with pad on load
-template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rfwd_rows_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                         RealSrc src, real2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows_half(PlaneGeom g, PL plan, con
 // R2: `plan` is the inverse-row plan whose FIRST stage is the radix-2 one (fused into the tangling); SK is
 // false in that case (the skew is not affine for ns = 2).
 // window_only (AdmmScalars::skiphv): B (= H V) is produced on the rows of the sensor window alone (paired_rows_of).
-template <int NT, int EMAX, bool SK, bool R2, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, bool R2, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, PL plan,
                                                      const real2* LPC_RESTRICT SA,
                                                      const real2* LPC_RESTRICT SB,
@@ -412,7 +412,7 @@ static __device__ __forceinline__ int shifted_col(int i, int hw, int col0, int W
   return c;
 }
 
-template <int NT, int EMAX, bool SK, bool R2>
+template <int NT, int EMAX, int SK, bool R2>
 __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
                                                    const real2* LPC_RESTRICT S, RealDst dst) {
   LPC_DYN_SMEM(smem);
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
 }
 
 // one real row per half-length transform, generic sink with ifftshift (+ crop)
-template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rinv_rows_half(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                         const real2* LPC_RESTRICT S, RealDst dst) {
   LPC_DYN_SMEM(smem);
@@ -948,6 +948,14 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
     tile = (int)(bx % (unsigned)cp.ntile_c);
     const int q = (int)(bx / (unsigned)cp.ntile_c);
     fr = q / g.DC; pp = q % g.DC;
+    // tiles_first == 2 (whole long columns, T x 8 bytes < one 128-byte line): the L = 128 / (8 T) tiles that share every
+    // cache line of their rows run on ONE XCD (block b runs on XCD b % 8): within 8 L consecutive blocks, block
+    // 8 y + x takes tile L x + y -- the line is fetched from HBM once into that XCD's L2 and served to its L users
+    if (tiles_first == 2) {
+      constexpr int L = (128 / (int)sizeof(real2)) / T > 1 ? (128 / (int)sizeof(real2)) / T : 1;
+      const int t0 = tile - tile % (8 * L);
+      if (t0 + 8 * L <= cp.ntile_c) { const int l = tile - t0; tile = t0 + (l % 8) * L + l / 8; }
+    }
   }
   const long pl = (long)fr * g.DC + pp;
   const int c0 = tile * T;
@@ -1453,7 +1461,7 @@ static __device__ __forceinline__ void xhalf_apply(const AdmmScalars& p, const X
 // (Three ways to split the image-domain work were built and measured, profiles/r02_notes.md: the stand-alone kernel,
 // everything inside the forward rows -- its stencil half then runs at the row kernel's 4 workgroups per CU, no faster
 // than the pair once the rows run on compile-time plans -- and this one, a win on every box and shape.)
-template <int NT, int EMAX, bool SK, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rfwd_half_x(PlaneGeom g, AdmmScalars p, PL plan, const real2* LPC_RESTRICT twW,
                                                      const real* LPC_RESTRICT Rsp, const real* LPC_RESTRICT HV,
                                                      const real* LPC_RESTRICT HVold, real* LPC_RESTRICT xi,
@@ -1512,7 +1520,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_half_x(PlaneGeom g, AdmmScalars p, 
 // the source functor of the first FFT stage (which also stores xi').  p.skipa: `a` on the rows of the sensor window
 // alone -- outside it a = mu1 HV needs no transform, SB keeps the row spectra the last inverse row pass read and the
 // fused middle rescales them (AdmmScalars::skipa).  Compile-time plans only.
-template <int NT, int EMAX, bool SK, class PL>
+template <int NT, int EMAX, int SK, class PL>
 __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p, PL plan, const real* LPC_RESTRICT Rsp,
                                                        const real* LPC_RESTRICT HV, const real* LPC_RESTRICT HVold,
                                                        real* LPC_RESTRICT xi, const real* LPC_RESTRICT Y,

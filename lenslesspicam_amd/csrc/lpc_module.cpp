@@ -7,6 +7,9 @@
 #include "lpc_engine.h"
 #include "lpc_gd_kernels.h"
 
+#ifndef LPC_MOD_MID_TWG
+#define LPC_MOD_MID_TWG 0
+#endif
 #ifndef LPC_MOD_FAMILY
 #error "lpc_module.cpp is compiled with the flags of plan_spec_defines() (lpc_plan.h)"
 #endif
@@ -22,8 +25,9 @@ static inline PlaneGeom geom_rev(const Engine* e, bool rev) {   // the launch's 
 typedef SPlan<LPC_MOD_ROW_RAD> RowP;
 typedef SPlanArg<RowP> RowPA;
 static constexpr int RNT = LPC_MOD_ROW_NT, REM = LPC_MOD_ROW_EM;
-static constexpr bool RSK = LPC_MOD_ROW_SK != 0;
-static_assert(!RSK || RowP::skew_ok(), "this row plan does not keep the LDS skew affine");
+static constexpr int RSK = LPC_MOD_ROW_SK;       // LDS layout of the row tile: LPC_LAY_NONE / _SKEW8 / _XOR16 (lpc_fft.h)
+static_assert(RSK != LPC_LAY_SKEW8 || RowP::skew_ok(), "this row plan does not keep the LDS skew affine");
+static_assert(RSK != LPC_LAY_XOR16 || RowP::n % 16 == 0, "the xor layout permutes aligned blocks of 16 elements");
 static const size_t kRowSmem = LPC_ROW_SMEM_BYTES(RowP::n, RSK);
 #endif
 
@@ -149,10 +153,13 @@ static int m_admm_mid(Engine* e, const ColPass* cp, const AdmmScalars* sc, real 
   const MidPA pa = splan_arg<MidP>(e->planB);
   const real rscale = (real)1.0 / ((real)g.Hp * (real)g.Wp);
 #if LPC_MOD_MID_KIND == LPC_MID_SEQ     // single-pass columns, one spectrum at a time through T columns
-  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, true>,
-                  dim3(cp->ntile_c * e->P), NT, (size_t)MidP::n * (T + 1) * sizeof(real2), g, pa, *cp, SA, SB,
+  constexpr bool TWL = LPC_MOD_MID_TWG == 0;     // the plan's twiddles in LDS behind the tile
+  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, TWL>,
+                  dim3(cp->ntile_c * e->P), NT, (size_t)MidP::n * (T + (TWL ? 1 : 0)) * sizeof(real2), g, pa, *cp, SA, SB,
                   (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, sc->mu1,
-                  sc->mu2, sc->mu3, rscale, sb_outside_scale, e->opt.seq_tiles_first);
+                  sc->mu2, sc->mu3, rscale, sb_outside_scale,
+                  // whole long columns two at a time (option col_single): the tiles that share a cache line on one XCD
+                  (e->opt.seq_tiles_first == 0 && (size_t)MidP::n * 16 > (size_t)kMaxTilePoints) ? 2 : e->opt.seq_tiles_first);
 #else                                   // both spectra side by side: [N][2 T]
   const FastDiv t2 = make_fastdiv((unsigned)(2 * T));
   return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<NT, EM, MidPA, 2 * T, true>, dim3(cp->G * cp->ntile_c, e->P), NT,

@@ -43,12 +43,13 @@ struct PlanSpec {
   int f64 = 0;
   int row_kind = LPC_ROWS_RUNTIME;
   StaticFft row;              // length Wp / 2 (half) or Wp (paired)
-  int row_sk = 0;             // i + i/8 LDS skew
+  int row_sk = 0;             // LDS layout of the row tile: 0 natural, 1 i + i/8, 2 i ^ ((i >> 4) & 15)  (lpc_fft.h)
   int row_x = 0;              // ADMM: forward rows with the X half of the image-domain work
   StaticFft passA;            // pass A of a split column transform (T = 32 | 16 | narrower)
   int mid_kind = LPC_MID_RUNTIME;
   StaticFft mid;              // ADMM fused middle in LDS
   int mid_minw = 1;           // __launch_bounds__ second argument of the sequential middle
+  int mid_twg = 0;            // sequential middle: twiddles read from global memory instead of a copy in LDS behind the tile
   bool any() const { return row_kind != LPC_ROWS_RUNTIME || passA.n || mid_kind != LPC_MID_RUNTIME; }
 };
 
@@ -61,9 +62,9 @@ static inline std::string fft_key(const StaticFft& f) {
 static inline std::string plan_spec_key(const PlanSpec& s) {
   std::string k = s.f64 ? "f64" : "f32";
   k += s.family == LPC_FAM_ADMM ? "_admm" : "_gd";
-  if (s.row_kind) k += std::string(s.row_kind == LPC_ROWS_HALF ? "_rh" : "_rp") + fft_key(s.row) + (s.row_sk ? "s" : "") + (s.row_x ? "x" : "");
+  if (s.row_kind) k += std::string(s.row_kind == LPC_ROWS_HALF ? "_rh" : "_rp") + fft_key(s.row) + (s.row_sk == 1 ? "s" : (s.row_sk == 2 ? "z" : "")) + (s.row_x ? "x" : "");
   if (s.passA.n) k += "_a" + fft_key(s.passA);
-  if (s.mid_kind) k += std::string(s.mid_kind == LPC_MID_PAIR ? "_mp" : "_ms") + fft_key(s.mid) + "m" + std::to_string(s.mid_minw);
+  if (s.mid_kind) k += std::string(s.mid_kind == LPC_MID_PAIR ? "_mp" : "_ms") + fft_key(s.mid) + "m" + std::to_string(s.mid_minw) + (s.mid_twg ? "g" : "");
   return k;
 }
 static inline std::string rad_list(const StaticFft& f) {
@@ -94,6 +95,7 @@ static inline std::vector<std::string> plan_spec_defines(const PlanSpec& s) {
     def("LPC_MOD_MID_RAD", rad_list(s.mid));
     defi("LPC_MOD_MID_NT", s.mid.nt); defi("LPC_MOD_MID_EM", s.mid.em); defi("LPC_MOD_MID_T", s.mid.T);
     defi("LPC_MOD_MID_MINW", s.mid_minw);
+    defi("LPC_MOD_MID_TWG", s.mid_twg);
   }
   return d;
 }
@@ -123,6 +125,10 @@ struct EngineOpts {
   int seq_t = 0, mid_nt = 0;  // tuning: columns per tile of the sequential middle (4 | 8 | 16), lanes per middle workgroup
   int g_plane = -1;           // ADMM middles read |PsiT Psi| from its plane (1) / as row + column terms when it separates (0);
                               // -1: the terms when the plane is larger than 8 MB (it then misses the L2 once per colour plane)
+  int col_single = -1;        // ADMM (float32): the whole column transform in ONE launch -- whole columns in LDS, two image
+                              // columns per workgroup, one spectrum at a time (k_cols_mid_admm_seq) -- instead of pass A +
+                              // middle + inverse pass A, whenever a two-column tile of whole columns fits LDS.  -1: by size
+  int mid_twg = 0;            // sequential middle: twiddles from global memory (no LDS copy: more workgroups per CU)
   int seq_tiles_first = 0;    // sequential middle: workgroups handed out column tiles fastest instead of frames fastest
   int mid_swz = -1;           // side-by-side LDS middle: pairs of column tiles on one XCD (ColPass::swz); -1: when a tile
                               // row is narrower than a 128-byte line
@@ -131,6 +137,8 @@ struct EngineOpts {
   int no_xhalf = 0;           // stand-alone image-domain kernel (no X half inside the forward rows)
   int k1_scalar = 0;          // ... in its scalar-lane form
   int no_r2 = 0, no_skew = 0; // run-time row plans: no folded radix-2 stage / no LDS skew
+  int row_lay = -1;           // LDS layout of the compile-time row plans: -1 / 1 i + i/8 where that stays affine; 0 natural;
+                              // 2 the conflict-free xor layout (lengths that are multiples of 16; measured: no faster)
   int gd_no_fuse_fwd = 0;     // gradient-descent update without the next iteration's forward rows
   int row_nt = 0;             // threads per row workgroup of the compile-time row plan (tuning; multiple of 64)
   std::string row_rad, passa_rad, mid_rad;   // "16.16.8": radices of the compile-time row / pass-A / LDS-middle plan
@@ -187,6 +195,8 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "seq_t") o.seq_t = (int)iv;
       else if (k == "mid_nt") o.mid_nt = (int)iv;
       else if (k == "seq_tiles_first") o.seq_tiles_first = (int)iv;
+      else if (k == "col_single") o.col_single = (int)iv;
+      else if (k == "mid_twg") o.mid_twg = (int)iv;
       else if (k == "g_plane") o.g_plane = (int)iv;
       else if (k == "mid_swz") o.mid_swz = (int)iv;
       else if (k == "hv_full") o.hv_full = (int)iv;
@@ -195,6 +205,7 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "k1_scalar") o.k1_scalar = (int)iv;
       else if (k == "no_r2") o.no_r2 = (int)iv;
       else if (k == "no_skew") o.no_skew = (int)iv;
+      else if (k == "row_lay") o.row_lay = (int)iv;
       else if (k == "gd_no_fuse_fwd") o.gd_no_fuse_fwd = (int)iv;
       else if (k == "row_nt") o.row_nt = (int)iv;
       else if (k == "row_rad") o.row_rad = v;

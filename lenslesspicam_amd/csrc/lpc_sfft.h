@@ -75,16 +75,17 @@ template <class T> struct is_static_plan : std::false_type {};
 template <class P> struct is_static_plan<SPlanArg<P>> : std::true_type {};
 
 // ---- one stage, everything but tid and the pointers known at compile time ------------------------------------
-template <class P, int ST, int NT, int BT, bool INV, bool SKEW>
+template <class P, int ST, int NT, int BT, bool INV, int SKEW>
 static __device__ __forceinline__ void sfft_stage(real2* s, const real2* LPC_RESTRICT tw, int tid) {
   constexpr int R = P::radix(ST), N = P::n, NS = P::ns(ST);
   constexpr int NB = N / R, NWORK = NB * BT, MAXB = (NWORK + NT - 1) / NT;
   constexpr bool GUARD = (NWORK % NT) != 0;
   constexpr int IST = NB * BT, OST = NS * BT;
-  constexpr int RS = SKEW ? IST + (IST >> 3) : IST, WS = SKEW ? OST + (OST >> 3) : OST;
+  constexpr int RS = lds_stride<SKEW>(IST), WS = lds_stride<SKEW>(OST);
+  constexpr bool RAFF = lds_affine<SKEW>(IST), WAFF = lds_affine<SKEW>(OST);
   constexpr int TWSTEP = N / (NS * R);
   real2 v[MAXB][R];
-  int obase[MAXB];
+  int obase[MAXB];          // element index of the butterfly's first output (WAFF: already its slot)
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
     const int w = tid + b * NT;
@@ -94,36 +95,40 @@ static __device__ __forceinline__ void sfft_stage(real2* s, const real2* LPC_RES
       const int jq = j / NS, k = j % NS;
       const int rb = lds_slot<SKEW>(w);
 #pragma unroll
-      for (int m = 0; m < R; ++m) v[b][m] = s[rb + m * RS];
+      for (int m = 0; m < R; ++m) v[b][m] = RAFF ? s[rb + m * RS] : s[lds_slot<SKEW>(w + m * IST)];
       if (NS > 1) twiddle_mul<R, INV>(v[b], tw, k * TWSTEP);
       Dft<R, INV>::run(v[b]);
-      obase[b] = lds_slot<SKEW>((jq * NS * R + k) * BT + c);
+      const int oi = (jq * NS * R + k) * BT + c;
+      obase[b] = (WAFF || SKEW == LPC_LAY_SKEW8) ? lds_slot<SKEW>(oi) : oi;
     }
   }
   __syncthreads();
 #pragma unroll
   for (int b = 0; b < MAXB; ++b) {
     if (!GUARD || obase[b] >= 0) {
-      if (SKEW && NS == 1) {
+      if (SKEW == LPC_LAY_SKEW8 && NS == 1) {
 #pragma unroll
         for (int m = 0; m < R; ++m) s[obase[b] + m + (m >> 3)] = v[b][m];
-      } else {
+      } else if (WAFF || SKEW == LPC_LAY_SKEW8) {
 #pragma unroll
         for (int m = 0; m < R; ++m) s[obase[b] + m * WS] = v[b][m];
+      } else {
+#pragma unroll
+        for (int m = 0; m < R; ++m) s[lds_slot<SKEW>(obase[b] + m * OST)] = v[b][m];
       }
     }
   }
   __syncthreads();
 }
 
-template <class P, int NT, int BT, bool INV, bool SKEW, int FIRST, int... I>
+template <class P, int NT, int BT, bool INV, int SKEW, int FIRST, int... I>
 static __device__ __forceinline__ void sfft_stages(real2* s, const real2* LPC_RESTRICT tw, int tid,
                                                     std::integer_sequence<int, I...>) {
   (sfft_stage<P, FIRST + I, NT, BT, INV, SKEW>(s, tw, tid), ...);
 }
 
 // first stage fused into the tile fill (see fft_first_stage_fused)
-template <class P, int NT, int BT, bool INV, bool SKEW, bool SRC_LDS, class Src, class Fix>
+template <class P, int NT, int BT, bool INV, int SKEW, bool SRC_LDS, class Src, class Fix>
 static __device__ __forceinline__ void sfft_first_fused(real2* s, int tid, Src& src, Fix& fix) {
   constexpr int R = P::radix(0), N = P::n;
   constexpr int NB = N / R, NWORK = NB * BT, MAXB = (NWORK + NT - 1) / NT;
@@ -148,9 +153,12 @@ static __device__ __forceinline__ void sfft_first_fused(real2* s, int tid, Src& 
       for (int m = 0; m < R; ++m) v[b][m] = fix(j + m * NB, c, v[b][m]);
       Dft<R, INV>::run(v[b]);
       const int ob = lds_slot<SKEW>(j * R * BT + c);
-      if (SKEW) {
+      if (SKEW == LPC_LAY_SKEW8) {
 #pragma unroll
         for (int m = 0; m < R; ++m) s[ob + m + (m >> 3)] = v[b][m];
+      } else if (SKEW == LPC_LAY_XOR16) {
+#pragma unroll
+        for (int m = 0; m < R; ++m) s[lds_slot<SKEW>(j * R * BT + c + m * BT)] = v[b][m];
       } else {
 #pragma unroll
         for (int m = 0; m < R; ++m) s[ob + m * BT] = v[b][m];
@@ -161,13 +169,14 @@ static __device__ __forceinline__ void sfft_first_fused(real2* s, int tid, Src& 
 }
 
 // last stage fused into the drain (see fft_last_stage_fused)
-template <class P, int NT, int BT, bool INV, bool SKEW, class Dst>
+template <class P, int NT, int BT, bool INV, int SKEW, class Dst>
 static __device__ __forceinline__ void sfft_last_fused(real2* s, const real2* LPC_RESTRICT tw, int tid, Dst& dst) {
   constexpr int ST = P::nst - 1;
   constexpr int R = P::radix(ST), N = P::n, NS = P::ns(ST);
   constexpr int NB = N / R, NWORK = NB * BT, MAXB = (NWORK + NT - 1) / NT;
   constexpr bool GUARD = (NWORK % NT) != 0;
-  constexpr int IST = NB * BT, RS = SKEW ? IST + (IST >> 3) : IST;
+  constexpr int IST = NB * BT, RS = lds_stride<SKEW>(IST);
+  constexpr bool RAFF = lds_affine<SKEW>(IST);
   constexpr int TWSTEP = N / (NS * R);
   real2 v[MAXB][R];
 #pragma unroll
@@ -176,7 +185,7 @@ static __device__ __forceinline__ void sfft_last_fused(real2* s, const real2* LP
     if (!GUARD || w < NWORK) {
       const int rb = lds_slot<SKEW>(w);
 #pragma unroll
-      for (int m = 0; m < R; ++m) v[b][m] = s[rb + m * RS];
+      for (int m = 0; m < R; ++m) v[b][m] = RAFF ? s[rb + m * RS] : s[lds_slot<SKEW>(w + m * IST)];
     }
   }
 #pragma unroll
@@ -197,7 +206,7 @@ static __device__ __forceinline__ void sfft_last_fused(real2* s, const real2* LP
 // ---- fft_tile, static-plan overload: same template parameters and call shape as the run-time one ----------------
 // EMAX must be n * BT / NT rounded up (the kernels' launch tables guarantee it); BT is passed as a run-time value for
 // source compatibility but MUST equal the compile-time SBT the kernel was instantiated for.
-template <int NT, int EMAX, bool INV, bool SKEW, bool SRC_LDS, bool FUSE1 = false, bool FUSEL = false, int SBT = 1,
+template <int NT, int EMAX, bool INV, int SKEW, bool SRC_LDS, bool FUSE1 = false, bool FUSEL = false, int SBT = 1,
           class P, class Src, class Dst, class Fix = NoFix>
 static __device__ __forceinline__ void fft_tile(real2* s, const SPlanArg<P>& pa, int /*BT*/, FastDiv /*btdiv*/, int tid,
                                                  Src src, Dst dst, Fix fix = Fix()) {

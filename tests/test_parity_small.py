@@ -801,3 +801,19 @@ def test_gram_as_row_and_column_terms(backend, monkeypatch):
     rec = lpa.ADMM(torch.from_numpy(psf), psi=lambda x: torch.stack([x, x], dim=-1), psi_adj=lambda u: u.sum(-1),
                    psi_gram=gram)
     assert "gram as row + column terms" not in rec._handle.plan_info()
+
+
+@pytest.mark.parametrize("lay", [0, 2], ids=["natural", "xor16"])
+@pytest.mark.parametrize("half", [0, 1], ids=["paired", "half_rows"])
+def test_row_tile_lds_layouts(backend, monkeypatch, lay, half):
+    """option row_lay: the LDS layout of the compile-time row plans (lpc_fft.h: lds_slot) -- natural, and the
+    conflict-free xor layout i ^ ((i >> 4) & 15) (the default is i + i/8).  Same golden trajectories on each: ADMM with
+    the X half in the forward rows (64- and 32-point row transforms), FISTA's residual / update rows, the operator."""
+    engine_opts(monkeypatch, row_lay=lay, rows_half=half, jit_min_points=0)
+    test_admm_matches_reference_golden(backend, "admm_24x32x3_tv")
+    test_gd_family_matches_reference_golden(backend, "fista_24x32x3")
+    test_convolver_golden(backend, "a")
+    psf = np.load(os.path.join(GOLDEN, "admm_24x32x3_tv.npz"))["psf"]
+    info = lpa.ADMM(torch.from_numpy(psf).to(backend.device))._handle.plan_info()
+    key = info.split("plan module ")[1]
+    assert ("z" if lay == 2 else "") + "x" in key.split("_")[2] and "s" not in key.split("_")[2].split("w")[1], key

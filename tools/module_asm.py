@@ -24,9 +24,9 @@ def defines(key):
             mid = p
     fft = r"(\d+)r([\d.]+)t(\d+)w(\d+)x(\d+)"
     if row:
-        m = re.fullmatch(r"r([hp])" + fft + r"(s?)(x?)", row)
+        m = re.fullmatch(r"r([hp])" + fft + r"([sz]?)(x?)", row)
         d += ["-DLPC_MOD_ROW_KIND=%d" % (1 if m[1] == "h" else 2), "-DLPC_MOD_ROW_RAD=" + m[3].replace(".", ","),
-              "-DLPC_MOD_ROW_NT=" + m[5], "-DLPC_MOD_ROW_EM=" + m[6], "-DLPC_MOD_ROW_SK=%d" % bool(m[7]),
+              "-DLPC_MOD_ROW_NT=" + m[5], "-DLPC_MOD_ROW_EM=" + m[6], "-DLPC_MOD_ROW_SK=%d" % {"": 0, "s": 1, "z": 2}[m[7]],
               "-DLPC_MOD_ROW_X=%d" % bool(m[8])]
     else:
         d.append("-DLPC_MOD_ROW_KIND=0")
@@ -37,9 +37,10 @@ def defines(key):
     else:
         d.append("-DLPC_MOD_PASSA=0")
     if mid:
-        m = re.fullmatch(r"m([ps])" + fft + r"m(\d+)", mid)
+        m = re.fullmatch(r"m([ps])" + fft + r"m(\d+)(g?)", mid)
         d += ["-DLPC_MOD_MID_KIND=%d" % (1 if m[1] == "p" else 2), "-DLPC_MOD_MID_RAD=" + m[3].replace(".", ","),
-              "-DLPC_MOD_MID_T=" + m[4], "-DLPC_MOD_MID_NT=" + m[5], "-DLPC_MOD_MID_EM=" + m[6], "-DLPC_MOD_MID_MINW=" + m[7]]
+              "-DLPC_MOD_MID_T=" + m[4], "-DLPC_MOD_MID_NT=" + m[5], "-DLPC_MOD_MID_EM=" + m[6], "-DLPC_MOD_MID_MINW=" + m[7],
+              "-DLPC_MOD_MID_TWG=%d" % bool(m[8])]
     else:
         d.append("-DLPC_MOD_MID_KIND=0")
     return d
