@@ -376,6 +376,10 @@ static void choose_plan(Engine* e, bool allow_static) {
       sp.mid_kind = seq ? LPC_MID_SEQ : LPC_MID_PAIR;
       if (seq) {   // waves per SIMD the register allocation must allow: as many workgroups as the LDS holds
         sp.mid_twg = o.mid_twg ? 1 : 0;
+        // both tiles' loads up front when the launch is many waves of workgroups deep (C4, 64 frames: 11 712 workgroups
+        // for 1 024 resident, middle 0.494 -> 0.473 ms; an 8-frame shard -- 1 464 workgroups -- is 1.5 % slower with it:
+        // profiles/r04h_ab.log)
+        sp.mid_pre = o.mid_pre >= 0 ? (o.mid_pre ? 1 : 0) : ((long)e->P * ((g.Wc + T - 1) / T) >= 4096 && !single ? 1 : 0);
         const size_t lds = (size_t)n * (T + (sp.mid_twg ? 0 : 1)) * sizeof(real2);
         const int wgs = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
         sp.mid_minw = std::min(4, std::max(1, (wgs * nt + 255) / 256));
@@ -584,8 +588,13 @@ static const int kGsepBlocks = 512;
 static int admm_alloc(Engine* e) {
   const PlaneGeom& g = e->g;
   const size_t rp = (size_t)g.rplane * e->P;
-  real** bufs[] = {&e->V[0], &e->V[1], &e->HVb[0], &e->HVb[1], &e->xi, &e->eta0[0], &e->eta0[1], &e->eta1[0],
-                    &e->eta1[1], &e->rho, &e->Rsp, &e->Aarr};
+  // the eight arrays reset() zeroes are ONE block, V[0] first: one fill instead of eight (a reset of a DiffuserCam-sized
+  // frame was 8 x 5.3 us of launch-bound fills in a 264-us apply(), profiles/r04k_c1_gaps.txt)
+  real* zeroed = nullptr;
+  LPC_OK(dev_alloc(e, &zeroed, 8 * rp));
+  real** zb[] = {&e->V[0], &e->V[1], &e->HVb[0], &e->HVb[1], &e->xi, &e->eta0[0], &e->eta1[0], &e->rho};
+  for (int k = 0; k < 8; ++k) *zb[k] = zeroed + (size_t)k * rp;
+  real** bufs[] = {&e->eta0[1], &e->eta1[1], &e->Rsp, &e->Aarr};
   for (real** b : bufs) LPC_OK(dev_alloc(e, b, rp));
   LPC_OK(dev_alloc(e, &e->Gabs, (size_t)g.cplane));
   LPC_OK(dev_alloc(e, &e->Ga, (size_t)g.Hp));
@@ -644,8 +653,9 @@ static int admm_setup_constants(Engine* e) {
 static int admm_reset(Engine* e) {
   const PlaneGeom& g = e->g;
   const size_t rb = (size_t)g.rplane * e->P * sizeof(real);
-  real* zero[] = {e->V[1], e->HVb[0], e->HVb[1], e->xi, e->eta0[0], e->eta1[0], e->rho};
-  for (real* z : zero) LPC_RT(rt::memset_async(z, 0, rb, e->stream));
+  // V[1], HVb[0], HVb[1], xi, eta0[0], eta1[0], rho: contiguous behind V[0] (admm_alloc)
+  if (e->has_init) LPC_RT(rt::memset_async(e->V[1], 0, 7 * rb, e->stream));
+  else LPC_RT(rt::memset_async(e->V[0], 0, 8 * rb, e->stream));
   e->vcur = 0;
   e->ecur = 0;
   e->hcur = 0;
@@ -654,8 +664,6 @@ static int admm_reset(Engine* e) {
     LPC_RT(rt::copy_d2d_async(e->V[0], e->init_est, rb, e->stream));
     // admm.py:172-176: forward_out = convolve(V0)
     LPC_OK(convolve_planar(e, e->V[0], e->HVb[0], e->P, true, false));
-  } else {
-    LPC_RT(rt::memset_async(e->V[0], 0, rb, e->stream));
   }
   e->first = true;
   e->pnp_mode = e->pnp_pending = false;

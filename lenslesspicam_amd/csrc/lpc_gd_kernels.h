@@ -23,7 +23,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid(PlaneGeom g, Fft1dPlan plan,
                                                      const real* LPC_RESTRICT Y) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const int u0 = 2 * blockIdx.x, u1 = u0 + 1;
   const long pl = blockIdx.y;
   const bool v1 = u1 < g.H;
@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update(PlaneGeom g, Fft1dPlan pl
                                                         const real* LPC_RESTRICT alpha, GdScalars p) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const int u0 = 2 * blockIdx.x, u1 = u0 + 1;
   const long pl = blockIdx.y;
   const bool v1 = u1 < g.H;
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid_half(PlaneGeom g, PL plan, c
                                                           const real* LPC_RESTRICT Y) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, u = (int)LPC_BX(g);
+  const int tid = LPC_TID(NT), u = (int)LPC_BX(g);
   const long pl = LPC_BY(g);
   const int hh = g.Hp / 2, hw = g.Wp / 2, M = g.Wp >> 1;
   const int sr = wrap_add(g.sh + u, hh, g.Hp);
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update_half(PlaneGeom g, PL plan
                                                              GdScalars p) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, u = (int)LPC_BX(g);
+  const int tid = LPC_TID(NT), u = (int)LPC_BX(g);
   const long pl = LPC_BY(g);
   const int hh = g.Hp / 2, hw = g.Wp / 2;
   const int sr = wrap_add(g.sh + u, hh, g.Hp);
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update_fwd_half(PlaneGeom g, PL 
                                                                  const real* LPC_RESTRICT alpha, GdScalars p) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, u = (int)LPC_BX(g);
+  const int tid = LPC_TID(NT), u = (int)LPC_BX(g);
   const long pl = LPC_BY(g);
   const int hh = g.Hp / 2, hw = g.Wp / 2, M = g.Wp >> 1;
   const int sr = wrap_add(g.sh + u, hh, g.Hp);
@@ -345,7 +345,7 @@ __global__ __launch_bounds__(NT) void k_plane_minmax(PlaneGeom g, const real2* L
                                                       real* LPC_RESTRICT partial) {
   LPC_DYN_SMEM(smem);
   real* scratch = (real*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const long pl = blockIdx.y;
   real mx = -INFINITY, mn = INFINITY;
   if (mode == 0) {
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(NT) void k_gsep_check(const real* LPC_RESTRICT G, i
                                                     real* LPC_RESTRICT partial) {
   LPC_DYN_SMEM(smem);
   real* scratch = (real*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   real mx = (real)0., mn = (real)0.;
   const long n = (long)Hp * Wc;
   for (long e = (long)blockIdx.x * NT + tid; e < n; e += (long)gridDim.x * NT) {

@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, PL plan,
                                                      real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const long pl = blockIdx.y;
   const PairedRows pr = paired_rows_of(g, blockIdx.x, false);
   const real* a = (pr.arr ? B : A) + pl * g.rplane + (long)pr.r0 * g.rpitch;
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_half(PlaneGeom g, PL plan, const re
                                                    real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, row = blockIdx.x >> 1, arr = blockIdx.x & 1;
+  const int tid = LPC_TID(NT), row = blockIdx.x >> 1, arr = blockIdx.x & 1;
   const long pl = blockIdx.y;
   const real2* a2 = (const real2*)((arr ? B : A) + pl * g.rplane + (long)row * g.rpitch);
   auto src = [&](int i, int) { return a2[i]; };
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, PL plan, const re
   real2* s = (real2*)smem;
   // block b runs on XCD b % 8: the array flips every fourth row so that each XCD transforms rows of both (the rows of
   // B outside the sensor window may be skipped: with `arr = b & 1` only the odd XCDs would have less to do: 0.49 -> 0.47 ms, r02ak)
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const unsigned bx = LPC_BX(g);
   int row = bx >> 1, arr = (bx ^ (bx >> 3)) & 1;
   const long pl = LPC_BY(g);
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows(PlaneGeom g, Fft1dPlan plan, R
                                                    real2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const int r0 = 2 * blockIdx.x, r1 = r0 + 1;
   const long pl = blockIdx.y;
   const bool v1 = r1 < src.nrows;
@@ -349,7 +349,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows_half(PlaneGeom g, PL plan, con
                                                         RealSrc src, real2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, r = blockIdx.x;
+  const int tid = LPC_TID(NT), r = blockIdx.x;
   const long pl = blockIdx.y;
   const real* a = src.base + pl * src.plane_stride + (long)r * src.pitch;
   auto in = [&](int i, int) {   // z[i] = (x[2i], x[2i+1]), x zero outside [col0, col0 + ncols)
@@ -372,7 +372,7 @@ __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, PL plan,
                                                      real* LPC_RESTRICT A, real* LPC_RESTRICT B, int window_only) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const long pl = LPC_BY(g);
   const PairedRows pr = paired_rows_of(g, LPC_BX(g), window_only != 0);
   const bool vb = pr.second;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(NT) void k_rinv_rows(PlaneGeom g, Fft1dPlan plan,
                                                    const real2* LPC_RESTRICT S, RealDst dst) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const int r0 = 2 * blockIdx.x, r1 = r0 + 1;
   const long pl = blockIdx.y;
   const bool v1 = r1 < dst.nrows;
@@ -448,7 +448,7 @@ __global__ __launch_bounds__(NT) void k_rinv_rows_half(PlaneGeom g, PL plan, con
                                                         const real2* LPC_RESTRICT S, RealDst dst) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x, r = blockIdx.x;
+  const int tid = LPC_TID(NT), r = blockIdx.x;
   const long pl = blockIdx.y;
   const int hh = g.Hp / 2, hw = g.Wp / 2;
   const int sr = wrap_add(dst.row0 + r, hh, g.Hp);
@@ -466,6 +466,9 @@ __global__ __launch_bounds__(NT) void k_rinv_rows_half(PlaneGeom g, PL plan, con
 
 #ifndef LPC_MID_FUSE1
 #define LPC_MID_FUSE1 false  // measured: no gain on the fused middle (profiles/r01b_notes.md)
+#endif
+#ifndef LPC_SEQ_FUSE1
+#define LPC_SEQ_FUSE1 false  // sequential ADMM middle: first stage of the forward transforms fused into the tile loads
 #endif
 #ifndef LPC_COLS_FUSEL
 #define LPC_COLS_FUSEL true
@@ -523,7 +526,7 @@ __global__ __launch_bounds__(NT) void k_cols(PlaneGeom g, PL plan, ColPass cp,
                                               real2* LPC_RESTRICT S) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const unsigned bx = cp.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;     // ColPass::rev
   const unsigned by = cp.rev ? gridDim.y - 1u - blockIdx.y : blockIdx.y;
   const int grp = (int)fd_div(bx, cp.tcdiv);
@@ -592,7 +595,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_mul(PlaneGeom g, Fft1dPlan plan
                                                       real hscale, int psf_planes) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const int T = cp.T;
   const int grp = (int)fd_div(blockIdx.x, cp.tcdiv);
   const int c0 = ((int)blockIdx.x - grp * cp.ntile_c) * T;
@@ -825,7 +828,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
                                                        real rscale, real sb_outside_scale) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   // (compile-time plans: the tile width is a constant -- e / T, e % T are shifts, not reciprocal multiplies)
   const int T = is_static_plan<PL>::value ? SBT2 / 2 : cp.T, T2 = 2 * T;
   unsigned bid = cp.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
@@ -925,7 +928,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
 // tiles that share a cache line on the same XCD 1.5 MB apart (C4: 0.608 -> 0.550 ms per launch, r03_notes.md section 15).
 // H and |G| are shared by all frames of a batch (L2-resident) and are loaded where they are used.  Compile-time plans
 // only (SBT == cp.T).
-template <int NT, int EMAX, class PL, int SBT, int MINW = 1, bool TWLDS = false>
+template <int NT, int EMAX, class PL, int SBT, int MINW = 1, bool TWLDS = false, bool PRE = false>
 __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL plan, ColPass cp, real2* LPC_RESTRICT SA,
                                                            real2* LPC_RESTRICT SB, const real2* LPC_RESTRICT Hs,
                                                            const real* LPC_RESTRICT Gabs, const real2* LPC_RESTRICT phr,
@@ -933,6 +936,9 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
                                                            real rscale, real sb_outside_scale, int tiles_first) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
+  // (plain threadIdx.x, not LPC_TID: knowing tid < NT the optimiser keeps all 17 row indices of a lane -- as 64-bit
+  // offsets for ga[] / phr[] -- alive from the tile loads to the point-wise step and spills them: 144 bytes of scratch,
+  // C4's middle 0.484 -> 0.797 ms, profiles/r04g_ab.log)
   const int tid = threadIdx.x;
   constexpr int T = SBT, N = PL::n, NELEM = N * T, EM = (NELEM + NT - 1) / NT;
   static_assert(EM <= EMAX, "tile does not fit the workgroup shape");
@@ -944,7 +950,25 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   const unsigned bx = cp.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;   // ColPass::rev
   int fr = (int)(bx % (unsigned)nfr), rest = (int)(bx / (unsigned)nfr);
   int tile = rest % cp.ntile_c, pp = rest / cp.ntile_c;                   // column tile, PSF plane
-  if (tiles_first) {     // A/B option seq_tiles_first: column tiles fastest, then planes (the order of round 2)
+  if (tiles_first == 3) {
+    // Half-line tiles (T x 8 bytes = 64): the two tiles that share every 128-byte line of a frame run on the same XCD
+    // EIGHT blocks apart instead of `frames` blocks apart -- within 16 consecutive blocks, blocks 0-7 are one tile of
+    // eight frames (one per XCD), blocks 8-15 the neighbouring tile of the same eight frames; then the next eight frames
+    // of that tile pair (H and |G| of the pair stay in the L2s meanwhile).  The second half of a line is then an L2 hit
+    // while the first is still in flight, not a fetch from the memory side after the line has been evicted.  Needs
+    // frames % 8 == 0; an odd last tile is handed out frames-fastest at the end of its plane.
+    const int per_pp = cp.ntile_c * nfr, npair = cp.ntile_c >> 1, paired = npair * nfr * 2;
+    pp = (int)(bx / (unsigned)per_pp);
+    const int r = (int)(bx % (unsigned)per_pp);
+    if (r < paired) {
+      const int q = r >> 4, g8 = nfr >> 3;
+      fr = (q % g8) * 8 + (r & 7);
+      tile = 2 * (q / g8) + ((r >> 3) & 1);
+    } else {
+      fr = (r - paired) % nfr;
+      tile = cp.ntile_c - 1;
+    }
+  } else if (tiles_first) {     // A/B option seq_tiles_first: column tiles fastest, then planes (the order of round 2)
     tile = (int)(bx % (unsigned)cp.ntile_c);
     const int q = (int)(bx / (unsigned)cp.ntile_c);
     fr = q / g.DC; pp = q % g.DC;
@@ -973,21 +997,64 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   // (the closures copy what they use: captured by reference they end up in scratch and every access through them
   // becomes a flat_load that also counts against the LDS wait counter)
   const int wc = g.Wc - c0, sh = g.sh, hwin = g.H;
-  auto inB = [=](int i, int j) {
-    real2 x = make_real2((real)0., (real)0.);      // (not `cond ? bb[..] : zero`: that selects between two ADDRESSES)
-    if (j < wc) x = ld_off(bb, mul24((unsigned)i, r8) + (unsigned)j * c8);
+  // Loads are UNCONDITIONAL and carry no arithmetic: the columns of a tile are independent transforms, so a column past
+  // the frame's edge may hold whatever the row padding holds (cpitch is a multiple of 16 >= every tile width: the
+  // address is always inside the plane) -- it is never stored.  The scale of SB's rows is applied where the value goes
+  // into LDS.  With `if (j < wc)` around the load and the product behind it, every load that MIGHT lie outside the
+  // sensor window had its own `s_waitcnt vmcnt(0)`: the first and last five of a lane's 17 loads went out one full
+  // HBM latency after the other (round 3's kernel).
+  static_assert(16 % T == 0, "tile columns must stay inside the padded row pitch");
+  auto inB = [=](int i, int j) { return ld_off(bb, mul24((unsigned)i, r8) + (unsigned)j * c8); };
+  auto fixB = [=](int i, int, real2 x) {
     return cscale(x, (unsigned)(i - sh) >= (unsigned)hwin ? sb_k : (real)1.);   // one compare, one select, one product
   };
-  auto inA = [=](int i, int j) {
-    real2 x = make_real2((real)0., (real)0.);
-    if (j < wc) x = ld_off(ba, mul24((unsigned)i, r8) + (unsigned)j * c8);
-    return x;
-  };
+  auto inA = [=](int i, int j) { return ld_off(ba, mul24((unsigned)i, r8) + (unsigned)j * c8); };
   // the twiddle table moves into LDS behind the tile (lpc_sfft.h twiddles_to_lds)
   if (TWLDS) plan = twiddles_to_lds<NT>(plan, s + NELEM, tid);
-  // 1. Ah = FFT(a), parked in registers in tile order e = tid + k NT
-  fft_tile<NT, EMAX, false, false, false, false, false, SBT>(s, plan, T, cp.tdiv, tid, inB, LdsNatural{});
   real2 a[EM];
+  if constexpr (PRE) {
+    // Both tiles' loads are issued up front, `a` first, r_sp right behind it: the transform of `a` then runs while the
+    // tile of r_sp is still in flight (the wait for `a` is a vmcnt(EM), not a vmcnt(0)), instead of every workgroup
+    // sitting out two full load latencies.  The registers that later park Ah hold the r_sp tile until then.
+    real2 pb[EM], pa[EM];
+#pragma unroll
+    for (int k = 0; k < EM; ++k) {
+      const int e = tid + k * NT;
+      const int ec = (!(NELEM % NT) || e < NELEM) ? e : 0;        // (the tail lanes of the last round load element 0)
+      pb[k] = inB(ec / T, ec % T);
+    }
+#pragma unroll
+    for (int k = 0; k < EM; ++k) {
+      const int e = tid + k * NT;
+      const int ec = (!(NELEM % NT) || e < NELEM) ? e : 0;
+      pa[k] = inA(ec / T, ec % T);
+    }
+#pragma unroll
+    for (int k = 0; k < EM; ++k) {
+      const int e = tid + k * NT;
+      if (!(NELEM % NT) || e < NELEM) s[e] = fixB(e / T, e % T, pb[k]);
+    }
+    __syncthreads();
+    // 1. Ah = FFT(a)
+    fft_tile<NT, EMAX, false, false, false, false, false, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, LdsNatural{});
+#pragma unroll
+    for (int k = 0; k < EM; ++k) {
+      const int e = tid + k * NT;
+      a[k] = make_real2((real)0., (real)0.);
+      if (e < NELEM) a[k] = s[e];
+    }
+    __syncthreads();
+    // 2. Rh = FFT(r_sp) in the same tile
+#pragma unroll
+    for (int k = 0; k < EM; ++k) {
+      const int e = tid + k * NT;
+      if (!(NELEM % NT) || e < NELEM) s[e] = pa[k];
+    }
+    __syncthreads();
+    fft_tile<NT, EMAX, false, false, false, false, false, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, LdsNatural{});
+  } else {
+  // 1. Ah = FFT(a), parked in registers in tile order e = tid + k NT
+  fft_tile<NT, EMAX, false, false, false, LPC_SEQ_FUSE1, false, SBT>(s, plan, T, cp.tdiv, tid, inB, LdsNatural{}, fixB);
 #pragma unroll
   for (int k = 0; k < EM; ++k) {
     const int e = tid + k * NT;
@@ -996,7 +1063,8 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   }
   __syncthreads();
   // 2. Rh = FFT(r_sp) in the same tile
-  fft_tile<NT, EMAX, false, false, false, false, false, SBT>(s, plan, T, cp.tdiv, tid, inA, LdsNatural{});
+  fft_tile<NT, EMAX, false, false, false, LPC_SEQ_FUSE1, false, SBT>(s, plan, T, cp.tdiv, tid, inA, LdsNatural{});
+  }
   // 3. Vh = Rdiv (Rh + s conj(H) Ah) -> tile;  HVh = s H Vh -> the registers that held Ah
 #pragma unroll
   for (int k = 0; k < EM; ++k) {
@@ -1131,7 +1199,7 @@ __global__ __launch_bounds__(NT) void k_admm_spatial(PlaneGeom g, AdmmScalars p,
   real* sO = sV + VH * VW;                 // same for V_old
   real* sQ0 = sO + VH * VW;                // [TH+1][TW]
   real* sQ1 = sQ0 + (TH + 1) * TW;         // [TH][TW+1]
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule, used for speed
   // only).  Give each XCD a contiguous band of tiles so that the halo lines shared by neighbouring
   // tiles are re-read from the SAME L2 instead of from the fabric.
@@ -1277,7 +1345,7 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
   constexpr int VH = TH + 2;
   real* sV = (real*)smem;                     // [VH][LP]
   real* sO = sV + VH * LP;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const unsigned nblk = gridDim.x, bid = p.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;   // XCD-aware tile order (see k_admm_spatial)
   const unsigned qd = nblk >> 3, rm = nblk & 7, xcd = bid & 7, idx = bid >> 3;
   const unsigned tile = (xcd < rm ? xcd * (qd + 1) : rm * (qd + 1) + (xcd - rm) * qd) + idx;
@@ -1469,7 +1537,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_half_x(PlaneGeom g, AdmmScalars p, 
                                                      real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   // No row needs a neighbour, and rows inside the sensor window cost more than rows outside (AdmmScalars::xiw): bands of
   // rows per XCD would leave the XCDs that hold the window rows working while the others idle, so rows go round-robin
   // over the XCDs (block b runs on XCD b % 8: the even XCDs transform the rows of r_sp, the odd ones form and transform
@@ -1527,7 +1595,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p
                                                        real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  const int tid = threadIdx.x;
+  const int tid = LPC_TID(NT);
   const long pl = LPC_BY(g);
   const PairedRows pr = paired_rows_of(g, LPC_BX(g), p.skipa != 0);
   const bool v1 = pr.second;

@@ -10,6 +10,9 @@
 #ifndef LPC_MOD_MID_TWG
 #define LPC_MOD_MID_TWG 0
 #endif
+#ifndef LPC_MOD_MID_PRE
+#define LPC_MOD_MID_PRE 0
+#endif
 #ifndef LPC_MOD_FAMILY
 #error "lpc_module.cpp is compiled with the flags of plan_spec_defines() (lpc_plan.h)"
 #endif
@@ -154,12 +157,15 @@ static int m_admm_mid(Engine* e, const ColPass* cp, const AdmmScalars* sc, real 
   const real rscale = (real)1.0 / ((real)g.Hp * (real)g.Wp);
 #if LPC_MOD_MID_KIND == LPC_MID_SEQ     // single-pass columns, one spectrum at a time through T columns
   constexpr bool TWL = LPC_MOD_MID_TWG == 0;     // the plan's twiddles in LDS behind the tile
-  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, TWL>,
+  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, TWL, LPC_MOD_MID_PRE != 0>,
                   dim3(cp->ntile_c * e->P), NT, (size_t)MidP::n * (T + (TWL ? 1 : 0)) * sizeof(real2), g, pa, *cp, SA, SB,
                   (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, sc->mu1,
                   sc->mu2, sc->mu3, rscale, sb_outside_scale,
                   // whole long columns two at a time (option col_single): the tiles that share a cache line on one XCD
-                  (e->opt.seq_tiles_first == 0 && (size_t)MidP::n * 16 > (size_t)kMaxTilePoints) ? 2 : e->opt.seq_tiles_first);
+                  (e->opt.seq_tiles_first == 0 && (size_t)MidP::n * 16 > (size_t)kMaxTilePoints) ? 2
+                  // half-line tiles of a batch: the two halves of a line eight blocks apart on one XCD (option seq_pair)
+                  : (e->opt.seq_tiles_first == 0 && e->opt.seq_pair != 0 && T * sizeof(real2) == 64 && (e->P / g.DC) % 8 == 0) ? 3
+                  : e->opt.seq_tiles_first);
 #else                                   // both spectra side by side: [N][2 T]
   const FastDiv t2 = make_fastdiv((unsigned)(2 * T));
   return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<NT, EM, MidPA, 2 * T, true>, dim3(cp->G * cp->ntile_c, e->P), NT,

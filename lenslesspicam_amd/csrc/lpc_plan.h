@@ -50,6 +50,7 @@ struct PlanSpec {
   StaticFft mid;              // ADMM fused middle in LDS
   int mid_minw = 1;           // __launch_bounds__ second argument of the sequential middle
   int mid_twg = 0;            // sequential middle: twiddles read from global memory instead of a copy in LDS behind the tile
+  int mid_pre = 0;            // sequential middle: both tiles' loads issued before the first transform
   bool any() const { return row_kind != LPC_ROWS_RUNTIME || passA.n || mid_kind != LPC_MID_RUNTIME; }
 };
 
@@ -64,7 +65,7 @@ static inline std::string plan_spec_key(const PlanSpec& s) {
   k += s.family == LPC_FAM_ADMM ? "_admm" : "_gd";
   if (s.row_kind) k += std::string(s.row_kind == LPC_ROWS_HALF ? "_rh" : "_rp") + fft_key(s.row) + (s.row_sk == 1 ? "s" : (s.row_sk == 2 ? "z" : "")) + (s.row_x ? "x" : "");
   if (s.passA.n) k += "_a" + fft_key(s.passA);
-  if (s.mid_kind) k += std::string(s.mid_kind == LPC_MID_PAIR ? "_mp" : "_ms") + fft_key(s.mid) + "m" + std::to_string(s.mid_minw) + (s.mid_twg ? "g" : "");
+  if (s.mid_kind) k += std::string(s.mid_kind == LPC_MID_PAIR ? "_mp" : "_ms") + fft_key(s.mid) + "m" + std::to_string(s.mid_minw) + (s.mid_twg ? "g" : "") + (s.mid_pre ? "p" : "");
   return k;
 }
 static inline std::string rad_list(const StaticFft& f) {
@@ -96,6 +97,7 @@ static inline std::vector<std::string> plan_spec_defines(const PlanSpec& s) {
     defi("LPC_MOD_MID_NT", s.mid.nt); defi("LPC_MOD_MID_EM", s.mid.em); defi("LPC_MOD_MID_T", s.mid.T);
     defi("LPC_MOD_MID_MINW", s.mid_minw);
     defi("LPC_MOD_MID_TWG", s.mid_twg);
+    defi("LPC_MOD_MID_PRE", s.mid_pre);
   }
   return d;
 }
@@ -129,7 +131,9 @@ struct EngineOpts {
                               // columns per workgroup, one spectrum at a time (k_cols_mid_admm_seq) -- instead of pass A +
                               // middle + inverse pass A, whenever a two-column tile of whole columns fits LDS.  -1: by size
   int mid_twg = 0;            // sequential middle: twiddles from global memory (no LDS copy: more workgroups per CU)
+  int mid_pre = -1;           // sequential middle: load both tiles before the first transform (-1: default of the plan)
   int seq_tiles_first = 0;    // sequential middle: workgroups handed out column tiles fastest instead of frames fastest
+  int seq_pair = 0;           // sequential middle, 64-byte tile rows: the two tiles of a cache line 8 blocks apart on one XCD (measured: no gain)
   int mid_swz = -1;           // side-by-side LDS middle: pairs of column tiles on one XCD (ColPass::swz); -1: when a tile
                               // row is narrower than a 128-byte line
   int hv_full = 0;            // every row of H V transformed in every iteration
@@ -195,8 +199,10 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "seq_t") o.seq_t = (int)iv;
       else if (k == "mid_nt") o.mid_nt = (int)iv;
       else if (k == "seq_tiles_first") o.seq_tiles_first = (int)iv;
+      else if (k == "seq_pair") o.seq_pair = (int)iv;
       else if (k == "col_single") o.col_single = (int)iv;
       else if (k == "mid_twg") o.mid_twg = (int)iv;
+      else if (k == "mid_pre") o.mid_pre = (int)iv;
       else if (k == "g_plane") o.g_plane = (int)iv;
       else if (k == "mid_swz") o.mid_swz = (int)iv;
       else if (k == "hv_full") o.hv_full = (int)iv;

@@ -53,6 +53,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
 #define gridDim (lpc_emu::ctx().gdim)
 #define __syncthreads() lpc_emu::barrier()
 #define LPC_DYN_SMEM(name) char* name = lpc_emu::ctx().smem
+#define LPC_TID(nt) ((int)threadIdx.x)
 
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32); }
 
@@ -91,6 +92,15 @@ static inline const char* backend_name() { return "simt-emu(test-only)"; }
 #define LPC_DYN_SMEM(name)                                              \
   extern __shared__ __attribute__((aligned(16))) char lpc_dyn_smem_[];  \
   char* name = lpc_dyn_smem_
+// threadIdx.x with its range: __launch_bounds__ alone does not tell the optimiser that tid < NT, and without it every
+// `tid + k * NT < NELEM` guard that is always true stays a branch -- with the load inside it and a `s_waitcnt vmcnt(0)`
+// behind the load (k_cols_mid_admm_seq: 4 of a lane's 17 tile loads went out one HBM latency after the other)
+static __device__ __forceinline__ int lpc_tid_below(unsigned nt) {
+  const unsigned t = threadIdx.x;
+  __builtin_assume(t < nt);
+  return (int)t;
+}
+#define LPC_TID(nt) lpc_tid_below((unsigned)(nt))
 
 typedef hipStream_t lpcStream_t;
 typedef hipError_t lpcError_t;

@@ -632,6 +632,28 @@ def test_c4_sequential_middle_frames_fastest_block_order(backend):
         assert torch.equal(single.apply(n_iter=2, disp_iter=None), got[b]), b
 
 
+def test_c4_sequential_middle_half_line_pairs_block_order(backend):
+    """Batches whose frame count is a multiple of 8: the two 64-byte-row tiles that share every cache line of a frame are
+    handed out 8 blocks apart on one XCD (k_cols_mid_admm_seq, tiles_first == 3; option seq_pair=0 restores the
+    frames-fastest order), with both tiles' loads issued up front (mid_pre=1, the default of large batches).  8 gray
+    frames x 2 depth planes x 61 column tiles (odd: the last tile of every plane is handed out on its own) -- bit for bit
+    the frames-fastest order's result, and a single-frame run's."""
+    rng = np.random.default_rng(32)
+    psf = torch.from_numpy(orc.synthetic_psf(2, 270, 480, 1, seed=2))
+    ys = torch.from_numpy(rng.random((8, 1, 270, 480, 1), dtype=np.float32))
+    outs = []
+    for extra in ({"mid_pre": 1}, {"seq_pair": 0, "mid_pre": 0}):
+        rec = lpa.ADMM(psf, engine_options={"mid_seq": 1, "prow_nt128": 1, "jit_min_points": 0, **extra})
+        rec.set_data(ys)
+        assert "one spectrum at a time" in rec._handle.plan_info()
+        outs.append(rec.apply_batch(n_iter=2))
+    assert torch.equal(outs[0], outs[1])
+    single = lpa.ADMM(psf, engine_options={"mid_seq": 1, "prow_nt128": 1, "jit_min_points": 0})
+    for b in (0, 5, 7):
+        single.set_data(ys[b, 0])
+        assert torch.equal(single.apply(n_iter=2, disp_iter=None), outs[0][b]), b
+
+
 def test_middle_tile_pairs_on_one_xcd(backend):
     """Option mid_swz: the side-by-side LDS middle hands its workgroups out so that the two 128-byte column tiles of a
     256-byte pair run on the same XCD (ColPass::swz) -- a permutation of the block order, so the result must be bit for
@@ -817,3 +839,24 @@ def test_row_tile_lds_layouts(backend, monkeypatch, lay, half):
     info = lpa.ADMM(torch.from_numpy(psf).to(backend.device))._handle.plan_info()
     key = info.split("plan module ")[1]
     assert ("z" if lay == 2 else "") + "x" in key.split("_")[2] and "s" not in key.split("_")[2].split("w")[1], key
+
+
+@pytest.mark.parametrize("shape,seq_t", [((270, 20, 1), 2), ((270, 20, 3), 1), ((300, 36, 1), 4)])
+def test_single_launch_columns(backend, monkeypatch, shape, seq_t):
+    """option col_single=1: the whole column transform of the ADMM step in one launch -- the sequential middle
+    (k_cols_mid_admm_seq) over WHOLE columns, seq_t image columns per workgroup, instead of pass A + middle + inverse pass
+    A (what 12 MP would run: 6144-row columns two at a time; here 540- / 600-row columns, the smallest heights that take
+    the mode).  Sensor-window structure included (rows of SB outside the window rescaled by the middle)."""
+    engine_opts(monkeypatch, col_single=1, jit_min_points=0, seq_t=seq_t)
+    H, W, C = shape
+    rng = np.random.default_rng(H + W)
+    psf = orc.synthetic_psf(1, H, W, C, seed=4)
+    y = rng.random((H, W, C), dtype=np.float32)
+    rec = lpa.ADMM(torch.from_numpy(psf).to(backend.device), tau=2e-6, mu2=1e-4)
+    info = rec._handle.plan_info()
+    assert f"single pass {rec._padded_shape[1]}, T = {seq_t}" in info and "one spectrum at a time" in info, info
+    assert "row transforms skipped" in info, info
+    rec.set_data(torch.from_numpy(y).to(backend.device))
+    o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
+    o.set_data(y)
+    assert rel(rec.apply(n_iter=8, disp_iter=None), o.apply(8)) <= 5e-6, info
