@@ -581,6 +581,7 @@ static AdmmScalars admm_scalars(const Engine* e, const double cur[4]) {
   p.xi_store = 1;              // admm_iterate clears it on all but the last iteration of a call
   p.skipa = p.skiphv = 0;      // set by admm_iterate inside a call (AdmmScalars::skipa)
   p.rev = (e->opt.rev_order & 1) ? 1 : 0;
+  p.half_in = p.half_out = 0;  // set by admm_iterate between the iterations of one call (AdmmScalars::half_in)
   return p;
 }
 
@@ -712,7 +713,17 @@ static int admm_iterate(Engine* e, int n_iter) {
     // xi = mu1p (HV - HV_old) of the final X half and every read-out after the call need HV_{n-2}, HV_{n-1}, HV_n whole
     sc.skipa = (e->hv_skip && sb_rows_valid && !sc.xi_store) ? 1 : 0;
     sc.skiphv = (e->hv_skip && it + 3 < n_iter) ? 1 : 0;
-    if (vec4 && e->xhalf_rows)
+    // duals half-applied between the iterations of this call (AdmmScalars::half_in; option k1_half=0: never): the
+    // first iteration reads plain duals, the last one writes them -- nothing outside this loop sees the other form
+    const bool k1_half = vec4 && e->xhalf_rows && e->opt.k1_half != 0;
+    sc.half_in = (k1_half && it > 0) ? 1 : 0;
+    sc.half_out = (k1_half && it + 1 < n_iter) ? 1 : 0;
+    if (sc.half_in)
+      LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4X, NT, false, true>, k1_grid4x, NT, k1_smem4x / 2, g, sc, (const real*)Vc,
+                      (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
+                      (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
+                      (const real*)e->Y, e->Rsp, e->Aarr, tiles_x4));
+    else if (vec4 && e->xhalf_rows)
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4X, NT, false>, k1_grid4x, NT, k1_smem4x, g, sc, (const real*)Vc,
                       (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
                       (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
@@ -1438,7 +1449,9 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
       // X half in the forward rows (default with compile-time row plans): the tiled kernel reads V, V_old, eta0, eta1,
       // rho and writes eta0, eta1, rho, r_sp = 9R (SURVEY's 15R + R0 minus its X part: reads HV, X, xi, y, writes xi, X,
       // a); the row kernel reads r_sp (R) and xi, HV, HV_old, y (3R + R0), writes xi (R) and the two spectra (2S).
-      case LPC_K_SPATIAL: b = e->xhalf_rows ? 9.0 * R : 15.0 * R + R0; break;
+      // ... and without V_old once the duals travel half-applied between the iterations of a call (k1_half): 8R
+      case LPC_K_SPATIAL: b = e->xhalf_rows ? ((e->opt.k1_half != 0 && g.Wp % 4 == 0 && !e->opt.k1_scalar) ? 8.0 : 9.0) * R
+                                            : 15.0 * R + R0; break;
       // ... with xi confined to the sensor window (AdmmScalars::xiw) the row kernel reads r_sp, HV everywhere (2R) and
       // xi, HV_old / writes xi only over the window (3 window-sized arrays per plane) and y: 2R + 3 Rw + R0 + 2S
       // ... and with the H V row transforms skipped on rows wholly outside the window (AdmmScalars::skipa, steady state

@@ -1140,6 +1140,15 @@ struct AdmmScalars {
   // W-update of this / of the previous iteration saw clamp(V) / clamp(V_old).
   int clamp_cur, clamp_old;
   int rev;    // the tiled kernel walks its grid backwards (see ColPass::rev)
+  // Half-applied duals between the iterations of ONE lpc_iterate() call (k_admm_spatial_v4, option k1_half):
+  //   eta~ = eta - mu2 U,   rho~ = rho - mu3 W          (stored by an iteration with half_out)
+  //   eta' = eta~ + mu2p Psi V_new,   rho' = rho~ + mu3p V_new      (the pending update, read by one with half_in)
+  // -- algebraically eta + mu2p (Psi V_new - U), the reference's update (admm.py:300-311), but U and W of the previous
+  // iteration need not be RECOMPUTED from V_old, so the kernel does not read V_old: 9 R -> 8 R of HBM traffic per launch.
+  // The first iteration of a call reads, and the last one writes, the plain duals: every other entry point (read-outs,
+  // plug-and-play, a caller's psi) sees the state of round 3.  Rounding differs from the reference's order of operations
+  // by one ulp of the dual per iteration (float64 build: identical to 1e-16).
+  int half_in, half_out;
 };
 // the estimate as the W-update saw it
 static __device__ __forceinline__ real w_sees(real v, bool clamped, bool inside) {
@@ -1316,17 +1325,22 @@ static __device__ __forceinline__ void tv_component(const AdmmScalars& p, real v
                                                      real eta, real& eta_new, real& q) {
   const real psi = vn - vc;                       // finite_diff: roll(+1) - x   (admm.py:349-359)
   if (!p.first) {
-    const real uo = soft_thresh_dev((on - oc) + div_by(eta, p.mu2p, p.r_mu2p), p.thrp);
-    eta = eta + p.mu2p * (psi - uo);               // pending eta update of the previous iteration
+    if (p.half_in) {
+      eta = eta + p.mu2p * psi;                    // stored: eta - mu2p U_old (AdmmScalars::half_in)
+    } else {
+      const real uo = soft_thresh_dev((on - oc) + div_by(eta, p.mu2p, p.r_mu2p), p.thrp);
+      eta = eta + p.mu2p * (psi - uo);             // pending eta update of the previous iteration
+    }
   }
   const real un = soft_thresh_dev(psi + div_by(eta, p.mu2, p.r_mu2), p.thr);
-  eta_new = eta;
   q = p.mu2 * un - eta;
+  eta_new = p.half_out ? -q : eta;
 }
 
 // XHALF == false: the TV / W half only (eta, rho, r_sp); xi and a = mu1 X - xi are then produced by the forward row
 // kernel itself (k_rfwd_half_x / k_rfwd_arrays_x), which needs nothing but its own row for them.
-template <int TH, int NT, bool XHALF = true>
+// HIN: the duals arrive half-applied (AdmmScalars::half_in): no V_old tile is staged or read.
+template <int TH, int NT, bool XHALF = true, bool HIN = false>
 __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars p,
                                                          const real* LPC_RESTRICT V,
                                                          const real* LPC_RESTRICT Vold,
@@ -1368,13 +1382,13 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
     const int ly = e / (TW / 4), l4 = e - ly * (TW / 4);
     const long o = (long)wrap_r(r0 + ly - 1) * g.rpitch + wrap_c4(c0 + 4 * l4);
     st4(sV + ly * LP + 4 + 4 * l4, ld4(v + o));
-    st4(sO + ly * LP + 4 + 4 * l4, p.first ? make_real4((real)0., (real)0., (real)0., (real)0.) : ld4(vo + o));
+    if (!HIN) st4(sO + ly * LP + 4 + 4 * l4, p.first ? make_real4((real)0., (real)0., (real)0., (real)0.) : ld4(vo + o));
   }
   for (int e = tid; e < VH * 2; e += NT) {
     const int ly = e >> 1, side = e & 1;
     const long o = (long)wrap_r(r0 + ly - 1) * g.rpitch + wrap_c(side ? c0 + TW : c0 - 1);
     sV[ly * LP + (side ? 4 + TW : 3)] = v[o];
-    sO[ly * LP + (side ? 4 + TW : 3)] = p.first ? (real)0. : vo[o];
+    if (!HIN) sO[ly * LP + (side ? 4 + TW : 3)] = p.first ? (real)0. : vo[o];
   }
   __syncthreads();
 
@@ -1405,8 +1419,9 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
     const real* orc = orm + LP;
     const real* orp = orc + LP;
     const real4 vm4 = ld4(rowm), vc4 = ld4(rowc), vp4 = ld4(rowp);
-    const real4 om4 = ld4(orm), oc4 = ld4(orc), op4 = ld4(orp);
-    const real vl = rowc[-1], vr = rowc[4], ol = orc[-1], orr = orc[4];
+    const real4 zo4 = make_real4((real)0., (real)0., (real)0., (real)0.);
+    const real4 om4 = HIN ? zo4 : ld4(orm), oc4 = HIN ? zo4 : ld4(orc), op4 = HIN ? zo4 : ld4(orp);
+    const real vl = rowc[-1], vr = rowc[4], ol = HIN ? (real)0. : orc[-1], orr = HIN ? (real)0. : orc[4];
     const real vcs[6] = {vl, vc4.x, vc4.y, vc4.z, vc4.w, vr};       // cols gc-1 .. gc+4 of row gr
     const real ocs[6] = {ol, oc4.x, oc4.y, oc4.z, oc4.w, orr};
     const real vms[4] = {vm4.x, vm4.y, vm4.z, vm4.w}, vps[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
@@ -1436,14 +1451,18 @@ __global__ __launch_bounds__(NT) void k_admm_spatial_v4(PlaneGeom g, AdmmScalars
           const real xo = (inside ? p.m_in_p : p.m_out_p) * (xiv + p.mu1p * hos[i] + yv);   // previous X
           xiv = xiv + p.mu1p * (hv - xo);
         }
-        const real wo = rmax(div_by(rhov, p.mu3p, p.r_mu3p) + w_sees(ocs[i + 1], p.clamp_old, inside), (real)0.);
-        rhov = rhov + p.mu3p * (vc - wo);
+        if (HIN || p.half_in) {
+          rhov = rhov + p.mu3p * vc;                // stored: rho - mu3p W_old (AdmmScalars::half_in)
+        } else {
+          const real wo = rmax(div_by(rhov, p.mu3p, p.r_mu3p) + w_sees(ocs[i + 1], p.clamp_old, inside), (real)0.);
+          rhov = rhov + p.mu3p * (vc - wo);
+        }
       }
       const real xnew = (inside ? p.m_in : p.m_out) * (xiv + p.mu1 * hv + yv);
       const real wn = rmax(div_by(rhov, p.mu3, p.r_mu3) + w_sees(vc, p.clamp_cur, inside), (real)0.);
       const real d1 = q0d - q0c;
       const real d2 = q1[i + 1] - q1[i];
-      xin[i] = xiv; rhn[i] = rhov;
+      xin[i] = xiv; rhn[i] = p.half_out ? rhov - p.mu3 * wn : rhov;
       rs[i] = (p.mu3 * wn - rhov) + (d1 + d2);
       as[i] = p.mu1 * xnew - xiv;
     }

@@ -479,7 +479,9 @@ def test_xi_outside_the_sensor_window(backend, monkeypatch, shape):
     H, W, C = shape
     # (hv_full: the H V row transforms run on every row, so that calls of any length are the same instruction stream;
     # the plan that also skips those outside the window is compared at the end and in the next test)
-    engine_opts(monkeypatch, jit_min_points=0, hv_full=1)
+    # (k1_half=0 likewise: with the duals half-applied between the iterations of a call, a 4-iteration call and four
+    # 1-iteration calls round the dual updates differently; the default plan is compared at the end)
+    engine_opts(monkeypatch, jit_min_points=0, hv_full=1, k1_half=0)
     rng = np.random.default_rng(8)
     psf = orc.synthetic_psf(1, H, W, C, seed=8)
     y = rng.random((H, W, C), dtype=np.float32)
@@ -513,7 +515,7 @@ def test_xi_outside_the_sensor_window(backend, monkeypatch, shape):
     engine_opts(monkeypatch, xi_full=1)
     _, xif, xf, vf = run([4])
     assert rel(vf, v4) <= 2e-6 and np.abs(xif - xi4).max() <= 2e-5 * scale
-    engine_opts(monkeypatch, xi_full=None, hv_full=None)           # the default plan
+    engine_opts(monkeypatch, xi_full=None, hv_full=None, k1_half=None)           # the default plan
     recd, xid, xd, vd = run([4])
     assert "row transforms skipped" in recd._handle.plan_info()
     assert rel(vd, v4) <= 2e-6 and rel(xd, x4) <= 2e-6 and np.abs(xid - xi4).max() <= 2e-5 * scale
