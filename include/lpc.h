@@ -96,6 +96,20 @@ typedef struct lpc_config {
  *   xi_full=1 hv_full=1 no_xhalf=1 k1_scalar=1      ADMM without the sensor-window structure of xi / of the H V row
  *                      transforms; with the stand-alone image-domain kernel; ... in its scalar-lane form
  *   row_rad=16.16.8 passa_rad=16.8 mid_rad=6.10.9   radices of the compile-time row / pass-A / LDS-middle plan (tuning)
+ *   k1_half=0          ADMM duals stored plain between the iterations of one call (default 1: half-applied, the tiled
+ *                      kernel then does not read V_old: 9R -> 8R)
+ *   mid_pre=0|1 mid_twg=1 seq_pair=1               sequential middle: both tiles' loads before the first transform (default:
+ *                      launches of >= 4096 workgroups); twiddles from global memory; the two 64-byte tiles of a cache line
+ *                      eight blocks apart on one XCD (measured: no gain)
+ *   col_single=0|1     ADMM, float32: the whole column transform in ONE launch over whole columns (measured at 12 MP:
+ *                      2.25 ms against 1.455 ms for pass A + middle + inverse pass A; default: off)
+ *   row_lay=0|1|2      LDS layout of the compile-time row tiles: natural / i + i/8 (default where affine) / the conflict-free
+ *                      xor layout (measured: no faster);  row_nt=N  lanes per row workgroup
+ *   module_max=N module_loaded_max=N               plan-module files kept per directory this library writes to (256, least
+ *                      recently used removed first); modules kept loaded once no handle uses them (64)
+ *   row_pf=N           ADMM inverse rows (half-length, float32, radices 8 / 16) as N persistent workgroups per CU with
+ *                      the next row in flight by LDS-DMA (N >= 16: workgroups in all); measured: no faster (default 0)
+ *   rpitch_pad=N       floats added to the row pitch of the padded real planes (measured: no faster; default 0)
  *   no_r2=1 no_skew=1 gd_no_fuse_fwd=1              run-time row plans without the folded radix-2 stage / the LDS skew;
  *                      gradient-descent update without the next iteration's forward rows
  * An unknown key makes lpc_create fail. */

@@ -401,7 +401,7 @@ static int setup_shape(Engine* e, bool* want_static_out) {
   g.Wc = g.Wp / 2 + 1;
   g.sh = (g.Hp - g.H) / 2;
   g.sw = (g.Wp - g.W) / 2;
-  g.rpitch = (g.Wp + 3) / 4 * 4;
+  g.rpitch = (g.Wp + 3) / 4 * 4 + (e->opt.rpitch_pad > 0 ? e->opt.rpitch_pad / 4 * 4 : 0);
   g.cpitch = (g.Wc + 15) / 16 * 16;
   g.rplane = (long)g.Hp * g.rpitch;
   g.cplane = (long)g.Hp * g.cpitch;

@@ -58,6 +58,18 @@ static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outsi
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const int hrows = skip_hv_outside ? g.Hp + g.H : 2 * g.Hp;
+#ifndef LPC_DOUBLE
+  if constexpr (LdsTw<RowP>::ok(RNT)) {
+    if (e->opt.row_pf > 0) {      // persistent workgroups, the next row in flight (k_rinv_half_pf)
+      const size_t smem = ((kRowSmem + 15) / 16) * 16 + (size_t)(RowP::n + 8 + LdsTw<RowP>::size) * sizeof(real2);
+      const int total = e->opt.row_pf >= 16 ? e->opt.row_pf : e->opt.row_pf * rt::cu_count();   // (>= 16: workgroups, tuning)
+      const int gx = std::max(1, std::min(hrows, total / std::max(1, e->P)));
+      return launch_k(e, LPC_K_ROW_INV, k_rinv_half_pf<RNT, REM, RSK, RowPA>, dim3(gx, e->P), RNT, smem,
+                      geom_rev(e, e->opt.rev_rows & 2), row_arg(e), e->planW.tw, (const real2*)SA, (const real2*)SB, Vout,
+                      HVout, skip_hv_outside ? 1 : 0, hrows);
+    }
+  }
+#endif
   return launch_k(e, LPC_K_ROW_INV, k_rinv_half<RNT, REM, RSK, RowPA>, dim3(hrows, e->P), RNT, kRowSmem,
                   geom_rev(e, e->opt.rev_rows & 2), row_arg(e),
                   e->planW.tw, (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);

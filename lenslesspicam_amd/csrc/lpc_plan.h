@@ -146,6 +146,10 @@ struct EngineOpts {
   int row_lay = -1;           // LDS layout of the compile-time row plans: -1 / 1 i + i/8 where that stays affine; 0 natural;
                               // 2 the conflict-free xor layout (lengths that are multiples of 16; measured: no faster)
   int gd_no_fuse_fwd = 0;     // gradient-descent update without the next iteration's forward rows
+  int rpitch_pad = 0;         // floats added to the pitch of the padded real planes (tuning: a pitch of 2^k bytes puts the same
+                              // column of every row on the same HBM channel)
+  int row_pf = 0;             // ADMM inverse rows (half-length, float32, radices 8 / 16): persistent workgroups, N per CU, with
+                              // the next row in flight by LDS-DMA (k_rinv_half_pf); 0: one workgroup per row
   int row_nt = 0;             // threads per row workgroup of the compile-time row plan (tuning; multiple of 64)
   std::string row_rad, passa_rad, mid_rad;   // "16.16.8": radices of the compile-time row / pass-A / LDS-middle plan
                               // instead of the chooser's (an experiment costs one module: ~3 s); ignored unless the
@@ -217,6 +221,8 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "row_lay") o.row_lay = (int)iv;
       else if (k == "gd_no_fuse_fwd") o.gd_no_fuse_fwd = (int)iv;
       else if (k == "row_nt") o.row_nt = (int)iv;
+      else if (k == "row_pf") o.row_pf = (int)iv;
+      else if (k == "rpitch_pad") o.rpitch_pad = (int)iv;
       else if (k == "row_rad") o.row_rad = v;
       else if (k == "passa_rad") o.passa_rad = v;
       else if (k == "mid_rad") o.mid_rad = v;

@@ -54,6 +54,11 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
 #define __syncthreads() lpc_emu::barrier()
 #define LPC_DYN_SMEM(name) char* name = lpc_emu::ctx().smem
 #define LPC_TID(nt) ((int)threadIdx.x)
+// LDS-DMA (see the HIP branch): the emulator copies the lane's 16 bytes itself
+static inline void lpc_glds16(const void* gsrc, void* lds_wave_base, int lane) {
+  std::memcpy((char*)lds_wave_base + 16 * lane, gsrc, 16);
+}
+static inline void lpc_glds_wait() {}
 
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32); }
 
@@ -77,6 +82,7 @@ static inline lpcError_t device_count(int* n) { *n = 1; return 0; }
 static inline lpcError_t current_device(int* d) { *d = 0; return 0; }
 static inline lpcError_t set_max_dyn_smem(const void*, size_t) { return 0; }
 static inline const char* backend_name() { return "simt-emu(test-only)"; }
+static inline int cu_count() { return 2; }
 }  // namespace rt
 
 #define LPC_LAUNCH(kernel, grid, block, smem, stream, ...) \
@@ -102,6 +108,23 @@ static __device__ __forceinline__ int lpc_tid_below(unsigned nt) {
 }
 #define LPC_TID(nt) lpc_tid_below((unsigned)(nt))
 
+// LDS-DMA: every active lane of the wave copies 16 bytes from ITS global address `gsrc` to LDS at the WAVE-UNIFORM byte
+// address of `lds_wave_base` + 16 * lane (global_load_lds_dwordx4: no VGPR destination, counted by vmcnt).  Written as
+// inline assembly so that the compiler does not know about the pending LDS write: a `__syncthreads()` then stays a bare
+// s_barrier and the copy stays in flight across the barriers of the transform that runs meanwhile (with the builtin the
+// fence of every barrier would drain it).  The price: the data is ordered for a reader only by lpc_glds_wait() in the
+// ISSUING wave followed by a barrier the reader has passed.  M0 (the LDS base) is saved and restored in the statement.
+// No "memory" clobber: loop-invariant table loads may move across it; the barriers around it order the LDS accesses.
+static __device__ __forceinline__ void lpc_glds16(const void* gsrc, void* lds_wave_base, int /*lane*/) {
+  const unsigned dst = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(dst));
+}
+static __device__ __forceinline__ void lpc_glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
 typedef hipStream_t lpcStream_t;
 typedef hipError_t lpcError_t;
 #define lpcSuccess hipSuccess
@@ -125,6 +148,11 @@ static inline lpcError_t set_max_dyn_smem(const void* fn, size_t bytes) {
   return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
 }
 static inline const char* backend_name() { return "hip-gfx950"; }
+static inline int cu_count() {     // compute units of the current device (persistent kernels size their grids by it)
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) return 256;
+  return n;
+}
 }  // namespace rt
 
 #define LPC_LAUNCH(kernel, grid, block, smem, stream, ...) \

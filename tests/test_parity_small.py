@@ -862,3 +862,40 @@ def test_single_launch_columns(backend, monkeypatch, shape, seq_t):
     o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
     o.set_data(y)
     assert rel(rec.apply(n_iter=8, disp_iter=None), o.apply(8)) <= 5e-6, info
+
+
+@pytest.mark.parametrize("shape,rad", [((20, 64, 3), "8.8"), ((12, 128, 1), "16.8"), ((9, 256, 3), "16.16")])
+def test_prefetching_inverse_rows(backend, monkeypatch, shape, rad):
+    """option row_pf: ADMM's inverse rows as persistent workgroups with the next half-spectrum row in flight by LDS-DMA
+    and the stage twiddles in LDS (k_rinv_half_pf).  Same arithmetic in the same order as k_rinv_half: the result is
+    BIT-identical to the one-workgroup-per-row kernel, and both agree with the float64 oracle.  More rows than
+    workgroups (every workgroup walks several rows), sensor-window structure (H V rows skipped outside it) included."""
+    H, W, C = shape
+    rng = np.random.default_rng(W)
+    psf = orc.synthetic_psf(1, H, W, C, seed=3)
+    y = rng.random((H, W, C), dtype=np.float32)
+    outs = []
+    for pf in (0, 1):
+        engine_opts(monkeypatch, rows_half=1, row_rad=rad, row_pf=pf, jit_min_points=0)
+        rec = lpa.ADMM(torch.from_numpy(psf).to(backend.device), tau=2e-6, mu2=1e-4)
+        info = rec._handle.plan_info()
+        assert "half-length %d [static %s" % (rec._padded_shape[2] // 2, rad) in info, info
+        rec.set_data(torch.from_numpy(y).to(backend.device))
+        outs.append(rec.apply(n_iter=7, disp_iter=None).detach().cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])
+    o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
+    o.set_data(y)
+    assert rel(outs[1], o.apply(7)) <= 5e-6
+
+
+@pytest.mark.parametrize("pad", [8, 36])
+def test_padded_real_row_pitch(backend, monkeypatch, pad):
+    """option rpitch_pad: the padded real planes (V, H V, the duals, r_sp) with a row pitch wider than the padded frame
+    (a tuning experiment: rows of 2^k bytes -- no HBM channel effect was found, profiles/r04_notes.md).  Every kernel
+    addresses those planes through PlaneGeom::rpitch: same goldens on both row schemes and on the run-time plans."""
+    for half in (0, 1):
+        engine_opts(monkeypatch, rpitch_pad=pad, rows_half=half, jit_min_points=0)
+        test_admm_matches_reference_golden(backend, "admm_24x32x3_tv")
+        test_convolver_golden(backend, "a")
+    engine_opts(monkeypatch, rpitch_pad=pad)
+    test_admm_matches_reference_golden(backend, "admm_24x32x3_tv")
