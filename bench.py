@@ -16,8 +16,10 @@ path would do when a batch is sharded over the node.  value = total iterations o
 max-over-ranks wall time.
 
 Rank 0 prints ONE JSON line.  On top of the driver's contract it carries:
-  roofline      ADMM prox / dual-update kernel (the TV / W half of the image-domain work, 9R per launch: reads V,
-                V_old, eta0, eta1, rho, writes eta0, eta1, rho, r_sp -- DESIGN.md section 4; the X half rides in the
+  roofline      ADMM prox / dual-update kernel (the TV / W half of the image-domain work, 8R per launch: reads V,
+                eta0, eta1, rho, writes eta0, eta1, rho, r_sp -- the duals travel half-applied between the iterations
+                of a call, so V_old is read by the first launch of a call only (9R: 1 launch in 100; the figure is
+                priced at 8R) -- DESIGN.md section 4; the X half rides in the
                 forward row kernel, listed under `kernels`) / mean launch duration from HIP events recorded inside the
                 timed region; `traffic` = HBM bytes per launch from separate rocprofv3 --pmc passes (profiles/traffic.json)
                 (only this kernel's launches are bracketed there: events around all of them cost 1.4-3.4 % of the rate)
