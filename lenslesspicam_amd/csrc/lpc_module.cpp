@@ -88,6 +88,19 @@ static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
 #else   // gradient-descent family
 static int m_gd_rows_mid(Engine* e) {
   const PlaneGeom& g = e->g;
+#ifndef LPC_DOUBLE
+  if constexpr (LdsTw<RowP>::ok(RNT)) {
+    // persistent workgroups, the next row in flight (k_rinv_gd_mid_half_pf); 8-byte accesses to y need the pair geometry
+    if (e->opt.row_pf > 0 && ((g.sw | g.W | (g.Wp / 2)) & 1) == 0) {
+      const size_t smem = ((kRowSmem + 15) / 16) * 16 + (size_t)(RowP::n + 8 + LdsTw<RowP>::size) * sizeof(real2);
+      const int total = e->opt.row_pf >= 16 ? e->opt.row_pf : e->opt.row_pf * rt::cu_count();
+      const int gx = std::max(1, std::min(g.H, total / std::max(1, e->P)));
+      return launch_k(e, LPC_K_ROW_INV, k_rinv_gd_mid_half_pf<RNT, REM, RSK, RowPA>, dim3(gx, e->P), RNT, smem,
+                      geom_rev(e, e->opt.gd_rev & 1), row_arg(e), e->planW.tw, (const real2*)e->S, e->S2,
+                      (const real*)e->Y, g.H);
+    }
+  }
+#endif
   return launch_k(e, LPC_K_ROW_INV, k_rinv_gd_mid_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem,
                   geom_rev(e, e->opt.gd_rev & 1),
                   row_arg(e), e->planW.tw, (const real2*)e->S, e->S2, (const real*)e->Y);

@@ -59,7 +59,6 @@ static inline void lpc_glds16(const void* gsrc, void* lds_wave_base, int lane) {
   std::memcpy((char*)lds_wave_base + 16 * lane, gsrc, 16);
 }
 static inline void lpc_glds_wait() {}
-
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32); }
 
 typedef void* lpcStream_t;
@@ -124,7 +123,6 @@ static __device__ __forceinline__ void lpc_glds16(const void* gsrc, void* lds_wa
                : "v"(gsrc), "s"(dst));
 }
 static __device__ __forceinline__ void lpc_glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-
 typedef hipStream_t lpcStream_t;
 typedef hipError_t lpcError_t;
 #define lpcSuccess hipSuccess

@@ -293,6 +293,11 @@ template <class P, int NT, bool INV, int SKEW, int... I>
 static __device__ __forceinline__ void sfft_stages_h(real2* s, const LdsTw<P>& h, int tid, std::integer_sequence<int, I...>) {
   (sfft_stage_h<P, I, NT, INV, SKEW>(s, h, tid), ...);
 }
+// stages 1 .. (behind a first stage the caller ran itself)
+template <class P, int NT, bool INV, int SKEW, int... I>
+static __device__ __forceinline__ void sfft_stages_h1(real2* s, const LdsTw<P>& h, int tid, std::integer_sequence<int, I...>) {
+  (sfft_stage_h<P, 1 + I, NT, INV, SKEW>(s, h, tid), ...);
+}
 // last stage into the drain, twiddles from LDS
 template <class P, int NT, bool INV, int SKEW, class Dst>
 static __device__ __forceinline__ void sfft_last_fused_h(real2* s, const LdsTw<P>& h, int tid, Dst& dst) {

@@ -899,3 +899,27 @@ def test_padded_real_row_pitch(backend, monkeypatch, pad):
         test_convolver_golden(backend, "a")
     engine_opts(monkeypatch, rpitch_pad=pad)
     test_admm_matches_reference_golden(backend, "admm_24x32x3_tv")
+
+
+@pytest.mark.parametrize("shape,rad", [((20, 64, 3), "8.8"), ((11, 128, 1), "16.8"), ((9, 256, 3), "16.16")])
+def test_prefetching_residual_rows(backend, monkeypatch, shape, rad):
+    """option row_pf on the gradient-descent family: the residual rows (irfft row -> crop, - y, re-pad -> rfft row) as
+    persistent workgroups with the next half-spectrum row in flight by LDS-DMA and the stage twiddles in LDS
+    (k_rinv_gd_mid_half_pf).  Same arithmetic in the same order as k_rinv_gd_mid_half: BIT-identical iterates; both agree
+    with the float64 oracle.  More rows than workgroups on the emulator (one workgroup walks all rows of a plane)."""
+    H, W, C = shape
+    rng = np.random.default_rng(W + 1)
+    psf = orc.synthetic_psf(1, H, W, C, seed=5)
+    y = rng.random((H, W, C), dtype=np.float32)
+    outs = []
+    for pf in (0, 1):
+        engine_opts(monkeypatch, row_rad=rad, row_pf=pf, jit_min_points=0)
+        rec = lpa.FISTA(torch.from_numpy(psf).to(backend.device))
+        info = rec._handle.plan_info()
+        assert "half-length %d [static %s" % (rec._padded_shape[2] // 2, rad) in info, info
+        rec.set_data(torch.from_numpy(y).to(backend.device))
+        outs.append(rec.apply(n_iter=9, disp_iter=None).detach().cpu().numpy().copy())
+    assert np.array_equal(outs[0], outs[1])
+    o = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
+    o.set_data(y)
+    assert rel(outs[1], o.apply(9)) <= 5e-6
