@@ -107,8 +107,9 @@ typedef struct lpc_config {
  *                      xor layout (measured: no faster);  row_nt=N  lanes per row workgroup
  *   module_max=N module_loaded_max=N               plan-module files kept per directory this library writes to (256, least
  *                      recently used removed first); modules kept loaded once no handle uses them (64)
- *   row_pf=N           ADMM inverse rows (half-length, float32, radices 8 / 16) as N persistent workgroups per CU with
- *                      the next row in flight by LDS-DMA (N >= 16: workgroups in all); measured: no faster (default 0)
+ *   row_pf=N           ADMM inverse rows and the gradient-descent family's residual rows (half-length, float32, radices
+ *                      8 / 16) as N persistent workgroups per CU with the next row in flight by LDS-DMA (N >= 16:
+ *                      workgroups in all); measured: no faster (default 0)
  *   rpitch_pad=N       floats added to the row pitch of the padded real planes (measured: no faster; default 0)
  *   no_r2=1 no_skew=1 gd_no_fuse_fwd=1              run-time row plans without the folded radix-2 stage / the LDS skew;
  *                      gradient-descent update without the next iteration's forward rows

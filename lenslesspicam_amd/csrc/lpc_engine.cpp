@@ -359,6 +359,14 @@ static void choose_plan(Engine* e, bool allow_static) {
     // one spectrum at a time: 6.10.9 inside a 128-register budget = TWO workgroups per CU overlapping one another's
     // loads and barriers -- 0.650 ms per launch at 64 frames against 0.84 ms for 30.18 and 0.95 ms for 6.6.5.3
     if (n == 540) rad = seq ? std::vector<int>{6, 10, 9} : std::vector<int>{30, 18};
+    // A launch of fewer workgroups than the chip holds at once (one DiffuserCam frame: 183 tiles on 256 CUs) lasts as
+    // long as ONE workgroup takes: twice the lanes on half the points each shorten that chain -- 540 x 16 points on 1024
+    // lanes as 6.10.9 (every stage has >= 864 butterflies; 30.18 has 288 / 480): C1's middle 21.2 -> 19.1 us, the
+    // 5-iteration call 0.243 -> 0.234 ms (profiles/r04t_ab_c1.log; 30.18 on 1024 lanes 19.8 us, 768 lanes 19.6 us).
+    // Only while every workgroup has a CU of its own (256 on an MI355X): two frames = 366 tiles are 6 % SLOWER that way
+    // (0.370 -> 0.392 ms, r04t_ab_c1c.log).
+    const bool one_wave_of_tiles = !seq && !single && e->N1 == 1 && (long)e->P * ((g.Wc + T - 1) / T) <= 256 && n * 2 * T > 8192;
+    if (one_wave_of_tiles && n == 540) rad = {6, 10, 9};
     if (single) {                  // long columns: fat stages (plan_radices stops at radix 8)
       rad.clear();
       int r = n;
@@ -370,6 +378,7 @@ static void choose_plan(Engine* e, bool allow_static) {
     const int pts = n * (seq ? T : 2 * T);
     int nt = pts <= 4096 ? 256 : (pts <= 9216 ? 512 : 1024);
     if (seq) nt = pts <= 18 * 256 ? 256 : (pts <= 18 * 512 ? 512 : 1024);
+    if (one_wave_of_tiles) nt = 1024;
     if (o.mid_nt >= 64 && o.mid_nt <= 1024 && o.mid_nt % 64 == 0) nt = o.mid_nt;
     set_static_fft(sp.mid, n, rad, T, nt, (pts + nt - 1) / nt);
     if (sp.mid.n && sp.mid.em <= 18) {
