@@ -358,7 +358,9 @@ static void choose_plan(Engine* e, bool allow_static) {
     // 540 = 30.18 side by side (two fat register butterflies, one LDS trip; 184 registers, one workgroup per CU);
     // one spectrum at a time: 6.10.9 inside a 128-register budget = TWO workgroups per CU overlapping one another's
     // loads and barriers -- 0.650 ms per launch at 64 frames against 0.84 ms for 30.18 and 0.95 ms for 6.6.5.3
-    if (n == 540) rad = seq ? std::vector<int>{6, 10, 9} : std::vector<int>{30, 18};
+    // (on 512 lanes the order 10.6.9 is 2 % faster than 6.10.9 -- 0.453 vs 0.464 ms at 64 frames, two instances each,
+    // profiles/r04u_ab_shard5.log; 9.10.6 0.479, 10.9.6 0.482, 6.9.10 0.498)
+    if (n == 540) rad = seq ? std::vector<int>{10, 6, 9} : std::vector<int>{30, 18};
     // A launch of fewer workgroups than the chip holds at once (one DiffuserCam frame: 183 tiles on 256 CUs) lasts as
     // long as ONE workgroup takes: twice the lanes on half the points each shorten that chain -- 540 x 16 points on 1024
     // lanes as 6.10.9 (every stage has >= 864 butterflies; 30.18 has 288 / 480): C1's middle 21.2 -> 19.1 us, the
@@ -377,7 +379,12 @@ static void choose_plan(Engine* e, bool allow_static) {
     override_radices(o.mid_rad, n, rad);
     const int pts = n * (seq ? T : 2 * T);
     int nt = pts <= 4096 ? 256 : (pts <= 9216 ? 512 : 1024);
-    if (seq) nt = pts <= 18 * 256 ? 256 : (pts <= 18 * 512 ? 512 : 1024);
+    // one spectrum at a time: 8 columns x 540 points on 512 lanes x 9 points (round 3: 256 x 17) -- the middle of a batch
+    // of 8 / 16 / 32 / 64 frames 79.6 -> 75.7 / 140 -> 136 / 262 -> 255 / 505 -> 491 us, the 8-frame shard's 20-iteration
+    // call 4.55 -> 4.44 ms (profiles/r04u_ab_shard2.log; 384 lanes 103 us, 1024 lanes 77.9 us, 16 columns x 1024: 84 us);
+    // three instances of each at 64 / 8 frames (r04u_ab_shard4.log): 256 lanes 0.499 ms / 78.5 us, 512 lanes 0.493 / 74.2,
+    // 512 lanes inside 64 VGPRs 0.464 / 70.6
+    if (seq) nt = pts <= 9 * 256 ? 256 : (pts <= 18 * 512 ? 512 : 1024);
     if (one_wave_of_tiles) nt = 1024;
     if (o.mid_nt >= 64 && o.mid_nt <= 1024 && o.mid_nt % 64 == 0) nt = o.mid_nt;
     set_static_fft(sp.mid, n, rad, T, nt, (pts + nt - 1) / nt);
@@ -391,7 +398,11 @@ static void choose_plan(Engine* e, bool allow_static) {
         sp.mid_pre = o.mid_pre >= 0 ? (o.mid_pre ? 1 : 0) : ((long)e->P * ((g.Wc + T - 1) / T) >= 4096 && !single ? 1 : 0);
         const size_t lds = (size_t)n * (T + (sp.mid_twg ? 0 : 1)) * sizeof(real2);
         const int wgs = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
-        sp.mid_minw = std::min(4, std::max(1, (wgs * nt + 255) / 256));
+        // (512 lanes: 8 = a 64-VGPR allocation, four workgroups per CU as the LDS allows -- 68 registers without the
+        // bound, i.e. three; the middle of 64 / 8 frames 0.493 -> 0.464 ms / 74.2 -> 70.6 us, three instances each,
+        // profiles/r04u_ab_shard4.log; 8-12 bytes of scratch)
+        sp.mid_minw = std::min(8, std::max(1, (wgs * nt + 255) / 256));
+        if (o.mid_minw > 0) sp.mid_minw = std::min(8, o.mid_minw);
       }
     } else {
       sp.mid = StaticFft{};

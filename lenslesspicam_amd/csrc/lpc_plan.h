@@ -131,6 +131,7 @@ struct EngineOpts {
                               // columns per workgroup, one spectrum at a time (k_cols_mid_admm_seq) -- instead of pass A +
                               // middle + inverse pass A, whenever a two-column tile of whole columns fits LDS.  -1: by size
   int mid_twg = 0;            // sequential middle: twiddles from global memory (no LDS copy: more workgroups per CU)
+  int mid_minw = 0;           // sequential middle: waves per SIMD its register allocation must allow (tuning; 0: 4 at most)
   int mid_pre = -1;           // sequential middle: load both tiles before the first transform (-1: default of the plan)
   int seq_tiles_first = 0;    // sequential middle: workgroups handed out column tiles fastest instead of frames fastest
   int seq_pair = 0;           // sequential middle, 64-byte tile rows: the two tiles of a cache line 8 blocks apart on one XCD (measured: no gain)
@@ -209,6 +210,7 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "col_single") o.col_single = (int)iv;
       else if (k == "mid_twg") o.mid_twg = (int)iv;
       else if (k == "mid_pre") o.mid_pre = (int)iv;
+      else if (k == "mid_minw") o.mid_minw = (int)iv;
       else if (k == "g_plane") o.g_plane = (int)iv;
       else if (k == "mid_swz") o.mid_swz = (int)iv;
       else if (k == "hv_full") o.hv_full = (int)iv;
