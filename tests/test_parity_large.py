@@ -352,3 +352,37 @@ def test_modules_unload_on_the_gpu(tmp_path):
     again.set_data(a[1])
     assert torch.equal(again.apply(n_iter=3, disp_iter=None), a[2])
     assert torch.equal(b[3].apply(n_iter=3, disp_iter=None), b[2])
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_random_batches_through_the_sequential_middle(seed):
+    """Batches of small frames of random shape (single-pass columns of any 5-smooth length, 8 image columns per tile on
+    256 / 512 / 1024 lanes, the 64-VGPR launch bound, loads up front for deep launches): the one-spectrum-at-a-time middle
+    of a batch (k_cols_mid_admm_seq on the shape's own radices, compiled here on first use) against the per-frame float64
+    oracle, and batch == single frames bit for bit on the same launch plan."""
+    torch.set_num_threads(16)
+    rng = np.random.default_rng(2000 + seed)
+    # 512 < padded rows <= 1024 and enough (frame, plane, tile) workgroups: the shapes the engine gives that middle
+    H, W = int(rng.integers(258, 500)), int(rng.integers(180, 420))
+    C, B = 3, int(rng.choice([16, 24, 40]))
+    psf = orc.synthetic_psf(1, H, W, C, seed=seed)
+    frames = rng.random((B, H, W, C), dtype=np.float32)
+    kw = dict(tau=2e-6, mu2=1e-4)
+    rec = lpa.ADMM(torch.from_numpy(psf).cuda(), **kw)
+    rec.set_data(torch.from_numpy(frames).cuda()[:, None])
+    full = rec.apply_batch(n_iter=7)
+    info = rec._handle.plan_info()
+    assert "one spectrum at a time" in info, (H, W, C, B, info)
+    for b in (0, B // 2, B - 1):
+        o = orc.ADMMOracle(psf, dtype=torch.float64, **kw)
+        o.set_data(frames[b])
+        assert rel(full[b], o.apply(7)) <= 1e-5, (H, W, C, B, b, info)
+    if "one spectrum at a time" in info:
+        opts = {"mid_seq": 1, "mid_pre": int(info.rstrip().endswith("p"))}
+        if "128 threads" in info.split("columns:")[0]:
+            opts["prow_nt128"] = 1
+        single = lpa.ADMM(torch.from_numpy(psf).cuda(), engine_options=opts, **kw)
+        if single._handle.plan_info().split("plan module")[1] == info.split("plan module")[1]:
+            for b in (0, B - 1):
+                single.set_data(torch.from_numpy(frames[b]).cuda())
+                assert torch.equal(single.apply(n_iter=7, disp_iter=None), full[b]), (H, W, C, B, b, info)
