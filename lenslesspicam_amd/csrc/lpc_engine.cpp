@@ -475,6 +475,9 @@ static int setup_geometry(Engine* e) {
   // forward pass A (any plan) or, for single-pass columns, by the module's fused middle (option hv_full: off)
   e->hv_skip = e->xi_window && !e->opt.hv_full && e->mod->admm_rows_inv && (e->N1 > 1 || e->mod->admm_mid);
   e->gd_fuse_fwd = c.algo >= LPC_ALGO_GD && e->mod && e->mod->gd_rows_update_fwd && !e->opt.gd_no_fuse_fwd;
+  // the second form of the fused row kernels: 8-byte accesses to y / x need an even window offset and frame width
+  e->gd_v2 = c.algo >= LPC_ALGO_GD && e->mod && e->mod->gd_v2 && e->opt.gd_v2 != 0 && e->opt.row_pf <= 0 &&
+             ((g.sw | g.W) & 1) == 0 && g.W >= 2;
   if (e->opt.gd_rev < 0)     // EngineOpts::gd_rev
     // all three (the row kernels and the register middle alternate with the forward-walking pass A, so every kernel
     // starts where its predecessor finished): 12 MP FISTA 75.4 / 74.1 / 73.8 -> 74.5 / 73.0 / 72.8 ms per 40 iterations on
@@ -1507,6 +1510,7 @@ int lpc_plan_info(lpc_handle e, char* buf, size_t n) {
   s += e->rows_half ? "; rows: half-length " + std::to_string(g.Wp / 2) : "; rows: paired " + std::to_string(g.Wp);
   const bool rows_static = e->mod && sp.row_kind && (e->rows_half || e->cfg.algo == LPC_ALGO_ADMM);
   if (rows_static) s += " [static " + radstr(sp.row) + ", " + std::to_string(sp.row.nt) + " threads]";
+  if (e->gd_v2) s += " (fused rows: second form, " + std::to_string(sp.row.n / sp.row.rad[0]) + " lanes)";
   s += "; columns: " + (e->N1 > 1 ? std::to_string(e->N1) + " x " + std::to_string(e->N2) + " split" : std::string("single pass ") + std::to_string(e->N2));
   s += ", T = " + std::to_string(e->T);
   if (e->mod && sp.passA.n) s += ", pass A [static " + radstr(sp.passA) + ", T = " + std::to_string(sp.passA.T) + "]";

@@ -145,6 +145,7 @@ struct lpc_engine {
   bool has_init = false, psf_set = false, data_set = false, first = true;
   bool gd_fwd_done = false;    // the row spectra of H x's input are already in S (written by the fused update kernel)
   bool gd_fuse_fwd = false;    // gradient-descent family: update kernel + next forward rows in one launch
+  bool gd_v2 = false;          // ... its two fused row kernels in their second form (lpc_gd_v2_kernels.h; option gd_v2)
   bool split_pending = false;  // lpc_iterate_begin ran, lpc_iterate_end has not yet
   // plug-and-play ADMM (lpc_admm_pnp_begin / _end): explicit state in the arrays the fused path uses for the TV duals
   //   eta0[0] = eta, eta1[0] = U, eta0[1] = X, eta1[1] = W   (all image-shaped)
@@ -255,6 +256,7 @@ struct LpcModule {
   int (*gd_rows_update_fwd)(Engine*, const GdScalars*, const real* alpha);
   int (*cols_passA)(Engine*, const ColPass*, real2* S, int nplanes, int inverse, int kid);
   int (*admm_mid)(Engine*, const ColPass*, const AdmmScalars*, real sb_outside_scale);
+  int gd_v2;      // the module holds k_gd_resid_v2 / k_gd_update_fwd_v2 for its row plan (lpc_gd_v2_kernels.h)
 };
 // lpc_jit.cpp: the module of `spec` -- from the process cache, from disk, or (allow_compile) compiled now; null + `why`
 const LpcModule* get_plan_module(const PlanSpec& spec, const EngineOpts& opt, bool allow_compile, std::string* why);

@@ -72,12 +72,13 @@ struct GdScalars {
 // KIND >= 0: the variant is known at compile time (the half-row kernels branch on p.kind ONCE and run a straight-line
 // body: with the uniform branches inside every element the loads of x and of the auxiliary state could not be issued
 // ahead of one another -- 5 700 static SALU instructions in the update kernel); KIND < 0: read p.kind.
-template <int KIND = -1>
+// SPLIT: 0 / 1 when the caller knows p.split at compile time (the update kernels with fused forward rows never run split)
+template <int KIND = -1, int SPLIT = -1>
 static __device__ __forceinline__ real gd_update_val(real x, real pp, real gr, real al, const GdScalars& p,
                                                       real& aux_out) {
   const int kind = KIND >= 0 ? KIND : p.kind;
   aux_out = pp;
-  if (p.split) {   // everything up to `self._form_image()` of the three _update()s; k_gd_post finishes
+  if (SPLIT >= 0 ? SPLIT != 0 : p.split != 0) {   // everything up to `self._form_image()` of the three _update()s; k_gd_post finishes
     if (kind == 1) {
       const real pn = p.mu * pp - al * gr;
       aux_out = pn;
@@ -100,11 +101,12 @@ static __device__ __forceinline__ real gd_update_val(real x, real pp, real gr, r
   aux_out = xk;
   return xk + p.coef * (xk - xp);
 }
-template <int KIND = -1>
+template <int KIND = -1, int SPLIT = -1>
 static __device__ __forceinline__ void gd_aux_access(const GdScalars& p, bool& rd, bool& wr) {
   const int kind = KIND >= 0 ? KIND : p.kind;
-  rd = kind == 1 || (kind == 2 && !p.split && !p.first);
-  wr = kind == 1 || (kind == 2 && (!p.split || p.first));
+  const bool split = SPLIT >= 0 ? SPLIT != 0 : p.split != 0;
+  rd = kind == 1 || (kind == 2 && !split && !p.first);
+  wr = kind == 1 || (kind == 2 && (!split || p.first));
 }
 template <int KIND = -1>
 static __device__ __forceinline__ real gd_update_one(real* LPC_RESTRICT X, real* LPC_RESTRICT AUX, long o,

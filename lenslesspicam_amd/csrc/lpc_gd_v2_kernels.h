@@ -1,0 +1,253 @@
+// lpc_gd_v2_kernels.h -- the gradient-descent family's two fused row kernels, second form (round 5; compile-time plans,
+// one real row per half-length transform, float32).
+//
+//   k_gd_resid_v2        spectrum row -> irfft -> shift + crop -> - y -> re-pad -> rfft -> spectrum row
+//   k_gd_update_fwd_v2   spectrum row -> irfft -> shift + crop = gradient -> fused update of x (+ momentum, projection)
+//                        -> the updated row, re-padded -> rfft -> spectrum row of the next iteration's H x
+// (gd.py:128-134,183-188,235-241; rfft_convolve.py:145-170,190-216 -- the same dataflow as k_rinv_gd_mid_half /
+// k_rinv_gd_update_fwd_half in lpc_gd_kernels.h, which stay the kernels of every other geometry.)
+//
+// What the first form spent its time on, read off its assembly (profiles/r05_notes.md section 1): the source functor of
+// the forward transform's first stage sat behind per-element branches, so each of a lane's 16 loads of y (of x and the
+// auxiliary state in the update kernel) was followed by `s_waitcnt vmcnt(0)` -- sixteen HBM latencies in a row on the
+// critical path of every row; 1371 of 2258 VALU instructions were index arithmetic; a 64-bit scalar division (the data
+// plane of a state plane) ran between the two transforms; and half of the 512 lanes had no butterfly in any stage.
+//
+// Here a workgroup is M / R lanes (4096-point rows: 256 lanes x 16 points, 128 VGPRs, four workgroups per CU = the same
+// sixteen working waves per CU as before without the sixteen idle ones) and every lane owns butterfly j of every stage:
+//   * the first inverse stage takes its inputs straight from global memory: lane j needs Z[k], k = j + (M/R) m, and the
+//     Hermitian tangling needs X[k] and X[M - k] -- both are loaded by the lane itself (the mirror is the coalesced
+//     descending run of lane M/R - j; every spectrum element is read by two lanes of the workgroup, once from HBM);
+//   * the LAST inverse stage leaves lane j with samples (pairs) j + (M/R) m -- and the ifftshift by Wp / 2 samples = M / 2
+//     pairs = R / 2 butterfly strides maps pair (j, m) to (j, m + R/2 mod R): the lane that produced a sample is the lane
+//     whose first FORWARD butterfly consumes it.  Residual / update happen in registers; the tile makes no trip through
+//     LDS between the two transforms (one write, one read and two barriers less per row);
+//   * every global load of a phase is issued before the first use (unconditional, clamped addresses): y right after the
+//     first inverse stage, so that two stages hide its latency; x / aux in front of the last inverse stage;
+//   * M is a compile-time constant (the plan), so is everything derived from it; the data plane comes from two
+//     reciprocal multiplications (FastDiv) prepared by the launcher.
+// LDS trips per row: 5 writes + 5 reads of the tile instead of 7 + 7; barriers 9 instead of 13.
+// Needs: every radix of the plan equal (R = 8 | 16: 4096 = 16.16.16, 512 = 8.8.8), M / R a multiple of 64, and the
+// `pair` geometry (window offset and frame width even: 8-byte accesses to y / x) -- the launcher checks.
+#pragma once
+#include "lpc_gd_kernels.h"
+
+#ifndef LPC_DOUBLE
+
+template <class P>
+struct GdV2 {
+  static constexpr int M = P::n, R = P::radix(0), NB = P::n / P::radix(0), L = P::nst;
+  static constexpr bool uniform() {
+    for (int st = 0; st < P::nst; ++st)
+      if (P::radix(st) != P::radix(0)) return false;
+    return true;
+  }
+  static constexpr bool ok = uniform() && (R == 8 || R == 16) && L >= 2 && NB % 64 == 0 && NB <= 1024;
+};
+
+// X[k], X[M - k] of one half-spectrum row -> Z (irfft semantics, see tangle_half_load) -> first inverse stage
+// (radix R, no twiddles) -> tile.  No trailing barrier.
+template <class P, int SK>
+static __device__ __forceinline__ void v2_load_tangle_first(real2* s, const real2* LPC_RESTRICT in,
+                                                            const real2* LPC_RESTRICT twW, int j) {
+  constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB;
+  real2 zk[R], zm[R], tw[R / 2];
+#pragma unroll
+  for (int m = 0; m < R; ++m) zk[m] = in[j + NB * m];
+#pragma unroll
+  for (int m = 0; m < R; ++m) zm[m] = in[M - j - NB * m];
+#pragma unroll
+  for (int m = 0; m < R / 2; ++m) tw[m] = twW[j + NB * m];
+  real2 v[R];
+#pragma unroll
+  for (int m = 0; m < R; ++m) {
+    // (w^(k + M/2) = -i w^k, w = exp(-2 pi i / Wp): the upper half of a lane's twiddles is a swap away from the lower)
+    const real2 t = m < R / 2 ? tw[m] : cmul_mi(tw[m - R / 2]);
+    real2 a = zk[m], b = zm[m];
+    if (m == 0) {   // k == 0: the imaginary parts of the DC and Nyquist bins are ignored
+      a.y = j == 0 ? (real)0. : a.y;
+      b.y = j == 0 ? (real)0. : b.y;
+    }
+    const real2 e = make_real2(a.x + b.x, a.y - b.y);
+    const real2 d = make_real2(a.x - b.x, a.y + b.y);
+    const real2 od = cmul_conj(d, t);
+    v[m] = make_real2(e.x - od.y, e.y + od.x);
+  }
+  Dft<R, true>::run(v);
+#pragma unroll
+  for (int m = 0; m < R; ++m) s[lds_slot<SK>(j * R + m)] = v[m];
+}
+
+// last stage of a transform (radix R, NS = NB: butterfly j, twiddles w^(j m)); inputs from the tile, outputs
+// (elements j + NB m) stay in v[]
+template <class P, int SK, bool INV>
+static __device__ __forceinline__ void v2_last_stage(const real2* s, const real2* LPC_RESTRICT tw, int j, real2* v) {
+  constexpr int R = GdV2<P>::R, NB = GdV2<P>::NB;
+#pragma unroll
+  for (int m = 0; m < R; ++m) v[m] = s[lds_slot<SK>(j + NB * m)];
+  twiddle_mul<R, INV>(v, tw, j);
+  Dft<R, INV>::run(v);
+}
+
+// first forward stage (radix R, no twiddles) from registers -> tile; trailing barrier
+template <class P, int SK>
+static __device__ __forceinline__ void v2_first_fwd(real2* s, int j, real2* r) {
+  constexpr int R = GdV2<P>::R;
+  Dft<R, false>::run(r);
+#pragma unroll
+  for (int m = 0; m < R; ++m) s[lds_slot<SK>(j * R + m)] = r[m];
+  __syncthreads();
+}
+
+// X = FFT_M(z) (elements j + NB m in x[]) -> half spectrum of the real row (see untangle_half_store) -> o[0 .. M].
+// Precondition: every lane is done reading the tile.
+template <class P, int SK>
+static __device__ __forceinline__ void v2_untangle_store(real2* s, const real2* LPC_RESTRICT twW, int j, const real2* x,
+                                                         real2* LPC_RESTRICT o) {
+  constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB;
+  // (the addresses below are those of the tangling at the top of the kernel: recomputed from an opaque copy of the lane
+  // index, a few integer instructions, instead of kept alive -- i.e. spilled -- across both transforms)
+  j = lpc_opaque(j);
+  real2 tw[R / 2];
+#pragma unroll
+  for (int m = 0; m < R / 2; ++m) tw[m] = twW[j + NB * m];
+#pragma unroll
+  for (int m = 0; m < R; ++m) s[lds_slot<SK>(j + NB * m)] = x[m];
+  __syncthreads();
+  real2 xm[R];
+#pragma unroll
+  for (int m = 0; m < R; ++m) {
+    const int km = (m == 0 && j == 0) ? 0 : M - j - NB * m;    // the DC bin pairs with itself
+    xm[m] = s[lds_slot<SK>(km)];
+  }
+#pragma unroll
+  for (int m = 0; m < R; ++m) {
+    const real2 zk = x[m], zm = xm[m];
+    const real ex = (real)0.5 * (zk.x + zm.x), ey = (real)0.5 * (zk.y - zm.y);
+    const real2 od = make_real2((real)0.5 * (zk.y + zm.y), (real)-0.5 * (zk.x - zm.x));
+    const real2 wo = cmul(m < R / 2 ? tw[m] : cmul_mi(tw[m - R / 2]), od);
+    o[j + NB * m] = make_real2(ex + wo.x, ey + wo.y);
+    if (m == 0 && j == 0) o[M] = make_real2(ex - wo.x, wo.y - ey);    // the Nyquist bin
+  }
+}
+
+template <class P, int NT, int SK, bool INV, int... I>
+static __device__ __forceinline__ void v2_mid_stages(real2* s, const real2* LPC_RESTRICT tw, int tid,
+                                                     std::integer_sequence<int, I...>) {
+  (sfft_stage<P, 1 + I, NT, 1, INV, SK>(s, tw, tid), ...);
+}
+
+// data plane of state plane pl: (pl / DC) * C + pl % C
+static __device__ __forceinline__ int v2_data_plane(unsigned pl, FastDiv fdc, FastDiv fc, int C) {
+  const unsigned q = fd_div(pl, fdc);
+  return (int)(q * (unsigned)C + (pl - fd_div(pl, fc) * fc.d));
+}
+
+template <int NT, int SK, class PL>
+__global__ __launch_bounds__(NT, 4) void k_gd_resid_v2(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
+                                                               const real2* LPC_RESTRICT Sin,
+                                                               real2* LPC_RESTRICT Sout, const real* LPC_RESTRICT Y,
+                                                               FastDiv fdc, FastDiv fc) {
+  using P = typename PL::plan;
+  constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB, L = GdV2<P>::L;
+  static_assert(GdV2<P>::ok && NT == NB, "k_gd_resid_v2: one butterfly per lane and stage");
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int j = LPC_TID(NT), u = (int)LPC_BX(g);
+  const unsigned pl = LPC_BY(g);
+  const int sr = wrap_add(g.sh + u, g.Hp / 2, g.Hp);
+  v2_load_tangle_first<P, SK>(s, Sin + (long)pl * g.cplane + (long)sr * g.cpitch, twW, j);
+  __syncthreads();
+  // the measurement row, in flight across the remaining inverse stages: padded pair i = j + NB m covers columns
+  // 2 i - sw, 2 i - sw + 1 of the frame; outside the window the loads return zero (lpc_make_rsrc)
+  const lpc_rsrc yr = lpc_make_rsrc(Y + (long)v2_data_plane(pl, fdc, fc, g.C) * g.uplane + (long)u * g.W,
+                                    (unsigned)g.W * (unsigned)sizeof(real));
+  int off[R];
+#pragma unroll
+  for (int m = 0; m < R; ++m) off[m] = lpc_opaque((2 * (j + NB * m) - g.sw) * (int)sizeof(real));
+  real2 yy[R];
+#pragma unroll
+  for (int m = 0; m < R; ++m) yy[m] = lpc_buf_load2(yr, off[m]);
+  v2_mid_stages<P, NT, SK, true>(s, plan.tw, j, std::make_integer_sequence<int, L - 2>{});
+  real2 v[R], r[R];
+  v2_last_stage<P, SK, true>(s, plan.tw, j, v);
+  // conv pair (j, m) is pair (j, m + R/2 mod R) of the shifted row: residual inside the window, zero outside
+#pragma unroll
+  for (int m = 0; m < R; ++m) {
+    const real2 z = v[(m + R / 2) % R];
+    r[m] = (unsigned)off[m] < (unsigned)g.W * (unsigned)sizeof(real) ? make_real2(z.x - yy[m].x, z.y - yy[m].y)
+                                                                     : make_real2((real)0., (real)0.);
+  }
+  __syncthreads();
+  v2_first_fwd<P, SK>(s, j, r);
+  v2_mid_stages<P, NT, SK, false>(s, plan.tw, j, std::make_integer_sequence<int, L - 2>{});
+  v2_last_stage<P, SK, false>(s, plan.tw, j, v);
+  __syncthreads();
+  v2_untangle_store<P, SK>(s, twW, j, v, Sout + (long)pl * g.cplane + (long)(g.sh + u) * g.cpitch);
+}
+
+template <int NT, int SK, class PL>
+__global__ __launch_bounds__(NT, 4) void k_gd_update_fwd_v2(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
+                                                                    const real2* LPC_RESTRICT Sin,
+                                                                    real2* LPC_RESTRICT Sout, real* LPC_RESTRICT X,
+                                                                    real* LPC_RESTRICT AUX,
+                                                                    const real* LPC_RESTRICT alpha, GdScalars p,
+                                                                    FastDiv fc) {
+  using P = typename PL::plan;
+  constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB, L = GdV2<P>::L;
+  static_assert(GdV2<P>::ok && NT == NB, "k_gd_update_fwd_v2: one butterfly per lane and stage");
+  LPC_DYN_SMEM(smem);
+  real2* s = (real2*)smem;
+  const int j = LPC_TID(NT), u = (int)LPC_BX(g);
+  const unsigned pl = LPC_BY(g);
+  const int sr = wrap_add(g.sh + u, g.Hp / 2, g.Hp);
+  v2_load_tangle_first<P, SK>(s, Sin + (long)pl * g.cplane + (long)sr * g.cpitch, twW, j);
+  __syncthreads();
+  v2_mid_stages<P, NT, SK, true>(s, plan.tw, j, std::make_integer_sequence<int, L - 2>{});
+  const real al = alpha[pl - fd_div(pl, fc) * fc.d];
+  // the rows of x and of the auxiliary state as range-checked buffers: loads outside the window return zero, stores
+  // outside it are dropped (lpc_make_rsrc); padded pair i = j + NB m covers columns 2 i - sw, 2 i - sw + 1
+  const unsigned rowb = (unsigned)g.W * (unsigned)sizeof(real);
+  const lpc_rsrc xr = lpc_make_rsrc(X + (long)pl * g.uplane + (long)u * g.W, rowb);
+  const lpc_rsrc ar = lpc_make_rsrc(AUX + (long)pl * g.uplane + (long)u * g.W, rowb);
+  int off[R];
+#pragma unroll
+  for (int m = 0; m < R; ++m) off[m] = lpc_opaque((2 * (j + NB * m) - g.sw) * (int)sizeof(real));
+  real2 v[R], r[R];
+  auto run = [&](auto kind_tag) {           // one branch on the variant, then a straight-line body (gd_update_val)
+    constexpr int KIND = decltype(kind_tag)::value;
+    bool rd, wr;
+    gd_aux_access<KIND, 0>(p, rd, wr);
+    // the row of x in flight across the last inverse stage, the auxiliary state behind its butterfly (with both rows in
+    // flight across it the kernel spills 400 bytes per lane)
+    real2 xx[R], aa[R];
+#pragma unroll
+    for (int m = 0; m < R; ++m) xx[m] = lpc_buf_load2(xr, off[m]);
+    v2_last_stage<P, SK, true>(s, plan.tw, j, v);
+    LPC_SCHED_FENCE();
+#pragma unroll
+    for (int m = 0; m < R; ++m) aa[m] = rd ? lpc_buf_load2(ar, off[m]) : make_real2((real)0., (real)0.);
+    // gradient pair (j, m + R/2 mod R) belongs to padded pair (j, m): update inside the window, zero outside
+#pragma unroll
+    for (int m = 0; m < R; ++m) {
+      const real2 gr = v[(m + R / 2) % R];
+      real2 an, xs;
+      xs.x = gd_update_val<KIND, 0>(xx[m].x, aa[m].x, gr.x, al, p, an.x);
+      xs.y = gd_update_val<KIND, 0>(xx[m].y, aa[m].y, gr.y, al, p, an.y);
+      if (wr) lpc_buf_store2(ar, off[m], an);
+      lpc_buf_store2(xr, off[m], xs);
+      r[m] = (unsigned)off[m] < rowb ? xs : make_real2((real)0., (real)0.);
+    }
+  };
+  if (p.kind == 2) run(std::integral_constant<int, 2>{});
+  else if (p.kind == 1) run(std::integral_constant<int, 1>{});
+  else run(std::integral_constant<int, 0>{});
+  __syncthreads();
+  v2_first_fwd<P, SK>(s, j, r);
+  v2_mid_stages<P, NT, SK, false>(s, plan.tw, j, std::make_integer_sequence<int, L - 2>{});
+  v2_last_stage<P, SK, false>(s, plan.tw, j, v);
+  __syncthreads();
+  v2_untangle_store<P, SK>(s, twW, j, v, Sout + (long)pl * g.cplane + (long)(g.sh + u) * g.cpitch);
+}
+
+#endif   // !LPC_DOUBLE

@@ -6,6 +6,7 @@
 // plan choice turned into a constant.  Nothing here is shape-specific source: the shape arrives as macros.
 #include "lpc_engine.h"
 #include "lpc_gd_kernels.h"
+#include "lpc_gd_v2_kernels.h"
 
 #ifndef LPC_MOD_MID_TWG
 #define LPC_MOD_MID_TWG 0
@@ -89,6 +90,12 @@ static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
 static int m_gd_rows_mid(Engine* e) {
   const PlaneGeom& g = e->g;
 #ifndef LPC_DOUBLE
+  if constexpr (GdV2<RowP>::ok) {
+    if (e->gd_v2)     // second form (lpc_gd_v2_kernels.h): one-radix plan, M / R lanes per row
+      return launch_k(e, LPC_K_ROW_INV, k_gd_resid_v2<GdV2<RowP>::NB, RSK, RowPA>, dim3(g.H, e->P), GdV2<RowP>::NB, kRowSmem,
+                      geom_rev(e, e->opt.gd_rev & 1), row_arg(e), e->planW.tw, (const real2*)e->S, e->S2,
+                      (const real*)e->Y, make_fastdiv((unsigned)g.DC), make_fastdiv((unsigned)g.C));
+  }
   if constexpr (LdsTw<RowP>::ok(RNT)) {
     // persistent workgroups, the next row in flight (k_rinv_gd_mid_half_pf); 8-byte accesses to y need the pair geometry
     if (e->opt.row_pf > 0 && ((g.sw | g.W | (g.Wp / 2)) & 1) == 0) {
@@ -113,6 +120,14 @@ static int m_gd_rows_update(Engine* e, const GdScalars* sc, const real* alpha) {
 }
 static int m_gd_rows_update_fwd(Engine* e, const GdScalars* sc, const real* alpha) {
   const PlaneGeom& g = e->g;
+#ifndef LPC_DOUBLE
+  if constexpr (GdV2<RowP>::ok) {
+    if (e->gd_v2)
+      return launch_k(e, LPC_K_SPATIAL, k_gd_update_fwd_v2<GdV2<RowP>::NB, RSK, RowPA>, dim3(g.H, e->P), GdV2<RowP>::NB,
+                      kRowSmem, geom_rev(e, e->opt.gd_rev & 2), row_arg(e), e->planW.tw, (const real2*)e->S2, e->S, e->gx,
+                      e->gaux, alpha, *sc, make_fastdiv((unsigned)g.C));
+  }
+#endif
   return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update_fwd_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem,
                   geom_rev(e, e->opt.gd_rev & 2),
                   row_arg(e), e->planW.tw, (const real2*)e->S2, e->S, e->gx, e->gaux, alpha, *sc);
@@ -217,6 +232,9 @@ extern "C" int lpc_module_init(LpcModule* m, size_t engine_size, const char* src
 #endif
 #endif
 #if LPC_MOD_ROW_KIND == LPC_ROWS_HALF && LPC_MOD_FAMILY == LPC_FAM_GD
+#ifndef LPC_DOUBLE
+  m->gd_v2 = GdV2<RowP>::ok ? 1 : 0;
+#endif
   m->gd_rows_mid = m_gd_rows_mid;
   m->gd_rows_update = m_gd_rows_update;
   m->gd_rows_update_fwd = m_gd_rows_update_fwd;

@@ -147,6 +147,8 @@ struct EngineOpts {
   int row_lay = -1;           // LDS layout of the compile-time row plans: -1 / 1 i + i/8 where that stays affine; 0 natural;
                               // 2 the conflict-free xor layout (lengths that are multiples of 16; measured: no faster)
   int gd_no_fuse_fwd = 0;     // gradient-descent update without the next iteration's forward rows
+  int gd_v2 = 1;              // gradient-descent family, half-length rows on a one-radix plan (4096 = 16.16.16, 512 = 8.8.8) and
+                              // even window offset / width: the fused row kernels of lpc_gd_v2_kernels.h (0: the first form)
   int rpitch_pad = 0;         // floats added to the pitch of the padded real planes (tuning: a pitch of 2^k bytes puts the same
                               // column of every row on the same HBM channel)
   int row_pf = 0;             // ADMM inverse rows (half-length, float32, radices 8 / 16): persistent workgroups, N per CU, with
@@ -222,6 +224,7 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "no_skew") o.no_skew = (int)iv;
       else if (k == "row_lay") o.row_lay = (int)iv;
       else if (k == "gd_no_fuse_fwd") o.gd_no_fuse_fwd = (int)iv;
+      else if (k == "gd_v2") o.gd_v2 = (int)iv;
       else if (k == "row_nt") o.row_nt = (int)iv;
       else if (k == "row_pf") o.row_pf = (int)iv;
       else if (k == "rpitch_pad") o.rpitch_pad = (int)iv;

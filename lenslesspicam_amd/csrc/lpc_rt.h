@@ -60,6 +60,11 @@ static inline void lpc_glds16(const void* gsrc, void* lds_wave_base, int lane) {
 }
 static inline void lpc_glds_wait() {}
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32); }
+// range-checked row accesses (see the HIP branch): the emulator checks the range itself
+struct lpc_rsrc { char* base; unsigned bytes; };
+static inline lpc_rsrc lpc_make_rsrc(const void* base, unsigned bytes) { lpc_rsrc r; r.base = (char*)base; r.bytes = bytes; return r; }
+static inline int lpc_opaque(int x) { return x; }
+#define LPC_SCHED_FENCE() ((void)0)
 
 typedef void* lpcStream_t;
 typedef int lpcError_t;
@@ -123,6 +128,19 @@ static __device__ __forceinline__ void lpc_glds16(const void* gsrc, void* lds_wa
                : "v"(gsrc), "s"(dst));
 }
 static __device__ __forceinline__ void lpc_glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Range-checked accesses to one row of an un-padded plane ("pad on load, crop on store" done by the address unit): a raw
+// buffer resource over the row's bytes; a load whose byte offset (unsigned: a negative column is a huge offset) lies
+// outside it returns zero, a store outside it is dropped -- no clamped addresses, no selects, no branches, and one 32-bit
+// offset register per access instead of a 64-bit address.  The offset must arrive COMPLETE in the VGPR: the range check
+// does not wrap, so "negative offset + positive immediate" would be out of range even when the sum is not -- lpc_opaque()
+// keeps the compiler from splitting a constant off into the instruction's immediate field.
+typedef __amdgpu_buffer_rsrc_t lpc_rsrc;
+static __device__ __forceinline__ lpc_rsrc lpc_make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);   // gfx9: DATA_FORMAT = 32 bit
+}
+static __device__ __forceinline__ int lpc_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+// nothing is scheduled across this point (keeps a batch of loads behind the arithmetic whose registers it needs)
+#define LPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 typedef hipStream_t lpcStream_t;
 typedef hipError_t lpcError_t;
 #define lpcSuccess hipSuccess
@@ -179,6 +197,29 @@ static __host__ __device__ __forceinline__ real rmax(real a, real b) { return fm
 static __host__ __device__ __forceinline__ real rmin(real a, real b) { return fminf(a, b); }
 static __host__ __device__ __forceinline__ real rabs(real a) { return fabsf(a); }
 static __host__ __device__ __forceinline__ real rsqrt_of(real a) { return sqrtf(a); }
+#endif
+
+// two adjacent floats of a row through its buffer resource (byte offset of the first; both in range or both out)
+#if defined(LPC_SIMT_EMU)
+static inline real2 lpc_buf_load2(lpc_rsrc r, int off) {
+  return (unsigned)off + 2 * sizeof(real) <= r.bytes && (unsigned)off < r.bytes ? *(const real2*)(r.base + off) : make_real2((real)0., (real)0.);
+}
+static inline void lpc_buf_store2(lpc_rsrc r, int off, real2 v) {
+  if ((unsigned)off + 2 * sizeof(real) <= r.bytes && (unsigned)off < r.bytes) *(real2*)(r.base + off) = v;
+}
+#elif !defined(LPC_DOUBLE)
+static __device__ __forceinline__ real2 lpc_buf_load2(lpc_rsrc r, int off) {
+  typedef unsigned lpc_u2 __attribute__((ext_vector_type(2)));
+  const lpc_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+  return make_real2(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y));
+}
+static __device__ __forceinline__ void lpc_buf_store2(lpc_rsrc r, int off, real2 v) {
+  typedef unsigned lpc_u2 __attribute__((ext_vector_type(2)));
+  lpc_u2 u;
+  u.x = __builtin_bit_cast(unsigned, v.x);
+  u.y = __builtin_bit_cast(unsigned, v.y);
+  __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0);
+}
 #endif
 
 // ------------------------------------------------------------ two-wide float math --

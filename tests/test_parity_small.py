@@ -923,3 +923,46 @@ def test_prefetching_residual_rows(backend, monkeypatch, shape, rad):
     o = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
     o.set_data(y)
     assert rel(outs[1], o.apply(9)) <= 5e-6
+
+
+@pytest.mark.parametrize("shape,algo,rad,extra", [
+    ((1, 5, 512, 1), "fista", "8.8.8", {}),
+    ((2, 4, 512, 3), "fista", "8.8.8", {"gd_rev": 7}),
+    ((1, 5, 512, 3), "nesterov", "8.8.8", {}),
+    ((1, 3, 512, 1), "gd", "8.8.8", {}),
+    ((1, 3, 4092, 1), "fista", "16.16.16", {}),
+    ((1, 3, 4092, 3), "nesterov", "8.8.8.8", {"row_rad": "8.8.8.8"}),
+])
+def test_gd_fused_rows_second_form(backend, monkeypatch, shape, algo, rad, extra):
+    """option gd_v2 (default on): the gradient-descent family's two fused row kernels in their second form
+    (lpc_gd_v2_kernels.h: M / R lanes per row, tangling + first inverse stage straight from global memory, the last inverse
+    stage handing its samples to the first forward stage in registers, y / x / aux through range-checked buffer
+    accesses).  Same products in the same order as k_rinv_gd_mid_half / k_rinv_gd_update_fwd_half: the iterates agree to
+    round-off with the first form (bit for bit on the emulator) and with the float64 oracle; a frame whose window
+    offset is odd keeps the first form.  gd.py:128-134,183-188,235-241."""
+    D, H, W, C = shape
+    rng = np.random.default_rng(W + C)
+    psf = orc.synthetic_psf(D, H, W, C, seed=5)
+    y = rng.random((H, W, C), dtype=np.float32)
+    cls = {"fista": lpa.FISTA, "nesterov": lpa.NesterovGradientDescent, "gd": lpa.GradientDescent}[algo]
+    outs = []
+    for v2 in (0, 1):
+        engine_opts(monkeypatch, gd_v2=v2, jit_min_points=0, **extra)
+        rec = cls(torch.from_numpy(psf).to(backend.device))
+        info = rec._handle.plan_info()
+        assert "half-length %d [static %s" % (rec._padded_shape[2] // 2, rad) in info, info
+        assert ("second form" in info) == bool(v2), info
+        rec.set_data(torch.from_numpy(y).to(backend.device))
+        a = rec.apply(n_iter=4, disp_iter=None).detach().cpu().numpy().copy()
+        b = rec.apply(n_iter=3, disp_iter=None, reset=False).detach().cpu().numpy().copy()   # continuation: state intact
+        outs.append((a, b))
+    assert rel(outs[1][0], outs[0][0]) <= 1e-6 and rel(outs[1][1], outs[0][1]) <= 1e-6
+    if backend.kind == "emu":
+        assert np.array_equal(outs[0][1], outs[1][1])
+    o = orc.GDOracle(psf, kind={"gd": "vanilla"}.get(algo, algo), dtype=torch.float64)
+    o.set_data(y)
+    assert rel(outs[1][1], o.apply(7)) <= 5e-6
+    # odd window offset: 8-byte accesses to y / x are not aligned -> first form
+    engine_opts(monkeypatch, jit_min_points=0)
+    rec = lpa.FISTA(torch.from_numpy(orc.synthetic_psf(1, 3, 510, 1, seed=1)).to(backend.device))
+    assert "second form" not in rec._handle.plan_info()
