@@ -133,6 +133,11 @@ static int row_layout(const EngineOpts& o, int n, const std::vector<int>& rad) {
   const int skew = radices_skew_ok(n, rad) ? 1 : 0;
   if (o.no_skew || o.row_lay == 0) return 0;
   if (o.row_lay == 2) return n % 16 == 0 ? 2 : skew;
+  if (o.row_lay == 3) {      // i + i/16: plans whose radices are all 8 or 16 (lpc_fft.h)
+    bool ok = n % 16 == 0;
+    for (int r : rad) ok = ok && (r == 8 || r == 16);
+    return ok ? 3 : skew;
+  }
   return skew;
 }
 

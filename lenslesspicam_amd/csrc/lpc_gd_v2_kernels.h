@@ -78,15 +78,83 @@ static __device__ __forceinline__ void v2_load_tangle_first(real2* s, const real
   for (int m = 0; m < R; ++m) s[lds_slot<SK>(j * R + m)] = v[m];
 }
 
-// last stage of a transform (radix R, NS = NB: butterfly j, twiddles w^(j m)); inputs from the tile, outputs
-// (elements j + NB m) stay in v[]
-template <class P, int SK, bool INV>
-static __device__ __forceinline__ void v2_last_stage(const real2* s, const real2* LPC_RESTRICT tw, int j, real2* v) {
-  constexpr int R = GdV2<P>::R, NB = GdV2<P>::NB;
+// ---- stage twiddles, loaded ONE STAGE AHEAD ------------------------------------------------------------------------
+// twiddle_mul() loads the base powers w, w^2, w^4 (, w^8) of its butterfly inside the stage, i.e. behind the barrier that
+// opens it: an L2 round trip on the critical path of every twiddled stage (four per row), with four waves per SIMD to
+// hide it -- the counters show the waves of these kernels waiting on vector memory for 45 % of their lifetime
+// (profiles/r05_notes.md).  Here the base powers of stage ST + 1 are requested while stage ST still computes.
+// v2_tw_apply is twiddle_mul's arithmetic on the loaded values: same products in the same order.
+template <class P, int ST>
+static __device__ __forceinline__ void v2_tw_load(const real2* LPC_RESTRICT tw, int j, real2* w) {
+  constexpr int R = GdV2<P>::R, NS = P::ns(ST), STEP = P::n / (NS * R);
+  // (an opaque copy of the lane index: the inverse and the forward transform request the same table entries, and the
+  // compiler would rather keep the eight 64-bit addresses alive -- spilled -- across a transform than recompute them)
+  const int q = (lpc_opaque(j) % NS) * STEP;
+  w[0] = tw[q]; w[1] = tw[2 * q]; w[2] = tw[4 * q];
+  if (R == 16) w[3] = tw[8 * q];
+}
+template <int R, bool INV>
+static __device__ __forceinline__ void v2_tw_apply(real2* v, const real2* wb) {
+  real2 w[16];
+  w[1] = wb[0]; w[2] = wb[1]; w[4] = wb[2];
+  if (R == 16) w[8] = wb[3];
+  w[3] = cmul(w[1], w[2]); w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]);
+  if (R == 16) {
+#pragma unroll
+    for (int m = 9; m < 16; ++m) w[m] = cmul(w[m - 8], w[8]);
+  }
+#pragma unroll
+  for (int m = 1; m < R; ++m) v[m] = INV ? cmul_conj(v[m], w[m]) : cmul(v[m], w[m]);
+}
+
+// stage ST (0 < ST < L - 1) in place in the tile, twiddles in wb; ends with a barrier (sfft_stage with one butterfly per
+// lane)
+template <class P, int ST, int SK, bool INV>
+static __device__ __forceinline__ void v2_mid_stage(real2* s, int j, const real2* wb) {
+  constexpr int R = GdV2<P>::R, NB = GdV2<P>::NB, NS = P::ns(ST);
+  real2 v[R];
 #pragma unroll
   for (int m = 0; m < R; ++m) v[m] = s[lds_slot<SK>(j + NB * m)];
-  twiddle_mul<R, INV>(v, tw, j);
+  v2_tw_apply<R, INV>(v, wb);
   Dft<R, INV>::run(v);
+  const int oi = (j / NS) * NS * R + j % NS;
+  __syncthreads();
+#pragma unroll
+  for (int m = 0; m < R; ++m) s[lds_slot<SK>(oi + m * NS)] = v[m];
+  __syncthreads();
+}
+
+// stages 1 .. L - 2 of a transform, in the tile.  On entry wb holds the base twiddles of stage 1, on exit those of
+// stage L - 1: each stage requests its successor's before its own arithmetic.
+template <class P, int ST, int SK, bool INV>
+static __device__ __forceinline__ void v2_mid_one(real2* s, const real2* LPC_RESTRICT tw, int j, real2* wb) {
+  real2 wn[4];
+  v2_tw_load<P, ST + 1>(tw, j, wn);
+  v2_mid_stage<P, ST, SK, INV>(s, j, wb);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) wb[i] = wn[i];
+}
+template <class P, int SK, bool INV, int... I>
+static __device__ __forceinline__ void v2_mid_chain(real2* s, const real2* LPC_RESTRICT tw, int j, real2* wb,
+                                                    std::integer_sequence<int, I...>) {
+  (v2_mid_one<P, 1 + I, SK, INV>(s, tw, j, wb), ...);
+}
+// last stage (ST = L - 1: NS = NB, butterfly j): inputs from the tile, outputs (elements j + NB m) stay in v[].  NEXT: the
+// base twiddles of stage 1 of the transform that follows are requested in front of the arithmetic and returned in wb.
+template <class P, int SK, bool INV, bool NEXT>
+static __device__ __forceinline__ void v2_final_stage(const real2* s, const real2* LPC_RESTRICT tw, int j, real2* wb,
+                                                      real2* v) {
+  constexpr int R = GdV2<P>::R, NB = GdV2<P>::NB;
+  real2 wn[4];
+  if (NEXT) v2_tw_load<P, 1>(tw, j, wn);
+#pragma unroll
+  for (int m = 0; m < R; ++m) v[m] = s[lds_slot<SK>(j + NB * m)];
+  v2_tw_apply<R, INV>(v, wb);
+  Dft<R, INV>::run(v);
+  if (NEXT) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) wb[i] = wn[i];
+  }
 }
 
 // first forward stage (radix R, no twiddles) from registers -> tile; trailing barrier
@@ -131,12 +199,6 @@ static __device__ __forceinline__ void v2_untangle_store(real2* s, const real2* 
   }
 }
 
-template <class P, int NT, int SK, bool INV, int... I>
-static __device__ __forceinline__ void v2_mid_stages(real2* s, const real2* LPC_RESTRICT tw, int tid,
-                                                     std::integer_sequence<int, I...>) {
-  (sfft_stage<P, 1 + I, NT, 1, INV, SK>(s, tw, tid), ...);
-}
-
 // data plane of state plane pl: (pl / DC) * C + pl % C
 static __device__ __forceinline__ int v2_data_plane(unsigned pl, FastDiv fdc, FastDiv fc, int C) {
   const unsigned q = fd_div(pl, fdc);
@@ -156,96 +218,104 @@ __global__ __launch_bounds__(NT, 4) void k_gd_resid_v2(PlaneGeom g, PL plan, con
   const int j = LPC_TID(NT), u = (int)LPC_BX(g);
   const unsigned pl = LPC_BY(g);
   const int sr = wrap_add(g.sh + u, g.Hp / 2, g.Hp);
+  real2 wb[4];
+  v2_tw_load<P, 1>(plan.tw, j, wb);
   v2_load_tangle_first<P, SK>(s, Sin + (long)pl * g.cplane + (long)sr * g.cpitch, twW, j);
   __syncthreads();
-  // the measurement row, in flight across the remaining inverse stages: padded pair i = j + NB m covers columns
-  // 2 i - sw, 2 i - sw + 1 of the frame; outside the window the loads return zero (lpc_make_rsrc)
+  v2_mid_chain<P, SK, true>(s, plan.tw, j, wb, std::make_integer_sequence<int, L - 2>{});
+  // the measurement row, in flight across the last inverse stage (across two stages it costs the registers that the
+  // twiddle prefetch needs): padded pair i = j + NB m covers columns 2 i - sw, 2 i - sw + 1 of the frame; outside the
+  // window the loads return zero (lpc_make_rsrc)
   const lpc_rsrc yr = lpc_make_rsrc(Y + (long)v2_data_plane(pl, fdc, fc, g.C) * g.uplane + (long)u * g.W,
                                     (unsigned)g.W * (unsigned)sizeof(real));
-  int off[R];
-#pragma unroll
-  for (int m = 0; m < R; ++m) off[m] = lpc_opaque((2 * (j + NB * m) - g.sw) * (int)sizeof(real));
   real2 yy[R];
 #pragma unroll
-  for (int m = 0; m < R; ++m) yy[m] = lpc_buf_load2(yr, off[m]);
-  v2_mid_stages<P, NT, SK, true>(s, plan.tw, j, std::make_integer_sequence<int, L - 2>{});
+  for (int m = 0; m < R; ++m) yy[m] = lpc_buf_load2(yr, lpc_opaque((2 * (j + NB * m) - g.sw) * (int)sizeof(real)));
   real2 v[R], r[R];
-  v2_last_stage<P, SK, true>(s, plan.tw, j, v);
+  v2_final_stage<P, SK, true, true>(s, plan.tw, j, wb, v);
   // conv pair (j, m) is pair (j, m + R/2 mod R) of the shifted row: residual inside the window, zero outside
 #pragma unroll
   for (int m = 0; m < R; ++m) {
     const real2 z = v[(m + R / 2) % R];
-    r[m] = (unsigned)off[m] < (unsigned)g.W * (unsigned)sizeof(real) ? make_real2(z.x - yy[m].x, z.y - yy[m].y)
-                                                                     : make_real2((real)0., (real)0.);
+    r[m] = (unsigned)(2 * (j + NB * m) - g.sw) < (unsigned)g.W ? make_real2(z.x - yy[m].x, z.y - yy[m].y)
+                                                                : make_real2((real)0., (real)0.);
   }
   __syncthreads();
   v2_first_fwd<P, SK>(s, j, r);
-  v2_mid_stages<P, NT, SK, false>(s, plan.tw, j, std::make_integer_sequence<int, L - 2>{});
-  v2_last_stage<P, SK, false>(s, plan.tw, j, v);
+  v2_mid_chain<P, SK, false>(s, plan.tw, j, wb, std::make_integer_sequence<int, L - 2>{});
+  v2_final_stage<P, SK, false, false>(s, plan.tw, j, wb, v);
   __syncthreads();
   v2_untangle_store<P, SK>(s, twW, j, v, Sout + (long)pl * g.cplane + (long)(g.sh + u) * g.cpitch);
 }
 
-template <int NT, int SK, class PL>
+// KIND (0 vanilla, 1 Nesterov, 2 FISTA) and FIRST (FISTA's first update, where x_k aliases the iterate: gd.py:233,236) are
+// template arguments -- the launcher picks the instantiation: with the variant and `first` as run-time flags inside one
+// kernel the loads of the auxiliary state sat behind a branch (a `s_waitcnt vmcnt(0)` right behind them) and the three
+// variants' registers added up to 250 bytes of scratch per lane.
+template <int NT, int SK, class PL, int KIND, int FIRST>
 __global__ __launch_bounds__(NT, 4) void k_gd_update_fwd_v2(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
-                                                                    const real2* LPC_RESTRICT Sin,
-                                                                    real2* LPC_RESTRICT Sout, real* LPC_RESTRICT X,
-                                                                    real* LPC_RESTRICT AUX,
-                                                                    const real* LPC_RESTRICT alpha, GdScalars p,
-                                                                    FastDiv fc) {
+                                                            const real2* LPC_RESTRICT Sin, real2* LPC_RESTRICT Sout,
+                                                            real* LPC_RESTRICT X, real* LPC_RESTRICT AUX,
+                                                            const real* LPC_RESTRICT alpha, GdScalars pin, FastDiv fc) {
   using P = typename PL::plan;
-  constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB, L = GdV2<P>::L;
+  constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB, L = GdV2<P>::L, H = R / 2;
   static_assert(GdV2<P>::ok && NT == NB, "k_gd_update_fwd_v2: one butterfly per lane and stage");
+  constexpr bool rd = KIND == 1 || (KIND == 2 && !FIRST), wr = KIND != 0;     // gd_aux_access, split == 0
+  GdScalars p = pin;
+  p.kind = KIND; p.first = FIRST; p.split = 0;
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int j = LPC_TID(NT), u = (int)LPC_BX(g);
   const unsigned pl = LPC_BY(g);
   const int sr = wrap_add(g.sh + u, g.Hp / 2, g.Hp);
+  real2 wb[4];
+  v2_tw_load<P, 1>(plan.tw, j, wb);
   v2_load_tangle_first<P, SK>(s, Sin + (long)pl * g.cplane + (long)sr * g.cpitch, twW, j);
   __syncthreads();
-  v2_mid_stages<P, NT, SK, true>(s, plan.tw, j, std::make_integer_sequence<int, L - 2>{});
+  v2_mid_chain<P, SK, true>(s, plan.tw, j, wb, std::make_integer_sequence<int, L - 2>{});
   const real al = alpha[pl - fd_div(pl, fc) * fc.d];
   // the rows of x and of the auxiliary state as range-checked buffers: loads outside the window return zero, stores
   // outside it are dropped (lpc_make_rsrc); padded pair i = j + NB m covers columns 2 i - sw, 2 i - sw + 1
   const unsigned rowb = (unsigned)g.W * (unsigned)sizeof(real);
   const lpc_rsrc xr = lpc_make_rsrc(X + (long)pl * g.uplane + (long)u * g.W, rowb);
   const lpc_rsrc ar = lpc_make_rsrc(AUX + (long)pl * g.uplane + (long)u * g.W, rowb);
-  int off[R];
-#pragma unroll
-  for (int m = 0; m < R; ++m) off[m] = lpc_opaque((2 * (j + NB * m) - g.sw) * (int)sizeof(real));
   real2 v[R], r[R];
-  auto run = [&](auto kind_tag) {           // one branch on the variant, then a straight-line body (gd_update_val)
-    constexpr int KIND = decltype(kind_tag)::value;
-    bool rd, wr;
-    gd_aux_access<KIND, 0>(p, rd, wr);
-    // the row of x in flight across the last inverse stage, the auxiliary state behind its butterfly (with both rows in
-    // flight across it the kernel spills 400 bytes per lane)
-    real2 xx[R], aa[R];
+  // Two halves of R / 2 pairs, so that x, the auxiliary state and the butterfly's registers never add up: the first
+  // half's rows travel across the last inverse stage, the second half's across the first half's arithmetic.
+  // (byte offsets are recomputed where they are used -- one integer operation each -- instead of kept across the butterfly)
+  auto offs = [&](int m) { return lpc_opaque((2 * (j + NB * m) - g.sw) * (int)sizeof(real)); };
+  auto loads = [&](int m0, real2* xx, real2* aa) {
 #pragma unroll
-    for (int m = 0; m < R; ++m) xx[m] = lpc_buf_load2(xr, off[m]);
-    v2_last_stage<P, SK, true>(s, plan.tw, j, v);
-    LPC_SCHED_FENCE();
+    for (int m = 0; m < H; ++m) xx[m] = lpc_buf_load2(xr, offs(m0 + m));
 #pragma unroll
-    for (int m = 0; m < R; ++m) aa[m] = rd ? lpc_buf_load2(ar, off[m]) : make_real2((real)0., (real)0.);
-    // gradient pair (j, m + R/2 mod R) belongs to padded pair (j, m): update inside the window, zero outside
+    for (int m = 0; m < H; ++m) aa[m] = rd ? lpc_buf_load2(ar, offs(m0 + m)) : make_real2((real)0., (real)0.);
+  };
+  // gradient pair (j, m + R/2 mod R) belongs to padded pair (j, m): update inside the window, zero outside
+  auto update = [&](int m0, const real2* xx, const real2* aa) {
 #pragma unroll
-    for (int m = 0; m < R; ++m) {
-      const real2 gr = v[(m + R / 2) % R];
+    for (int m = 0; m < H; ++m) {
+      const real2 gr = v[(m0 + m + H) % R];
       real2 an, xs;
       xs.x = gd_update_val<KIND, 0>(xx[m].x, aa[m].x, gr.x, al, p, an.x);
       xs.y = gd_update_val<KIND, 0>(xx[m].y, aa[m].y, gr.y, al, p, an.y);
-      if (wr) lpc_buf_store2(ar, off[m], an);
-      lpc_buf_store2(xr, off[m], xs);
-      r[m] = (unsigned)off[m] < rowb ? xs : make_real2((real)0., (real)0.);
+      const int off = offs(m0 + m);
+      if (wr) lpc_buf_store2(ar, off, an);
+      lpc_buf_store2(xr, off, xs);
+      r[m0 + m] = (unsigned)off < rowb ? xs : make_real2((real)0., (real)0.);
     }
   };
-  if (p.kind == 2) run(std::integral_constant<int, 2>{});
-  else if (p.kind == 1) run(std::integral_constant<int, 1>{});
-  else run(std::integral_constant<int, 0>{});
+  real2 x0[H], a0[H], x1[H], a1[H];
+  loads(0, x0, a0);
+  v2_final_stage<P, SK, true, true>(s, plan.tw, j, wb, v);
+  LPC_SCHED_FENCE();
+  loads(H, x1, a1);
+  LPC_SCHED_FENCE();
+  update(0, x0, a0);
+  update(H, x1, a1);
   __syncthreads();
   v2_first_fwd<P, SK>(s, j, r);
-  v2_mid_stages<P, NT, SK, false>(s, plan.tw, j, std::make_integer_sequence<int, L - 2>{});
-  v2_last_stage<P, SK, false>(s, plan.tw, j, v);
+  v2_mid_chain<P, SK, false>(s, plan.tw, j, wb, std::make_integer_sequence<int, L - 2>{});
+  v2_final_stage<P, SK, false, false>(s, plan.tw, j, wb, v);
   __syncthreads();
   v2_untangle_store<P, SK>(s, twW, j, v, Sout + (long)pl * g.cplane + (long)(g.sh + u) * g.cpitch);
 }

@@ -32,6 +32,7 @@ static constexpr int RNT = LPC_MOD_ROW_NT, REM = LPC_MOD_ROW_EM;
 static constexpr int RSK = LPC_MOD_ROW_SK;       // LDS layout of the row tile: LPC_LAY_NONE / _SKEW8 / _XOR16 (lpc_fft.h)
 static_assert(RSK != LPC_LAY_SKEW8 || RowP::skew_ok(), "this row plan does not keep the LDS skew affine");
 static_assert(RSK != LPC_LAY_XOR16 || RowP::n % 16 == 0, "the xor layout permutes aligned blocks of 16 elements");
+static_assert(RSK != LPC_LAY_SKEW16 || RowP::n % 16 == 0, "the i + i/16 layout pads aligned blocks of 16 elements");
 static const size_t kRowSmem = LPC_ROW_SMEM_BYTES(RowP::n, RSK);
 #endif
 
@@ -87,12 +88,20 @@ static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
 }
 #endif
 #else   // gradient-descent family
+// the second form of the fused rows keeps its tile in the NATURAL layout whatever the module's other row kernels use:
+// immediate LDS offsets and the fewest registers (no scratch, five workgroups per CU for the residual rows); its bank
+// conflicts cost nothing measurable -- these kernels wait on memory, not on LDS (profiles/r05_notes.md)
+#ifndef LPC_MOD_V2_SK
+#define LPC_MOD_V2_SK LPC_LAY_NONE
+#endif
+static constexpr int V2SK = LPC_MOD_V2_SK;
+static const size_t kV2Smem = LPC_ROW_SMEM_BYTES(RowP::n, V2SK);
 static int m_gd_rows_mid(Engine* e) {
   const PlaneGeom& g = e->g;
 #ifndef LPC_DOUBLE
   if constexpr (GdV2<RowP>::ok) {
     if (e->gd_v2)     // second form (lpc_gd_v2_kernels.h): one-radix plan, M / R lanes per row
-      return launch_k(e, LPC_K_ROW_INV, k_gd_resid_v2<GdV2<RowP>::NB, RSK, RowPA>, dim3(g.H, e->P), GdV2<RowP>::NB, kRowSmem,
+      return launch_k(e, LPC_K_ROW_INV, k_gd_resid_v2<GdV2<RowP>::NB, V2SK, RowPA>, dim3(g.H, e->P), GdV2<RowP>::NB, kV2Smem,
                       geom_rev(e, e->opt.gd_rev & 1), row_arg(e), e->planW.tw, (const real2*)e->S, e->S2,
                       (const real*)e->Y, make_fastdiv((unsigned)g.DC), make_fastdiv((unsigned)g.C));
   }
@@ -122,10 +131,17 @@ static int m_gd_rows_update_fwd(Engine* e, const GdScalars* sc, const real* alph
   const PlaneGeom& g = e->g;
 #ifndef LPC_DOUBLE
   if constexpr (GdV2<RowP>::ok) {
-    if (e->gd_v2)
-      return launch_k(e, LPC_K_SPATIAL, k_gd_update_fwd_v2<GdV2<RowP>::NB, RSK, RowPA>, dim3(g.H, e->P), GdV2<RowP>::NB,
-                      kRowSmem, geom_rev(e, e->opt.gd_rev & 2), row_arg(e), e->planW.tw, (const real2*)e->S2, e->S, e->gx,
-                      e->gaux, alpha, *sc, make_fastdiv((unsigned)g.C));
+    if (e->gd_v2) {
+      auto go = [&](auto kernel) {
+        return launch_k(e, LPC_K_SPATIAL, kernel, dim3(g.H, e->P), GdV2<RowP>::NB, kV2Smem, geom_rev(e, e->opt.gd_rev & 2),
+                        row_arg(e), e->planW.tw, (const real2*)e->S2, e->S, e->gx, e->gaux, alpha, *sc,
+                        make_fastdiv((unsigned)g.C));
+      };
+      constexpr int NB = GdV2<RowP>::NB;
+      if (sc->kind == 2) return sc->first ? go(k_gd_update_fwd_v2<NB, V2SK, RowPA, 2, 1>) : go(k_gd_update_fwd_v2<NB, V2SK, RowPA, 2, 0>);
+      if (sc->kind == 1) return go(k_gd_update_fwd_v2<NB, V2SK, RowPA, 1, 0>);
+      return go(k_gd_update_fwd_v2<NB, V2SK, RowPA, 0, 0>);
+    }
   }
 #endif
   return launch_k(e, LPC_K_SPATIAL, k_rinv_gd_update_fwd_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem,

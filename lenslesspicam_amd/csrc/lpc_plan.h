@@ -63,7 +63,7 @@ static inline std::string fft_key(const StaticFft& f) {
 static inline std::string plan_spec_key(const PlanSpec& s) {
   std::string k = s.f64 ? "f64" : "f32";
   k += s.family == LPC_FAM_ADMM ? "_admm" : "_gd";
-  if (s.row_kind) k += std::string(s.row_kind == LPC_ROWS_HALF ? "_rh" : "_rp") + fft_key(s.row) + (s.row_sk == 1 ? "s" : (s.row_sk == 2 ? "z" : "")) + (s.row_x ? "x" : "");
+  if (s.row_kind) k += std::string(s.row_kind == LPC_ROWS_HALF ? "_rh" : "_rp") + fft_key(s.row) + (s.row_sk == 1 ? "s" : (s.row_sk == 2 ? "z" : (s.row_sk == 3 ? "h" : ""))) + (s.row_x ? "x" : "");
   if (s.passA.n) k += "_a" + fft_key(s.passA);
   if (s.mid_kind) k += std::string(s.mid_kind == LPC_MID_PAIR ? "_mp" : "_ms") + fft_key(s.mid) + "m" + std::to_string(s.mid_minw) + (s.mid_twg ? "g" : "") + (s.mid_pre ? "p" : "");
   return k;

@@ -208,17 +208,21 @@ static inline void lpc_buf_store2(lpc_rsrc r, int off, real2 v) {
   if ((unsigned)off + 2 * sizeof(real) <= r.bytes && (unsigned)off < r.bytes) *(real2*)(r.base + off) = v;
 }
 #elif !defined(LPC_DOUBLE)
+// (the loaded / stored pair is converted as a WHOLE vector: hipcc 7.2 folds `bit_cast<float>(v.x), bit_cast<float>(v.y)` on
+// the builtin's result into two copies of a one-dword load)
 static __device__ __forceinline__ real2 lpc_buf_load2(lpc_rsrc r, int off) {
   typedef unsigned lpc_u2 __attribute__((ext_vector_type(2)));
-  const lpc_u2 v = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
-  return make_real2(__builtin_bit_cast(float, v.x), __builtin_bit_cast(float, v.y));
+  typedef float lpc_f2 __attribute__((ext_vector_type(2)));
+  const lpc_f2 f = __builtin_bit_cast(lpc_f2, (lpc_u2)__builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0));
+  return make_real2(f.x, f.y);
 }
 static __device__ __forceinline__ void lpc_buf_store2(lpc_rsrc r, int off, real2 v) {
   typedef unsigned lpc_u2 __attribute__((ext_vector_type(2)));
-  lpc_u2 u;
-  u.x = __builtin_bit_cast(unsigned, v.x);
-  u.y = __builtin_bit_cast(unsigned, v.y);
-  __builtin_amdgcn_raw_buffer_store_b64(u, r, off, 0, 0);
+  typedef float lpc_f2 __attribute__((ext_vector_type(2)));
+  lpc_f2 f;
+  f.x = v.x;
+  f.y = v.y;
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(lpc_u2, f), r, off, 0, 0);
 }
 #endif
 

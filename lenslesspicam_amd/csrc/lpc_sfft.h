@@ -156,7 +156,7 @@ static __device__ __forceinline__ void sfft_first_fused(real2* s, int tid, Src& 
       if (SKEW == LPC_LAY_SKEW8) {
 #pragma unroll
         for (int m = 0; m < R; ++m) s[ob + m + (m >> 3)] = v[b][m];
-      } else if (SKEW == LPC_LAY_XOR16) {
+      } else if (SKEW == LPC_LAY_XOR16 || SKEW == LPC_LAY_SKEW16) {
 #pragma unroll
         for (int m = 0; m < R; ++m) s[lds_slot<SKEW>(j * R * BT + c + m * BT)] = v[b][m];
       } else {

@@ -10,8 +10,12 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 EMU_DIR = os.path.join(ROOT, "tests", "simt_emu")
-EMU_LIB = os.path.join(EMU_DIR, "_build", "liblpc_emu.so")
-EMU_LIB_F64 = os.path.join(EMU_DIR, "_build", "liblpc_emu_f64.so")
+# LPC_EMU_FLAVOUR=san: the AddressSanitizer + UndefinedBehaviorSanitizer build of the emulator (build_emu.sh --san,
+# tests/test_sanitizer.py runs a part of the suite on it in a child process with the ASan runtime preloaded)
+EMU_SAN = os.environ.get("LPC_EMU_FLAVOUR", "") == "san"
+EMU_BUILD = os.path.join(EMU_DIR, "_build_san" if EMU_SAN else "_build")
+EMU_LIB = os.path.join(EMU_BUILD, "liblpc_emu.so")
+EMU_LIB_F64 = os.path.join(EMU_BUILD, "liblpc_emu_f64.so")
 
 
 def pytest_configure(config):
@@ -30,12 +34,13 @@ def emu_lib():
     """SIMT-emulator build of the engine's real kernel sources (tests only, see lpc_rt.h)."""
     from lenslesspicam_amd import _native
 
+    libs = (EMU_LIB,) if EMU_SAN else (EMU_LIB, EMU_LIB_F64)       # (the sanitizer flavour is float32 only)
     stale = any(not os.path.exists(lib) or any(os.path.getmtime(f) > os.path.getmtime(lib) for f in _emu_sources())
-                for lib in (EMU_LIB, EMU_LIB_F64))
+                for lib in libs)
     if stale:
-        subprocess.check_call(["sh", os.path.join(EMU_DIR, "build_emu.sh")])
+        subprocess.check_call(["sh", os.path.join(EMU_DIR, "build_emu.sh")] + (["--san"] if EMU_SAN else []))
     lib = _native.Lib(EMU_LIB)
-    lib.f64 = _native.Lib(EMU_LIB_F64)     # the float64 flavour rides along
+    lib.f64 = None if EMU_SAN else _native.Lib(EMU_LIB_F64)     # the float64 flavour rides along
     return lib
 
 

@@ -12,6 +12,14 @@
 #include <thread>
 #include <vector>
 
+// Sanitizer flavour (build_emu.sh --san: -fsanitize=address,undefined): AddressSanitizer has to be told about every
+// switch between the scheduler's stack and a fibre's, and the LDS of a workgroup becomes an exact-size heap block per
+// workgroup, so that an index one element past the tile is a report instead of a read of the slack behind it.
+#if defined(__SANITIZE_ADDRESS__)
+#include <sanitizer/common_interface_defs.h>
+#define LPC_EMU_ASAN 1
+#endif
+
 namespace lpc_emu {
 
 namespace {
@@ -24,6 +32,11 @@ struct Worker {
   std::vector<char> done;
   std::vector<char> smem;
   ucontext_t sched;
+#if defined(LPC_EMU_ASAN)
+  const void* sched_stack = nullptr;     // the scheduler's (= the OS thread's) stack, learnt at the first switch back
+  size_t sched_size = 0;
+  void* exact_smem = nullptr;
+#endif
   int cur = -1;
   int nthreads = 0;
   const std::function<void()>* body = nullptr;
@@ -31,10 +44,33 @@ struct Worker {
 
 thread_local Worker* tl_worker = nullptr;
 
+#if defined(LPC_EMU_ASAN)
+// scheduler -> fibre t
+static void switch_to_fibre(Worker& w, int t) {
+  void* fake = nullptr;
+  __sanitizer_start_switch_fiber(&fake, w.stacks.data() + (size_t)t * kStack, kStack);
+  swapcontext(&w.sched, &w.fibres[t]);
+  __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+}
+// fibre -> scheduler (at a barrier: the fibre lives on; at its end: its fake stack is destroyed)
+static void switch_to_sched(Worker& w, int me, bool dying) {
+  void* fake = nullptr;
+  __sanitizer_start_switch_fiber(dying ? nullptr : &fake, w.sched_stack, w.sched_size);
+  swapcontext(&w.fibres[me], &w.sched);
+  __sanitizer_finish_switch_fiber(fake, nullptr, nullptr);
+}
+#endif
+
 void fibre_entry() {
   Worker* w = tl_worker;
+#if defined(LPC_EMU_ASAN)
+  __sanitizer_finish_switch_fiber(nullptr, &w->sched_stack, &w->sched_size);
+#endif
   (*w->body)();
   w->done[w->cur] = 1;
+#if defined(LPC_EMU_ASAN)
+  switch_to_sched(*w, w->cur, true);     // (never resumed)
+#endif
   // returning resumes uc_link == scheduler
 }
 
@@ -46,9 +82,15 @@ void run_block(Worker& w, dim3 bid, dim3 grid, dim3 block, size_t smem_bytes, co
     w.ctxs.resize(nt);
     w.done.resize(nt);
   }
+#if defined(LPC_EMU_ASAN)
+  std::free(w.exact_smem);
+  w.exact_smem = std::malloc(smem_bytes ? smem_bytes : 1);     // 16-byte aligned, red zones on both sides
+  char* smem = (char*)w.exact_smem;
+#else
   if (w.smem.size() < smem_bytes + 64) w.smem.resize(smem_bytes + 64);
   char* smem = w.smem.data();
   smem += (64 - ((uintptr_t)smem & 63)) & 63;
+#endif
   w.nthreads = nt;
   w.body = &body;
   for (int t = 0; t < nt; ++t) {
@@ -68,11 +110,19 @@ void run_block(Worker& w, dim3 bid, dim3 grid, dim3 block, size_t smem_bytes, co
     for (int t = 0; t < nt; ++t) {
       if (w.done[t]) continue;
       w.cur = t;
+#if defined(LPC_EMU_ASAN)
+      switch_to_fibre(w, t);
+#else
       swapcontext(&w.sched, &w.fibres[t]);
+#endif
       if (w.done[t]) --remaining;
     }
   }
   w.cur = -1;
+#if defined(LPC_EMU_ASAN)
+  std::free(w.exact_smem);
+  w.exact_smem = nullptr;
+#endif
 }
 }  // namespace
 
@@ -81,7 +131,11 @@ ThreadCtx& ctx() { return tl_worker->ctxs[tl_worker->cur]; }
 void barrier() {
   Worker* w = tl_worker;
   int me = w->cur;
+#if defined(LPC_EMU_ASAN)
+  switch_to_sched(*w, me, false);
+#else
   swapcontext(&w->fibres[me], &w->sched);  // scheduler resumes the next fibre; we continue next round
+#endif
 }
 
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body) {
@@ -111,3 +165,17 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
 }
 
 }  // namespace lpc_emu
+
+// Self-test of the sanitizer flavour (tests/test_sanitizer.py): a two-lane workgroup reads one byte past its 64 bytes of
+// LDS, across a barrier (= on a fibre stack, after a switch).  The plain build reads the slack behind the tile; the
+// --san build must die here with a heap-buffer-overflow report.
+extern "C" int lpc_emu_selftest_lds_overrun() {
+  volatile int sink = 0;
+  lpc_emu::launch(dim3(1), dim3(2), 64, [&]() {
+    char* s = lpc_emu::ctx().smem;
+    lpc_emu::barrier();
+    sink = sink + s[64 + (int)lpc_emu::ctx().tid.x];
+  });
+  return sink;
+}
+

@@ -843,6 +843,25 @@ def test_row_tile_lds_layouts(backend, monkeypatch, lay, half):
     assert ("z" if lay == 2 else "") + "x" in key.split("_")[2] and "s" not in key.split("_")[2].split("w")[1], key
 
 
+@pytest.mark.parametrize("shape,rad", [((20, 64, 3), "8.8"), ((9, 256, 1), "16.16")])
+def test_row_tile_layout_one_pad_per_16(backend, monkeypatch, shape, rad):
+    """option row_lay=3: i + i/16 (plans whose radices are all 8 or 16; lpc_fft.h) on ADMM's half-length row kernels --
+    forward rows with the X half, inverse rows, sensor-window structure -- against the float64 oracle."""
+    H, W, C = shape
+    rng = np.random.default_rng(W)
+    psf = orc.synthetic_psf(1, H, W, C, seed=3)
+    y = rng.random((H, W, C), dtype=np.float32)
+    engine_opts(monkeypatch, rows_half=1, row_rad=rad, row_lay=3, jit_min_points=0)
+    rec = lpa.ADMM(torch.from_numpy(psf).to(backend.device), tau=2e-6, mu2=1e-4)
+    info = rec._handle.plan_info()
+    assert "half-length %d [static %s" % (rec._padded_shape[2] // 2, rad) in info, info
+    assert info.split("plan module ")[1].split("_")[2].split("x")[1].startswith(("8h", "16h")) or "hx" in info, info
+    rec.set_data(torch.from_numpy(y).to(backend.device))
+    o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
+    o.set_data(y)
+    assert rel(rec.apply(n_iter=7, disp_iter=None), o.apply(7)) <= 5e-6, info
+
+
 @pytest.mark.parametrize("shape,seq_t", [((270, 20, 1), 2), ((270, 20, 3), 1), ((300, 36, 1), 4)])
 def test_single_launch_columns(backend, monkeypatch, shape, seq_t):
     """option col_single=1: the whole column transform of the ADMM step in one launch -- the sequential middle
@@ -932,6 +951,10 @@ def test_prefetching_residual_rows(backend, monkeypatch, shape, rad):
     ((1, 3, 512, 1), "gd", "8.8.8", {}),
     ((1, 3, 4092, 1), "fista", "16.16.16", {}),
     ((1, 3, 4092, 3), "nesterov", "8.8.8.8", {"row_rad": "8.8.8.8"}),
+    ((1, 4, 512, 3), "fista", "8.8.8", {"row_lay": 3}),
+    ((1, 3, 4092, 1), "fista", "16.16.16", {"row_lay": 3}),
+    ((1, 3, 4092, 1), "nesterov", "16.16.16", {"row_lay": 0}),
+    ((1, 3, 4092, 1), "gd", "16.16.16", {"row_lay": 2}),
 ])
 def test_gd_fused_rows_second_form(backend, monkeypatch, shape, algo, rad, extra):
     """option gd_v2 (default on): the gradient-descent family's two fused row kernels in their second form
@@ -956,7 +979,7 @@ def test_gd_fused_rows_second_form(backend, monkeypatch, shape, algo, rad, extra
         a = rec.apply(n_iter=4, disp_iter=None).detach().cpu().numpy().copy()
         b = rec.apply(n_iter=3, disp_iter=None, reset=False).detach().cpu().numpy().copy()   # continuation: state intact
         outs.append((a, b))
-    assert rel(outs[1][0], outs[0][0]) <= 1e-6 and rel(outs[1][1], outs[0][1]) <= 1e-6
+    assert rel(outs[1][0], outs[0][0]) <= 2e-6 and rel(outs[1][1], outs[0][1]) <= 2e-6
     if backend.kind == "emu":
         assert np.array_equal(outs[0][1], outs[1][1])
     o = orc.GDOracle(psf, kind={"gd": "vanilla"}.get(algo, algo), dtype=torch.float64)

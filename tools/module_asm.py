@@ -24,9 +24,9 @@ def defines(key):
             mid = p
     fft = r"(\d+)r([\d.]+)t(\d+)w(\d+)x(\d+)"
     if row:
-        m = re.fullmatch(r"r([hp])" + fft + r"([sz]?)(x?)", row)
+        m = re.fullmatch(r"r([hp])" + fft + r"([szh]?)(x?)", row)
         d += ["-DLPC_MOD_ROW_KIND=%d" % (1 if m[1] == "h" else 2), "-DLPC_MOD_ROW_RAD=" + m[3].replace(".", ","),
-              "-DLPC_MOD_ROW_NT=" + m[5], "-DLPC_MOD_ROW_EM=" + m[6], "-DLPC_MOD_ROW_SK=%d" % {"": 0, "s": 1, "z": 2}[m[7]],
+              "-DLPC_MOD_ROW_NT=" + m[5], "-DLPC_MOD_ROW_EM=" + m[6], "-DLPC_MOD_ROW_SK=%d" % {"": 0, "s": 1, "z": 2, "h": 3}[m[7]],
               "-DLPC_MOD_ROW_X=%d" % bool(m[8])]
     else:
         d.append("-DLPC_MOD_ROW_KIND=0")
