@@ -44,6 +44,32 @@ static int make_twiddles(Engine* e, int n, real2** out) {
   return upload(e, *out, h.data(), h.size() * sizeof(real2));
 }
 
+// stage twiddles of a compile-time plan in lane order: layout and purpose in lpc_sfft.h (SPlan::tws_off)
+static int make_stage_twiddles(Engine* e, const StaticFft& f, real2** out) {
+  *out = nullptr;
+  std::vector<real2> h;
+  bool any = false;
+  int ns = f.rad[0];
+  for (int st = 1; st < f.nst; ++st) {
+    const int R = f.rad[st], nb = f.n / R, step = f.n / (ns * R);
+    const size_t base = h.size();
+    h.resize(base + (size_t)4 * nb, make_real2((real)0., (real)0.));
+    any = any || R == 8 || R == 16;
+    if (R == 8 || R == 16)     // (twiddle_mul reads exact table entries for the other radices: their blocks stay empty)
+    for (int hh = 0; hh < 2; ++hh)
+      for (int j = 0; j < nb; ++j)
+        for (int i = 0; i < 2; ++i) {
+          const long q = (long)(j % ns) * step * (1L << (2 * hh + i));     // q, 2q | 4q, 8q
+          const double a = -2.0 * M_PI * (double)(q % f.n) / (double)f.n;
+          h[base + ((size_t)hh * nb + j) * 2 + i] = make_real2((real)std::cos(a), (real)std::sin(a));
+        }
+    ns *= R;
+  }
+  if (h.empty() || !any) return 0;
+  LPC_OK(dev_alloc(e, out, h.size()));
+  return upload(e, *out, h.data(), h.size() * sizeof(real2));
+}
+
 static int plan_from_radices(Engine* e, Fft1dPlan& p, int n, const std::vector<int>& rad) {
   p.n = n;
   p.nst = 0;
@@ -468,6 +494,8 @@ static int setup_geometry(Engine* e) {
     e->planWi.skew_ok = 0;
   }
   if (e->rows_half) LPC_OK(build_plan(e, e->planWh, g.Wp / 2));
+  e->tws_row = nullptr;
+  if (e->mod && e->spec.row_kind != LPC_ROWS_RUNTIME) LPC_OK(make_stage_twiddles(e, e->spec.row, &e->tws_row));
   LPC_OK(build_plan(e, e->planB, e->N2));
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
   // The half of the image-domain work that needs no neighbours rides in the module's forward row kernel: the blocks of
@@ -481,7 +509,7 @@ static int setup_geometry(Engine* e) {
   e->hv_skip = e->xi_window && !e->opt.hv_full && e->mod->admm_rows_inv && (e->N1 > 1 || e->mod->admm_mid);
   e->gd_fuse_fwd = c.algo >= LPC_ALGO_GD && e->mod && e->mod->gd_rows_update_fwd && !e->opt.gd_no_fuse_fwd;
   // the second form of the fused row kernels: 8-byte accesses to y / x need an even window offset and frame width
-  e->gd_v2 = c.algo >= LPC_ALGO_GD && e->mod && e->mod->gd_v2 && e->opt.gd_v2 != 0 && e->opt.row_pf <= 0 &&
+  e->gd_v2 = c.algo >= LPC_ALGO_GD && e->mod && e->mod->gd_v2 && e->tws_row && e->opt.gd_v2 != 0 && e->opt.row_pf <= 0 &&
              ((g.sw | g.W) & 1) == 0 && g.W >= 2;
   if (e->opt.gd_rev < 0)     // EngineOpts::gd_rev
     // all three (the row kernels and the register middle alternate with the forward-walking pass A, so every kernel

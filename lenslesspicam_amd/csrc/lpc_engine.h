@@ -116,6 +116,7 @@ struct lpc_engine {
   real2* phr = nullptr;    // [Hp] ifftshift phase, stored row order
   real2* phc = nullptr;    // [Wc]
   real2* twH = nullptr;
+  real2* tws_row = nullptr;   // stage twiddles of the module's row plan in lane order (lpc_sfft.h: SPlan::tws_off)
   // work spectra: [2][P] planes (ADMM uses both halves, others the first)
   real2* S = nullptr;
   // ADMM state (padded real planes)

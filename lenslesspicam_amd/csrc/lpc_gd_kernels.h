@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid_half(PlaneGeom g, PL plan, c
     return make_real2(sample(2 * i), sample(2 * i + 1));
   };
   fft_tile<NT, EMAX, false, SK, true, true>(s, plan, 1, make_fastdiv_dev1(), tid, resid, LdsNatural{});
-  untangle_half_store<NT, SK, EMAX / 2 + 1>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
+  untangle_half_store<NT, SK>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
 }
 
 // ---- k_rinv_gd_mid_half as a PERSISTENT workgroup with the next row in flight (option row_pf; compile-time plans) ------
@@ -437,7 +437,7 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_update_fwd_half(PlaneGeom g, PL 
   if (p.kind == 2) run(std::integral_constant<int, 2>{});
   else if (p.kind == 1) run(std::integral_constant<int, 1>{});
   else run(std::integral_constant<int, 0>{});
-  untangle_half_store<NT, SK, EMAX / 2 + 1>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
+  untangle_half_store<NT, SK>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
 }
 
 // second half of a split iteration: PROJ = proj(image_est) as the caller computed it, channels-last (n,H,W,C)

@@ -34,6 +34,29 @@
 
 #ifndef LPC_DOUBLE
 
+// Timing-only knock-outs (a plan module compiled by hand with -DLPC_V2_KNOCK_MASK=n and loaded through option module_dir,
+// tools/knock_modules.py; the results are garbage by construction): which resource do these kernels wait for?
+// bit 0: no butterflies / twiddle products; bit 1: no LDS traffic between the stages; bit 2: no y / x / aux accesses;
+// bit 3: no barriers.  A knocked-out operation sits behind a predicate that is false at run time but opaque to the
+// compiler, so that everything feeding it and depending on it stays in the instruction stream.
+#ifndef LPC_V2_KNOCK_MASK
+#define LPC_V2_KNOCK_MASK 0
+#endif
+static __device__ __forceinline__ bool v2_live(int bit) { return !(LPC_V2_KNOCK_MASK & bit) || lpc_opaque(0) != 0; }
+template <int R, bool INV>
+static __device__ __forceinline__ void v2_dft(real2* v) {
+  if (v2_live(1)) Dft<R, INV>::run(v);
+}
+static __device__ __forceinline__ void v2_lds_st(real2* s, int slot, real2 v) {
+  if (v2_live(2)) s[slot] = v;
+}
+static __device__ __forceinline__ real2 v2_lds_ld(const real2* s, int slot) {
+  return v2_live(2) ? s[slot] : make_real2((real)slot, (real)1.);
+}
+static __device__ __forceinline__ void v2_barrier() {
+  if (v2_live(8)) __syncthreads();
+}
+
 template <class P>
 struct GdV2 {
   static constexpr int M = P::n, R = P::radix(0), NB = P::n / P::radix(0), L = P::nst;
@@ -73,9 +96,9 @@ static __device__ __forceinline__ void v2_load_tangle_first(real2* s, const real
     const real2 od = cmul_conj(d, t);
     v[m] = make_real2(e.x - od.y, e.y + od.x);
   }
-  Dft<R, true>::run(v);
+  v2_dft<R, true>(v);
 #pragma unroll
-  for (int m = 0; m < R; ++m) s[lds_slot<SK>(j * R + m)] = v[m];
+  for (int m = 0; m < R; ++m) v2_lds_st(s, lds_slot<SK>(j * R + m), v[m]);
 }
 
 // ---- stage twiddles, loaded ONE STAGE AHEAD ------------------------------------------------------------------------
@@ -85,16 +108,20 @@ static __device__ __forceinline__ void v2_load_tangle_first(real2* s, const real
 // (profiles/r05_notes.md).  Here the base powers of stage ST + 1 are requested while stage ST still computes.
 // v2_tw_apply is twiddle_mul's arithmetic on the loaded values: same products in the same order.
 template <class P, int ST>
-static __device__ __forceinline__ void v2_tw_load(const real2* LPC_RESTRICT tw, int j, real2* w) {
-  constexpr int R = GdV2<P>::R, NS = P::ns(ST), STEP = P::n / (NS * R);
-  // (an opaque copy of the lane index: the inverse and the forward transform request the same table entries, and the
-  // compiler would rather keep the eight 64-bit addresses alive -- spilled -- across a transform than recompute them)
-  const int q = (lpc_opaque(j) % NS) * STEP;
-  w[0] = tw[q]; w[1] = tw[2 * q]; w[2] = tw[4 * q];
-  if (R == 16) w[3] = tw[8 * q];
+static __device__ __forceinline__ void v2_tw_load(const real2* LPC_RESTRICT tws, int j, real2* w) {
+  constexpr int R = GdV2<P>::R, NB = P::n / R;
+  // two 16-byte loads, contiguous across the wave, from the lane-ordered table (lpc_sfft.h: SPlan::tws_off; the values
+  // are the table entries twiddle_mul() gathers).  An opaque copy of the lane index: the inverse and the forward transform
+  // request the same entries, and the compiler would rather keep the addresses alive -- spilled -- than recompute them.
+  const real2* b = tws + P::tws_off(ST) + 2 * lpc_opaque(j);
+  const real4_t lo = *(const real4_t*)b, hi = *(const real4_t*)(b + 2 * NB);
+  w[0] = make_real2(lo.x, lo.y); w[1] = make_real2(lo.z, lo.w);
+  w[2] = make_real2(hi.x, hi.y);
+  if (R == 16) w[3] = make_real2(hi.z, hi.w);
 }
 template <int R, bool INV>
 static __device__ __forceinline__ void v2_tw_apply(real2* v, const real2* wb) {
+  if (!v2_live(1)) { v[1].x += wb[0].x + wb[1].x + wb[2].x + wb[R == 16 ? 3 : 0].x; return; }
   real2 w[16];
   w[1] = wb[0]; w[2] = wb[1]; w[4] = wb[2];
   if (R == 16) w[8] = wb[3];
@@ -114,14 +141,14 @@ static __device__ __forceinline__ void v2_mid_stage(real2* s, int j, const real2
   constexpr int R = GdV2<P>::R, NB = GdV2<P>::NB, NS = P::ns(ST);
   real2 v[R];
 #pragma unroll
-  for (int m = 0; m < R; ++m) v[m] = s[lds_slot<SK>(j + NB * m)];
+  for (int m = 0; m < R; ++m) v[m] = v2_lds_ld(s, lds_slot<SK>(j + NB * m));
   v2_tw_apply<R, INV>(v, wb);
-  Dft<R, INV>::run(v);
+  v2_dft<R, INV>(v);
   const int oi = (j / NS) * NS * R + j % NS;
-  __syncthreads();
+  v2_barrier();
 #pragma unroll
-  for (int m = 0; m < R; ++m) s[lds_slot<SK>(oi + m * NS)] = v[m];
-  __syncthreads();
+  for (int m = 0; m < R; ++m) v2_lds_st(s, lds_slot<SK>(oi + m * NS), v[m]);
+  v2_barrier();
 }
 
 // stages 1 .. L - 2 of a transform, in the tile.  On entry wb holds the base twiddles of stage 1, on exit those of
@@ -148,9 +175,9 @@ static __device__ __forceinline__ void v2_final_stage(const real2* s, const real
   real2 wn[4];
   if (NEXT) v2_tw_load<P, 1>(tw, j, wn);
 #pragma unroll
-  for (int m = 0; m < R; ++m) v[m] = s[lds_slot<SK>(j + NB * m)];
+  for (int m = 0; m < R; ++m) v[m] = v2_lds_ld(s, lds_slot<SK>(j + NB * m));
   v2_tw_apply<R, INV>(v, wb);
-  Dft<R, INV>::run(v);
+  v2_dft<R, INV>(v);
   if (NEXT) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) wb[i] = wn[i];
@@ -161,10 +188,10 @@ static __device__ __forceinline__ void v2_final_stage(const real2* s, const real
 template <class P, int SK>
 static __device__ __forceinline__ void v2_first_fwd(real2* s, int j, real2* r) {
   constexpr int R = GdV2<P>::R;
-  Dft<R, false>::run(r);
+  v2_dft<R, false>(r);
 #pragma unroll
-  for (int m = 0; m < R; ++m) s[lds_slot<SK>(j * R + m)] = r[m];
-  __syncthreads();
+  for (int m = 0; m < R; ++m) v2_lds_st(s, lds_slot<SK>(j * R + m), r[m]);
+  v2_barrier();
 }
 
 // X = FFT_M(z) (elements j + NB m in x[]) -> half spectrum of the real row (see untangle_half_store) -> o[0 .. M].
@@ -180,13 +207,13 @@ static __device__ __forceinline__ void v2_untangle_store(real2* s, const real2* 
 #pragma unroll
   for (int m = 0; m < R / 2; ++m) tw[m] = twW[j + NB * m];
 #pragma unroll
-  for (int m = 0; m < R; ++m) s[lds_slot<SK>(j + NB * m)] = x[m];
-  __syncthreads();
+  for (int m = 0; m < R; ++m) v2_lds_st(s, lds_slot<SK>(j + NB * m), x[m]);
+  v2_barrier();
   real2 xm[R];
 #pragma unroll
   for (int m = 0; m < R; ++m) {
     const int km = (m == 0 && j == 0) ? 0 : M - j - NB * m;    // the DC bin pairs with itself
-    xm[m] = s[lds_slot<SK>(km)];
+    xm[m] = v2_lds_ld(s, lds_slot<SK>(km));
   }
 #pragma unroll
   for (int m = 0; m < R; ++m) {
@@ -209,20 +236,21 @@ template <int NT, int SK, class PL>
 __global__ __launch_bounds__(NT, 4) void k_gd_resid_v2(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                                const real2* LPC_RESTRICT Sin,
                                                                real2* LPC_RESTRICT Sout, const real* LPC_RESTRICT Y,
-                                                               FastDiv fdc, FastDiv fc) {
+                                                               FastDiv fdc, FastDiv fc, int stagger) {
   using P = typename PL::plan;
   constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB, L = GdV2<P>::L;
   static_assert(GdV2<P>::ok && NT == NB, "k_gd_resid_v2: one butterfly per lane and stage");
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
+  lpc_stagger(blockIdx.x + gridDim.x * blockIdx.y, stagger >> 16, stagger & 0xffff);
   const int j = LPC_TID(NT), u = (int)LPC_BX(g);
   const unsigned pl = LPC_BY(g);
   const int sr = wrap_add(g.sh + u, g.Hp / 2, g.Hp);
   real2 wb[4];
-  v2_tw_load<P, 1>(plan.tw, j, wb);
+  v2_tw_load<P, 1>(plan.tws, j, wb);
   v2_load_tangle_first<P, SK>(s, Sin + (long)pl * g.cplane + (long)sr * g.cpitch, twW, j);
-  __syncthreads();
-  v2_mid_chain<P, SK, true>(s, plan.tw, j, wb, std::make_integer_sequence<int, L - 2>{});
+  v2_barrier();
+  v2_mid_chain<P, SK, true>(s, plan.tws, j, wb, std::make_integer_sequence<int, L - 2>{});
   // the measurement row, in flight across the last inverse stage (across two stages it costs the registers that the
   // twiddle prefetch needs): padded pair i = j + NB m covers columns 2 i - sw, 2 i - sw + 1 of the frame; outside the
   // window the loads return zero (lpc_make_rsrc)
@@ -230,9 +258,10 @@ __global__ __launch_bounds__(NT, 4) void k_gd_resid_v2(PlaneGeom g, PL plan, con
                                     (unsigned)g.W * (unsigned)sizeof(real));
   real2 yy[R];
 #pragma unroll
-  for (int m = 0; m < R; ++m) yy[m] = lpc_buf_load2(yr, lpc_opaque((2 * (j + NB * m) - g.sw) * (int)sizeof(real)));
+  for (int m = 0; m < R; ++m)
+    yy[m] = !v2_live(4) ? make_real2((real)m, (real)j) : lpc_buf_load2(yr, lpc_opaque((2 * (j + NB * m) - g.sw) * (int)sizeof(real)));
   real2 v[R], r[R];
-  v2_final_stage<P, SK, true, true>(s, plan.tw, j, wb, v);
+  v2_final_stage<P, SK, true, true>(s, plan.tws, j, wb, v);
   // conv pair (j, m) is pair (j, m + R/2 mod R) of the shifted row: residual inside the window, zero outside
 #pragma unroll
   for (int m = 0; m < R; ++m) {
@@ -240,11 +269,11 @@ __global__ __launch_bounds__(NT, 4) void k_gd_resid_v2(PlaneGeom g, PL plan, con
     r[m] = (unsigned)(2 * (j + NB * m) - g.sw) < (unsigned)g.W ? make_real2(z.x - yy[m].x, z.y - yy[m].y)
                                                                 : make_real2((real)0., (real)0.);
   }
-  __syncthreads();
+  v2_barrier();
   v2_first_fwd<P, SK>(s, j, r);
-  v2_mid_chain<P, SK, false>(s, plan.tw, j, wb, std::make_integer_sequence<int, L - 2>{});
-  v2_final_stage<P, SK, false, false>(s, plan.tw, j, wb, v);
-  __syncthreads();
+  v2_mid_chain<P, SK, false>(s, plan.tws, j, wb, std::make_integer_sequence<int, L - 2>{});
+  v2_final_stage<P, SK, false, false>(s, plan.tws, j, wb, v);
+  v2_barrier();
   v2_untangle_store<P, SK>(s, twW, j, v, Sout + (long)pl * g.cplane + (long)(g.sh + u) * g.cpitch);
 }
 
@@ -256,7 +285,8 @@ template <int NT, int SK, class PL, int KIND, int FIRST>
 __global__ __launch_bounds__(NT, 4) void k_gd_update_fwd_v2(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                             const real2* LPC_RESTRICT Sin, real2* LPC_RESTRICT Sout,
                                                             real* LPC_RESTRICT X, real* LPC_RESTRICT AUX,
-                                                            const real* LPC_RESTRICT alpha, GdScalars pin, FastDiv fc) {
+                                                            const real* LPC_RESTRICT alpha, GdScalars pin, FastDiv fc,
+                                                            int stagger) {
   using P = typename PL::plan;
   constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB, L = GdV2<P>::L, H = R / 2;
   static_assert(GdV2<P>::ok && NT == NB, "k_gd_update_fwd_v2: one butterfly per lane and stage");
@@ -265,14 +295,15 @@ __global__ __launch_bounds__(NT, 4) void k_gd_update_fwd_v2(PlaneGeom g, PL plan
   p.kind = KIND; p.first = FIRST; p.split = 0;
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
+  lpc_stagger(blockIdx.x + gridDim.x * blockIdx.y, stagger >> 16, stagger & 0xffff);
   const int j = LPC_TID(NT), u = (int)LPC_BX(g);
   const unsigned pl = LPC_BY(g);
   const int sr = wrap_add(g.sh + u, g.Hp / 2, g.Hp);
   real2 wb[4];
-  v2_tw_load<P, 1>(plan.tw, j, wb);
+  v2_tw_load<P, 1>(plan.tws, j, wb);
   v2_load_tangle_first<P, SK>(s, Sin + (long)pl * g.cplane + (long)sr * g.cpitch, twW, j);
-  __syncthreads();
-  v2_mid_chain<P, SK, true>(s, plan.tw, j, wb, std::make_integer_sequence<int, L - 2>{});
+  v2_barrier();
+  v2_mid_chain<P, SK, true>(s, plan.tws, j, wb, std::make_integer_sequence<int, L - 2>{});
   const real al = alpha[pl - fd_div(pl, fc) * fc.d];
   // the rows of x and of the auxiliary state as range-checked buffers: loads outside the window return zero, stores
   // outside it are dropped (lpc_make_rsrc); padded pair i = j + NB m covers columns 2 i - sw, 2 i - sw + 1
@@ -286,9 +317,9 @@ __global__ __launch_bounds__(NT, 4) void k_gd_update_fwd_v2(PlaneGeom g, PL plan
   auto offs = [&](int m) { return lpc_opaque((2 * (j + NB * m) - g.sw) * (int)sizeof(real)); };
   auto loads = [&](int m0, real2* xx, real2* aa) {
 #pragma unroll
-    for (int m = 0; m < H; ++m) xx[m] = lpc_buf_load2(xr, offs(m0 + m));
+    for (int m = 0; m < H; ++m) xx[m] = !v2_live(4) ? make_real2((real)m, (real)j) : lpc_buf_load2(xr, offs(m0 + m));
 #pragma unroll
-    for (int m = 0; m < H; ++m) aa[m] = rd ? lpc_buf_load2(ar, offs(m0 + m)) : make_real2((real)0., (real)0.);
+    for (int m = 0; m < H; ++m) aa[m] = (rd && v2_live(4)) ? lpc_buf_load2(ar, offs(m0 + m)) : make_real2((real)0., (real)0.);
   };
   // gradient pair (j, m + R/2 mod R) belongs to padded pair (j, m): update inside the window, zero outside
   auto update = [&](int m0, const real2* xx, const real2* aa) {
@@ -299,24 +330,24 @@ __global__ __launch_bounds__(NT, 4) void k_gd_update_fwd_v2(PlaneGeom g, PL plan
       xs.x = gd_update_val<KIND, 0>(xx[m].x, aa[m].x, gr.x, al, p, an.x);
       xs.y = gd_update_val<KIND, 0>(xx[m].y, aa[m].y, gr.y, al, p, an.y);
       const int off = offs(m0 + m);
-      if (wr) lpc_buf_store2(ar, off, an);
-      lpc_buf_store2(xr, off, xs);
+      if (wr && v2_live(4)) lpc_buf_store2(ar, off, an);
+      if (v2_live(4)) lpc_buf_store2(xr, off, xs);
       r[m0 + m] = (unsigned)off < rowb ? xs : make_real2((real)0., (real)0.);
     }
   };
   real2 x0[H], a0[H], x1[H], a1[H];
   loads(0, x0, a0);
-  v2_final_stage<P, SK, true, true>(s, plan.tw, j, wb, v);
+  v2_final_stage<P, SK, true, true>(s, plan.tws, j, wb, v);
   LPC_SCHED_FENCE();
   loads(H, x1, a1);
   LPC_SCHED_FENCE();
   update(0, x0, a0);
   update(H, x1, a1);
-  __syncthreads();
+  v2_barrier();
   v2_first_fwd<P, SK>(s, j, r);
-  v2_mid_chain<P, SK, false>(s, plan.tw, j, wb, std::make_integer_sequence<int, L - 2>{});
-  v2_final_stage<P, SK, false, false>(s, plan.tw, j, wb, v);
-  __syncthreads();
+  v2_mid_chain<P, SK, false>(s, plan.tws, j, wb, std::make_integer_sequence<int, L - 2>{});
+  v2_final_stage<P, SK, false, false>(s, plan.tws, j, wb, v);
+  v2_barrier();
   v2_untangle_store<P, SK>(s, twW, j, v, Sout + (long)pl * g.cplane + (long)(g.sh + u) * g.cpitch);
 }
 

@@ -35,6 +35,20 @@ struct PlaneGeom {
 #define LPC_BY(g) ((g).rev ? gridDim.y - 1u - blockIdx.y : blockIdx.y)
 #define LPC_BZ(g) ((g).rev ? gridDim.z - 1u - blockIdx.z : blockIdx.z)
 
+// ---- phase stagger of the first generation of workgroups ---------------------------------------------------------------
+// A row kernel's workgroup is load -> transform(s) -> store, and every workgroup of a launch does the same amount of
+// work: the ~1300 workgroups that start together at the top of a launch stay in step, generation after generation (a slot
+// is refilled when its workgroup ends, i.e. in step too) -- the whole chip loads, then the whole chip computes with HBM
+// idle, then the whole chip stores.  The kernel then takes memory time PLUS compute time instead of the larger of the two
+// (knock-out timings, profiles/r05_notes.md: removing the butterflies changes nothing, removing 50 % of the bytes removes
+// exactly their HBM time).  Fix: the workgroups of the first generation that share a CU start `layer * units` sleep units
+// apart (layer = which of the CU's slots the block fills: linear block id / (8 XCDs x 32 CUs)), one fifth of a workgroup's
+// lifetime each; later generations inherit the offsets.  Costs the first generation's sleep once per launch.
+//   lpc_stagger(linear block id, slots per CU, units): call at the top of the kernel (all lanes).
+static __device__ __forceinline__ void lpc_stagger(unsigned bid, int slots, int units) {
+  if (units > 0 && bid < 256u * (unsigned)slots) lpc_sleep_units((int)(bid >> 8) * units);
+}
+
 static __device__ __forceinline__ int wrap_add(int i, int d, int n) {  // (i + d) mod n for |d| <= n
   int r = i + d;
   if (r >= n) r -= n;
@@ -221,41 +235,18 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, PL plan,
 // row passes are bound by compute that two workgroups per CU cannot hide (profiles/r01b_notes.md).
 // blockIdx.x = 2*row + array.  `plan` has length M, `twW` is the length-Wp table.  Needs Wp even.
 // s[] holds Z = FFT_M(z) in natural order; writes X[0 .. M] (M = Wp/2) to o
-// EH > 0 (= EMAX / 2 + 1 of the calling kernel): the lane's bins are walked in an unrolled loop with the twiddles and both
-// tile reads of every bin requested before the first product (round 5: inside the run-time loop each twiddle was a load,
-// a `s_waitcnt vmcnt(0)` and a store -- five L2 round trips in a row at the end of every forward row)
-template <int NT, int SK, int EH = 0>
+template <int NT, int SK>
 static __device__ __forceinline__ void untangle_half_store(const real2* s, int M, const real2* LPC_RESTRICT twW,
                                                             real2* LPC_RESTRICT o, int tid) {
-  auto emit = [&](int k, real2 zk, real2 zm, real2 w) {
+  for (int k = tid; k <= M / 2; k += NT) {
     const int km = M - k;
+    const real2 zk = s[lds_slot<SK>(k)];
+    const real2 zm = s[lds_slot<SK>(k == 0 ? 0 : km)];
     const real ex = (real)0.5 * (zk.x + zm.x), ey = (real)0.5 * (zk.y - zm.y);
     const real2 od = make_real2((real)0.5 * (zk.y + zm.y), (real)-0.5 * (zk.x - zm.x));   // O
-    const real2 wo = cmul(w, od);
+    const real2 wo = cmul(twW[k], od);
     o[k] = make_real2(ex + wo.x, ey + wo.y);
     if (k != km) o[km] = make_real2(ex - wo.x, wo.y - ey);
-  };
-  if constexpr (EH > 0) {
-    real2 w[EH], zk[EH], zm[EH];
-#pragma unroll
-    for (int q = 0; q < EH; ++q) {
-      const int k = tid + q * NT;
-      w[q] = twW[k <= M / 2 ? k : 0];
-    }
-#pragma unroll
-    for (int q = 0; q < EH; ++q) {
-      const int k = tid + q * NT, kc = k <= M / 2 ? k : 0;
-      zk[q] = s[lds_slot<SK>(kc)];
-      zm[q] = s[lds_slot<SK>(kc == 0 ? 0 : M - kc)];
-    }
-#pragma unroll
-    for (int q = 0; q < EH; ++q) {
-      const int k = tid + q * NT;
-      if (k <= M / 2) emit(k, zk[q], zm[q], w[q]);
-    }
-  } else {
-    for (int k = tid; k <= M / 2; k += NT)
-      emit(k, s[lds_slot<SK>(k)], s[lds_slot<SK>(k == 0 ? 0 : M - k)], twW[k]);
   }
 }
 
@@ -270,7 +261,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_half(PlaneGeom g, PL plan, const re
   const real2* a2 = (const real2*)((arr ? B : A) + pl * g.rplane + (long)row * g.rpitch);
   auto src = [&](int i, int) { return a2[i]; };
   fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
-  untangle_half_store<NT, SK, EMAX / 2 + 1>(s, g.Wp >> 1, twW, (arr ? SB : SA) + pl * g.cplane + (long)row * g.cpitch, tid);
+  untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, (arr ? SB : SA) + pl * g.cplane + (long)row * g.cpitch, tid);
 }
 
 // inverse: Z[k] = E' + i O',  Z[M-k] = conj(E') + i conj(O'),  E' = X[k] + conj X[M-k],
@@ -281,20 +272,13 @@ template <int NT, int EMAX, int SK>
 static __device__ __forceinline__ void tangle_half_load(real2* s, int M, const real2* LPC_RESTRICT twW,
                                                          const real2* LPC_RESTRICT in, int tid) {
   constexpr int EH = EMAX / 2 + 1;
-  real2 xk[EH], xm[EH], tw[EH];
+  real2 xk[EH], xm[EH];
 #pragma unroll
   for (int q = 0; q < EH; ++q) {          // every spectrum element is loaded once; all loads before the LDS writes
     const int k = tid + q * NT;
     xk[q] = make_real2((real)0., (real)0.);
     xm[q] = xk[q];
     if (k <= M / 2) { xk[q] = in[k]; xm[q] = in[M - k]; }
-  }
-  // ... the tangling twiddles too (round 5): read where they are used, each sat behind its own `s_waitcnt vmcnt(0)` --
-  // five L2 round trips in a row at the top of every inverse row
-#pragma unroll
-  for (int q = 0; q < EH; ++q) {
-    const int k = tid + q * NT;
-    tw[q] = twW[k <= M / 2 ? k : 0];
   }
 #pragma unroll
   for (int q = 0; q < EH; ++q) {
@@ -304,7 +288,7 @@ static __device__ __forceinline__ void tangle_half_load(real2* s, int M, const r
       if (k == 0) { a.y = (real)0.; b.y = (real)0.; }
       const real2 e = make_real2(a.x + b.x, a.y - b.y);            // E'
       const real2 d = make_real2(a.x - b.x, a.y + b.y);            // X[k] - conj X[M-k]
-      const real2 od = cmul_conj(d, tw[q]);                        // O'
+      const real2 od = cmul_conj(d, twW[k]);                       // O'
       s[lds_slot<SK>(k)] = make_real2(e.x - od.y, e.y + od.x);
       if (k != 0 && k != M - k) s[lds_slot<SK>(M - k)] = make_real2(e.x + od.y, od.x - e.y);
     }
@@ -473,7 +457,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows_half(PlaneGeom g, PL plan, con
                       (c + 1 >= 0 && c + 1 < src.ncols) ? a[c + 1] : (real)0.);
   };
   fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, in, LdsNatural{});
-  untangle_half_store<NT, SK, EMAX / 2 + 1>(s, g.Wp >> 1, twW, S + pl * g.cplane + (long)(src.out_row0 + r) * g.cpitch, tid);
+  untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, S + pl * g.cplane + (long)(src.out_row0 + r) * g.cpitch, tid);
 }
 
 // ---- inverse, ADMM: spectra SA, SB -> real arrays A, B (no shift, padded), two rows of one array per transform -------
@@ -1691,7 +1675,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_half_x(PlaneGeom g, AdmmScalars p, 
     const real2* a2 = (const real2*)(Rsp + o_row);
     auto src = [&](int i, int) { return a2[i]; };
     fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{});
-    untangle_half_store<NT, SK, EMAX / 2 + 1>(s, g.Wp >> 1, twW, SA + pl * g.cplane + (long)gr * g.cpitch, tid);
+    untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, SA + pl * g.cplane + (long)gr * g.cpitch, tid);
     return;
   }
   {
@@ -1714,7 +1698,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_half_x(PlaneGeom g, AdmmScalars p, 
   }
   __syncthreads();
   fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
-  untangle_half_store<NT, SK, EMAX / 2 + 1>(s, g.Wp >> 1, twW, SB + pl * g.cplane + (long)gr * g.cpitch, tid);
+  untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, SB + pl * g.cplane + (long)gr * g.cpitch, tid);
 }
 
 // ---- paired forward rows with the X half computed on the fly (narrow frames: C1 / C4, 760 x 1014) ---------------

@@ -27,7 +27,10 @@ static inline PlaneGeom geom_rev(const Engine* e, bool rev) {   // the launch's 
 // ============================================================================== rows ==
 #if LPC_MOD_ROW_KIND != 0
 typedef SPlan<LPC_MOD_ROW_RAD> RowP;
-typedef SPlanArg<RowP> RowPA;
+#ifndef LPC_MOD_TW_LANE
+#define LPC_MOD_TW_LANE 1      // row kernels: radix-8 / -16 stage twiddles from the lane-ordered table (lpc_sfft.h); 0: gathered
+#endif
+typedef SPlanArg<RowP, LPC_MOD_TW_LANE != 0> RowPA;
 static constexpr int RNT = LPC_MOD_ROW_NT, REM = LPC_MOD_ROW_EM;
 static constexpr int RSK = LPC_MOD_ROW_SK;       // LDS layout of the row tile: LPC_LAY_NONE / _SKEW8 / _XOR16 (lpc_fft.h)
 static_assert(RSK != LPC_LAY_SKEW8 || RowP::skew_ok(), "this row plan does not keep the LDS skew affine");
@@ -37,7 +40,7 @@ static const size_t kRowSmem = LPC_ROW_SMEM_BYTES(RowP::n, RSK);
 #endif
 
 #if LPC_MOD_ROW_KIND == LPC_ROWS_HALF
-static RowPA row_arg(const Engine* e) { return splan_arg<RowP>(e->planWh); }
+static RowPA row_arg(const Engine* e) { return splan_arg<RowP, LPC_MOD_TW_LANE != 0>(e->planWh, e->tws_row); }
 
 static int m_rows_fwd_single(Engine* e, const RealSrc* src, real2* S, int nplanes, int kid) {
   return launch_k(e, kid, k_rfwd_rows_half<RNT, REM, RSK, RowPA>, dim3(src->nrows, nplanes), RNT, kRowSmem, e->g,
@@ -101,9 +104,10 @@ static int m_gd_rows_mid(Engine* e) {
 #ifndef LPC_DOUBLE
   if constexpr (GdV2<RowP>::ok) {
     if (e->gd_v2)     // second form (lpc_gd_v2_kernels.h): one-radix plan, M / R lanes per row
-      return launch_k(e, LPC_K_ROW_INV, k_gd_resid_v2<GdV2<RowP>::NB, V2SK, RowPA>, dim3(g.H, e->P), GdV2<RowP>::NB, kV2Smem,
+      return launch_k(e, LPC_K_ROW_INV, k_gd_resid_v2<GdV2<RowP>::NB, V2SK, RowPA>, dim3(g.H, e->P), GdV2<RowP>::NB, kV2Smem + (size_t)std::max(0, e->opt.lds_pad),
                       geom_rev(e, e->opt.gd_rev & 1), row_arg(e), e->planW.tw, (const real2*)e->S, e->S2,
-                      (const real*)e->Y, make_fastdiv((unsigned)g.DC), make_fastdiv((unsigned)g.C));
+                      (const real*)e->Y, make_fastdiv((unsigned)g.DC), make_fastdiv((unsigned)g.C),
+                      (5 << 16) | (e->opt.stagger < 0 ? 0 : e->opt.stagger));
   }
   if constexpr (LdsTw<RowP>::ok(RNT)) {
     // persistent workgroups, the next row in flight (k_rinv_gd_mid_half_pf); 8-byte accesses to y need the pair geometry
@@ -133,9 +137,9 @@ static int m_gd_rows_update_fwd(Engine* e, const GdScalars* sc, const real* alph
   if constexpr (GdV2<RowP>::ok) {
     if (e->gd_v2) {
       auto go = [&](auto kernel) {
-        return launch_k(e, LPC_K_SPATIAL, kernel, dim3(g.H, e->P), GdV2<RowP>::NB, kV2Smem, geom_rev(e, e->opt.gd_rev & 2),
+        return launch_k(e, LPC_K_SPATIAL, kernel, dim3(g.H, e->P), GdV2<RowP>::NB, kV2Smem + (size_t)std::max(0, e->opt.lds_pad), geom_rev(e, e->opt.gd_rev & 2),
                         row_arg(e), e->planW.tw, (const real2*)e->S2, e->S, e->gx, e->gaux, alpha, *sc,
-                        make_fastdiv((unsigned)g.C));
+                        make_fastdiv((unsigned)g.C), (4 << 16) | (e->opt.stagger < 0 ? 0 : e->opt.stagger));
       };
       constexpr int NB = GdV2<RowP>::NB;
       if (sc->kind == 2) return sc->first ? go(k_gd_update_fwd_v2<NB, V2SK, RowPA, 2, 1>) : go(k_gd_update_fwd_v2<NB, V2SK, RowPA, 2, 0>);
@@ -152,7 +156,7 @@ static int m_gd_rows_update_fwd(Engine* e, const GdScalars* sc, const real* alph
 #endif   // half rows
 
 #if LPC_MOD_ROW_KIND == LPC_ROWS_PAIRED   // ADMM only: two real rows per complex transform of length Wp
-static RowPA row_arg(const Engine* e) { return splan_arg<RowP>(e->planW); }
+static RowPA row_arg(const Engine* e) { return splan_arg<RowP, LPC_MOD_TW_LANE != 0>(e->planW, e->tws_row); }
 
 static int m_admm_rows_fwd(Engine* e) {
   const PlaneGeom& g = e->g;

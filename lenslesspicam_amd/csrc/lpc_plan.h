@@ -149,6 +149,10 @@ struct EngineOpts {
   int gd_no_fuse_fwd = 0;     // gradient-descent update without the next iteration's forward rows
   int gd_v2 = 1;              // gradient-descent family, half-length rows on a one-radix plan (4096 = 16.16.16, 512 = 8.8.8) and
                               // even window offset / width: the fused row kernels of lpc_gd_v2_kernels.h (0: the first form)
+  int stagger = -1;           // sleep units (2048 cycles) between the start times of the workgroups of a launch's first
+                              // generation that share a CU (lpc_kernels.h: lpc_stagger); -1: the kernel's default, 0: off
+  int lds_pad = 0;            // tuning: bytes of LDS a fused gradient-descent row workgroup claims beyond its tile (fewer workgroups
+                              // per CU: the last, partly filled generation of a launch is shorter)
   int rpitch_pad = 0;         // floats added to the pitch of the padded real planes (tuning: a pitch of 2^k bytes puts the same
                               // column of every row on the same HBM channel)
   int row_pf = 0;             // ADMM inverse rows (half-length, float32, radices 8 / 16): persistent workgroups, N per CU, with
@@ -225,6 +229,8 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "row_lay") o.row_lay = (int)iv;
       else if (k == "gd_no_fuse_fwd") o.gd_no_fuse_fwd = (int)iv;
       else if (k == "gd_v2") o.gd_v2 = (int)iv;
+      else if (k == "stagger") o.stagger = (int)iv;
+      else if (k == "lds_pad") o.lds_pad = (int)iv;
       else if (k == "row_nt") o.row_nt = (int)iv;
       else if (k == "row_pf") o.row_pf = (int)iv;
       else if (k == "rpitch_pad") o.rpitch_pad = (int)iv;

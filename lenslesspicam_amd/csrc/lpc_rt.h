@@ -65,6 +65,7 @@ struct lpc_rsrc { char* base; unsigned bytes; };
 static inline lpc_rsrc lpc_make_rsrc(const void* base, unsigned bytes) { lpc_rsrc r; r.base = (char*)base; r.bytes = bytes; return r; }
 static inline int lpc_opaque(int x) { return x; }
 #define LPC_SCHED_FENCE() ((void)0)
+static inline void lpc_sleep_units(int) {}
 
 typedef void* lpcStream_t;
 typedef int lpcError_t;
@@ -141,6 +142,10 @@ static __device__ __forceinline__ lpc_rsrc lpc_make_rsrc(const void* base, unsig
 static __device__ __forceinline__ int lpc_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 // nothing is scheduled across this point (keeps a batch of loads behind the arithmetic whose registers it needs)
 #define LPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+// the wave sleeps n x 2048 cycles (s_sleep 32, n times; about 0.9 us each at 2.3 GHz) -- see lpc_stagger()
+static __device__ __forceinline__ void lpc_sleep_units(int n) {
+  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
+}
 typedef hipStream_t lpcStream_t;
 typedef hipError_t lpcError_t;
 #define lpcSuccess hipSuccess
@@ -182,6 +187,7 @@ static inline int cu_count() {     // compute units of the current device (persi
 #ifdef LPC_DOUBLE
 typedef double real;
 typedef double2 real2;
+struct real4_t { double x, y, z, w; };
 #define make_real2 make_double2
 #define LPC_REAL_NAME "float64"
 static __host__ __device__ __forceinline__ real rmax(real a, real b) { return fmax(a, b); }
@@ -191,6 +197,7 @@ static __host__ __device__ __forceinline__ real rsqrt_of(real a) { return sqrt(a
 #else
 typedef float real;
 typedef float2 real2;
+typedef float4 real4_t;     // four reals in one 16-byte access
 #define make_real2 make_float2
 #define LPC_REAL_NAME "float32"
 static __host__ __device__ __forceinline__ real rmax(real a, real b) { return fmaxf(a, b); }

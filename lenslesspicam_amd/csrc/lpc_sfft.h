@@ -36,6 +36,18 @@ struct SPlan {
     }
     return true;
   }
+  // Stage twiddles in LANE ORDER (round 5; SPlanArg::tws): for every stage st >= 1 and butterfly j < n / radix(st) the base
+  // powers w^q, w^2q, w^4q, w^8q (q = (j % ns(st)) * n / (ns(st) radix(st)); radices 8 and 16) that twiddle_mul() gathers
+  // from the n-entry table, stored [st][h][j] as pairs {w^q, w^2q} (h = 0) and {w^4q, w^8q} (h = 1): a lane's two 16-byte
+  // loads per stage are contiguous across the wave (8 cache lines per instruction) where the gathers tw[q], tw[2q], tw[4q],
+  // tw[8q] touch up to 32 lines each -- measured on the row kernels' access pattern, 32 such gathers per lane cost as
+  // much as the rows' HBM traffic itself (tools/probe/row_pattern.hip, profiles/r05_notes.md).
+  static __host__ __device__ constexpr int tws_off(int st) {      // offset of stage st's block, in real2
+    int o = 0;
+    for (int i = 1; i < st; ++i) o += 4 * (n / radix(i));
+    return o;
+  }
+  static constexpr int tws_size = tws_off(nst);
   static bool matches(const Fft1dPlan& p) {             // host: is this the plan build_plan() made?
     if (p.n != n || p.nst != nst) return false;
     for (int st = 0; st < nst; ++st)
@@ -45,16 +57,22 @@ struct SPlan {
 };
 
 // what a kernel receives instead of an Fft1dPlan: only the twiddle table travels at run time
-template <class P>
+// LANE: the kernel takes the radix-8 / -16 stage twiddles of its row tiles (BT == 1) from `tws`, the lane-ordered table --
+// a property of the TYPE (the row kernels of a plan module), so that a kernel holds one of the two code paths, not both
+// (with a run-time choice between them the 512-lane row kernels grew from 64 to 122 VGPRs: two workgroups per CU, +35 %)
+template <class P, bool LANE = false>
 struct SPlanArg {
   using plan = P;
   static constexpr int n = P::n;
+  static constexpr bool lane_tw = LANE;
   const real2* tw;   // exp(-2 pi i q / n), n entries (the table of the Fft1dPlan this replaces)
+  const real2* tws;  // LANE: the stage twiddles in lane order (SPlan::tws_off)
 };
-template <class P>
-static inline SPlanArg<P> splan_arg(const Fft1dPlan& p) {
-  SPlanArg<P> a;
+template <class P, bool LANE = false>
+static inline SPlanArg<P, LANE> splan_arg(const Fft1dPlan& p, const real2* tws = nullptr) {
+  SPlanArg<P, LANE> a;
   a.tw = p.tw;
+  a.tws = tws;
   return a;
 }
 
@@ -62,8 +80,8 @@ static inline SPlanArg<P> splan_arg(const Fft1dPlan& p) {
 // workgroup): each lane reads the same few powers in every transform of its kernel, and as global loads those were
 // most of a column kernel's memory instructions (C4's 540-point middle: 136 of 204 loads; 0.651 -> 0.590 ms).  The
 // first twiddle is read after the tile fill's barrier (stage 0 of a Stockham pass has none), so no extra barrier.
-template <int NT, class P>
-static __device__ __forceinline__ SPlanArg<P> twiddles_to_lds(SPlanArg<P> pa, real2* dst, int tid) {
+template <int NT, class P, bool LANE>
+static __device__ __forceinline__ SPlanArg<P, LANE> twiddles_to_lds(SPlanArg<P, LANE> pa, real2* dst, int tid) {
   for (int q = tid; q < P::n; q += NT) dst[q] = pa.tw[q];
   pa.tw = dst;
   return pa;
@@ -72,11 +90,13 @@ template <int NT>
 static __device__ __forceinline__ Fft1dPlan twiddles_to_lds(const Fft1dPlan& p, real2*, int) { return p; }
 
 template <class T> struct is_static_plan : std::false_type {};
-template <class P> struct is_static_plan<SPlanArg<P>> : std::true_type {};
+template <class P, bool LANE> struct is_static_plan<SPlanArg<P, LANE>> : std::true_type {};
 
 // ---- one stage, everything but tid and the pointers known at compile time ------------------------------------
-template <class P, int ST, int NT, int BT, bool INV, int SKEW>
-static __device__ __forceinline__ void sfft_stage(real2* s, const real2* LPC_RESTRICT tw, int tid) {
+// LANE (SPlanArg::lane_tw): row tiles (BT == 1) take the twiddles of radix-8 / -16 stages from tws, the lane-ordered table
+template <class P, int ST, int NT, int BT, bool INV, int SKEW, bool LANE = false>
+static __device__ __forceinline__ void sfft_stage(real2* s, const real2* LPC_RESTRICT tw, int tid,
+                                                   const real2* LPC_RESTRICT tws = nullptr) {
   constexpr int R = P::radix(ST), N = P::n, NS = P::ns(ST);
   constexpr int NB = N / R, NWORK = NB * BT, MAXB = (NWORK + NT - 1) / NT;
   constexpr bool GUARD = (NWORK % NT) != 0;
@@ -96,7 +116,8 @@ static __device__ __forceinline__ void sfft_stage(real2* s, const real2* LPC_RES
       const int rb = lds_slot<SKEW>(w);
 #pragma unroll
       for (int m = 0; m < R; ++m) v[b][m] = RAFF ? s[rb + m * RS] : s[lds_slot<SKEW>(w + m * IST)];
-      if (NS > 1) twiddle_mul<R, INV>(v[b], tw, k * TWSTEP);
+      if constexpr (LANE && NS > 1 && BT == 1 && (R == 8 || R == 16)) twiddle_mul_lane<R, INV>(v[b], tws + P::tws_off(ST), NB, j);
+      else if (NS > 1) twiddle_mul<R, INV>(v[b], tw, k * TWSTEP);
       Dft<R, INV>::run(v[b]);
       const int oi = (jq * NS * R + k) * BT + c;
       obase[b] = (WAFF || SKEW == LPC_LAY_SKEW8) ? lds_slot<SKEW>(oi) : oi;
@@ -121,10 +142,10 @@ static __device__ __forceinline__ void sfft_stage(real2* s, const real2* LPC_RES
   __syncthreads();
 }
 
-template <class P, int NT, int BT, bool INV, int SKEW, int FIRST, int... I>
+template <class P, int NT, int BT, bool INV, int SKEW, int FIRST, bool LANE = false, int... I>
 static __device__ __forceinline__ void sfft_stages(real2* s, const real2* LPC_RESTRICT tw, int tid,
-                                                    std::integer_sequence<int, I...>) {
-  (sfft_stage<P, FIRST + I, NT, BT, INV, SKEW>(s, tw, tid), ...);
+                                                    std::integer_sequence<int, I...>, const real2* LPC_RESTRICT tws = nullptr) {
+  (sfft_stage<P, FIRST + I, NT, BT, INV, SKEW, LANE>(s, tw, tid, tws), ...);
 }
 
 // first stage fused into the tile fill (see fft_first_stage_fused)
@@ -169,8 +190,9 @@ static __device__ __forceinline__ void sfft_first_fused(real2* s, int tid, Src& 
 }
 
 // last stage fused into the drain (see fft_last_stage_fused)
-template <class P, int NT, int BT, bool INV, int SKEW, class Dst>
-static __device__ __forceinline__ void sfft_last_fused(real2* s, const real2* LPC_RESTRICT tw, int tid, Dst& dst) {
+template <class P, int NT, int BT, bool INV, int SKEW, bool LANE = false, class Dst>
+static __device__ __forceinline__ void sfft_last_fused(real2* s, const real2* LPC_RESTRICT tw, int tid, Dst& dst,
+                                                        const real2* LPC_RESTRICT tws = nullptr) {
   constexpr int ST = P::nst - 1;
   constexpr int R = P::radix(ST), N = P::n, NS = P::ns(ST);
   constexpr int NB = N / R, NWORK = NB * BT, MAXB = (NWORK + NT - 1) / NT;
@@ -194,7 +216,8 @@ static __device__ __forceinline__ void sfft_last_fused(real2* s, const real2* LP
     if (!GUARD || w < NWORK) {
       const int j = w / BT, c = w % BT;
       const int jq = j / NS, k = j % NS;
-      if (NS > 1) twiddle_mul<R, INV>(v[b], tw, k * TWSTEP);
+      if constexpr (LANE && NS > 1 && BT == 1 && (R == 8 || R == 16)) twiddle_mul_lane<R, INV>(v[b], tws + P::tws_off(ST), NB, j);
+      else if (NS > 1) twiddle_mul<R, INV>(v[b], tw, k * TWSTEP);
       Dft<R, INV>::run(v[b]);
       const int oi = jq * NS * R + k;
 #pragma unroll
@@ -325,8 +348,8 @@ static __device__ __forceinline__ void sfft_last_fused_h(real2* s, const LdsTw<P
 // EMAX must be n * BT / NT rounded up (the kernels' launch tables guarantee it); BT is passed as a run-time value for
 // source compatibility but MUST equal the compile-time SBT the kernel was instantiated for.
 template <int NT, int EMAX, bool INV, int SKEW, bool SRC_LDS, bool FUSE1 = false, bool FUSEL = false, int SBT = 1,
-          class P, class Src, class Dst, class Fix = NoFix>
-static __device__ __forceinline__ void fft_tile(real2* s, const SPlanArg<P>& pa, int /*BT*/, FastDiv /*btdiv*/, int tid,
+          class P, bool LANE, class Src, class Dst, class Fix = NoFix>
+static __device__ __forceinline__ void fft_tile(real2* s, const SPlanArg<P, LANE>& pa, int /*BT*/, FastDiv /*btdiv*/, int tid,
                                                  Src src, Dst dst, Fix fix = Fix()) {
   constexpr int BT = SBT;
   constexpr int NELEM = P::n * BT;
@@ -359,9 +382,9 @@ static __device__ __forceinline__ void fft_tile(real2* s, const SPlanArg<P>& pa,
   }
   constexpr int FIRST = fuse1 ? 1 : 0;
   constexpr int NMID = P::nst - FIRST - (fusel ? 1 : 0);
-  sfft_stages<P, NT, BT, INV, SKEW, FIRST>(s, tw, tid, std::make_integer_sequence<int, (NMID > 0 ? NMID : 0)>{});
+  sfft_stages<P, NT, BT, INV, SKEW, FIRST, LANE>(s, tw, tid, std::make_integer_sequence<int, (NMID > 0 ? NMID : 0)>{}, pa.tws);
   if constexpr (fusel) {
-    sfft_last_fused<P, NT, BT, INV, SKEW>(s, tw, tid, dst);
+    sfft_last_fused<P, NT, BT, INV, SKEW, LANE>(s, tw, tid, dst, pa.tws);
   } else if constexpr (!dst_lds) {
 #pragma unroll
     for (int k = 0; k < EM; ++k) {

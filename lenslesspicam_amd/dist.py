@@ -13,6 +13,8 @@ batches; ``reconstruct_sharded`` is the one-shot form and accepts a ready solver
 from __future__ import annotations
 
 import numpy as np
+import time
+
 import torch
 import torch.distributed as dist
 
@@ -53,8 +55,11 @@ class ShardedReconstructor:
         self._ev = None
 
     def gather_ms(self):
+        """milliseconds of the last call's collective (device events; wall clock when the engine's device is the CPU)"""
         if self._ev is None:
             return None
+        if isinstance(self._ev, float):
+            return self._ev
         self._ev[1].synchronize()
         return float(self._ev[0].elapsed_time(self._ev[1]))
 
@@ -86,9 +91,12 @@ class ShardedReconstructor:
         if dev.type == "cuda":
             self._ev = self._ev or (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             self._ev[0].record()
+        t0 = time.perf_counter()
         dist.all_gather_into_tensor(recv, send, group=self.group)            # the single collective of the path
         if dev.type == "cuda":
             self._ev[1].record()
+        else:
+            self._ev = (time.perf_counter() - t0) * 1e3
         if B == world * cap:
             # even shards: the receive buffer already is the batch (handed out as it is only on request: the other
             # buffer of the pair is overwritten by the next call, this one by the call after that)

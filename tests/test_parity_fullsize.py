@@ -65,6 +65,27 @@ PLAIN = {"hv_full": 1, "xi_full": 1}     # launch plan without the sensor-window
 
 
 @pytest.fixture(scope="module")
+def oracle64(c2_inputs):
+    """The float64 oracle's 12-MP runs, computed once per (solver, parameters, iterations) and shared by the tests that
+    compare against them (each costs ~1 minute of host time; the GPU suite has a 20-minute step)."""
+    psf, _, y = c2_inputs
+    cache = {}
+
+    def run(kind, n, **kw):
+        key = (kind, n, tuple(sorted(kw.items())))
+        if key not in cache:
+            o = (orc.ADMMOracle(psf, dtype=torch.float64, **kw) if kind == "admm"
+                 else orc.GDOracle(psf, kind=kind, dtype=torch.float64))
+            o.set_data(y)
+            out = o.apply(n).numpy()
+            cache[key] = (out, float((o.U != 0).double().mean()) if kind == "admm" else None)
+            del o
+        return cache[key]
+
+    return run
+
+
+@pytest.fixture(scope="module")
 def c2_tv_params(c2_inputs):
     """TV-active hyper-parameters at 12 MP.  The soft-threshold branch must be LIVE within 5 iterations: with a
     unit-energy 12-MP PSF the estimate is ~1e-3 and its finite differences ~1e-6, far below the default threshold
@@ -87,7 +108,7 @@ def c2_tv_params(c2_inputs):
 
 
 @pytest.mark.parametrize("tv_active", [True, False], ids=["tv_active", "defaults"])
-def test_c2_admm_5_iterations_vs_float64_oracle(c2_inputs, c2_tv_params, tv_active):
+def test_c2_admm_5_iterations_vs_float64_oracle(c2_inputs, c2_tv_params, oracle64, tv_active):
     psf, scene, y = c2_inputs
     psf_d, y_d = torch.from_numpy(psf).cuda(), torch.from_numpy(y).cuda()
     kw = c2_tv_params if tv_active else {}
@@ -97,13 +118,9 @@ def test_c2_admm_5_iterations_vs_float64_oracle(c2_inputs, c2_tv_params, tv_acti
     got = rec.apply(n_iter=5, disp_iter=None).cpu().numpy()
     del rec
     torch.cuda.empty_cache()
-    o = orc.ADMMOracle(psf, dtype=torch.float64, **kw)
-    o.set_data(y)
-    ref = o.apply(5).numpy()
+    ref, nz = oracle64("admm", 5, **kw)
     if tv_active:
-        nz = float((o.U != 0).double().mean())
         assert 0.02 < nz < 0.999, nz                           # the soft-threshold branch is live (and not trivial)
-    del o
     e = rel(got, ref)
     d = orc.psnr(got[0], scene) - orc.psnr(ref[0].astype(np.float32), scene)
     print(f"C2 ADMM {kw or 'defaults'}: rel err vs float64 oracle after 5 it = {e:.2e}, PSNR delta = {d:+.2e} dB")
@@ -111,7 +128,7 @@ def test_c2_admm_5_iterations_vs_float64_oracle(c2_inputs, c2_tv_params, tv_acti
     assert abs(d) <= 0.01, d
 
 
-def test_c2_float64_build_vs_float64_oracle(c2_inputs, c2_tv_params):
+def test_c2_float64_build_vs_float64_oracle(c2_inputs, c2_tv_params, oracle64):
     """Anchor of the long comparisons below: the float64 build (liblpc_f64.so) with xi and H V on the whole padded frame
     (options xi_full, hv_full: no sensor-window structure) against the float64 oracle, 12 MP, 5 iterations, TV-active."""
     psf, _, y = c2_inputs
@@ -121,9 +138,7 @@ def test_c2_float64_build_vs_float64_oracle(c2_inputs, c2_tv_params):
     got = rec.apply(n_iter=5, disp_iter=None).cpu().numpy()
     del rec
     torch.cuda.empty_cache()
-    o = orc.ADMMOracle(psf.astype(np.float64), dtype=torch.float64, **c2_tv_params)
-    o.set_data(y.astype(np.float64))
-    e = rel(got, o.apply(5).numpy())
+    e = rel(got, oracle64("admm", 5, **c2_tv_params)[0])      # (float32 inputs are exact in float64: the same oracle run)
     print(f"C2 ADMM float64 build vs float64 oracle after 5 it: {e:.2e}")
     assert e <= 1e-10, e
 
@@ -178,17 +193,14 @@ def test_c2_admm_100_iterations_in_one_call(c2_inputs, c2_tv_params, tv_active):
     assert abs(p["got"] - p["full"]) <= 0.01 and abs(p["got"] - p["f64"]) <= 0.01, p
 
 
-def test_c3_fista_12mp_vs_float64_oracle(c2_inputs):
+def test_c3_fista_12mp_vs_float64_oracle(c2_inputs, oracle64):
     psf, scene, y = c2_inputs
     rec = lpa.FISTA(torch.from_numpy(psf).cuda())
     rec.set_data(torch.from_numpy(y).cuda())
     got = rec.apply(n_iter=6, disp_iter=None).cpu().numpy()
     del rec
     torch.cuda.empty_cache()
-    o = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
-    o.set_data(y)
-    ref = o.apply(6).numpy()
-    del o
+    ref = oracle64("fista", 6)[0]
     e = rel(got, ref)
     d = orc.psnr(got[0], scene) - orc.psnr(ref[0].astype(np.float32), scene)
     print(f"C3 FISTA: rel err vs float64 oracle after 6 it = {e:.2e}, PSNR delta = {d:+.2e} dB")
@@ -196,7 +208,7 @@ def test_c3_fista_12mp_vs_float64_oracle(c2_inputs):
     assert abs(d) <= 0.01, d
 
 
-def test_c3_fista_30_iterations_vs_float64_build(c2_inputs):
+def test_c3_fista_30_iterations_vs_float64_build(c2_inputs, oracle64):
     """FISTA's extrapolation coefficient approaches 1 late in a run, which is where float32 drift shows: 30 iterations
     at 12 MP, float32 engine vs the float64 build, the latter anchored to the float64 oracle for 6 (gd.py:235-241)."""
     psf, scene, y = c2_inputs
@@ -204,10 +216,7 @@ def test_c3_fista_30_iterations_vs_float64_build(c2_inputs):
     r64 = lpa.FISTA(psf_d.double(), dtype="float64")
     r64.set_data(y_d.double())
     g6 = r64.apply(n_iter=6, disp_iter=None).cpu().numpy()
-    o = orc.GDOracle(psf.astype(np.float64), kind="fista", dtype=torch.float64)
-    o.set_data(y.astype(np.float64))
-    e6 = rel(g6, o.apply(6).numpy())
-    del o
+    e6 = rel(g6, oracle64("fista", 6)[0])
     t30 = r64.apply(n_iter=30, disp_iter=None).cpu().numpy()
     del r64
     torch.cuda.empty_cache()

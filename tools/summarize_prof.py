@@ -81,9 +81,9 @@ def kid_of(k):
         return "row_inv"
     if k.startswith(("k_cols_mid_admm", "k_cols_mid_mul")):
         return "col_mid"
-    if k.startswith("k_rinv_gd_update"):          # gradient-descent family: inverse rows + update (+ next forward rows)
+    if k.startswith(("k_rinv_gd_update", "k_gd_update_fwd_v2")):   # gradient-descent family: inverse rows + update (+ next forward rows)
         return "spatial"
-    if k.startswith("k_rinv_gd_mid"):             # ... inverse rows + residual + forward rows
+    if k.startswith(("k_rinv_gd_mid", "k_gd_resid_v2")):          # ... inverse rows + residual + forward rows
         return "row_inv"
     if k.startswith("k_cols<") and "SPlan" in k:
         return "col_a_inv" if k.split(",")[2].strip() == "true" else "col_a_fwd"
@@ -100,7 +100,12 @@ if os.path.exists(bench_json):
             workload = bj.get("config", {}).get("workload", "")
 if plan and "plan module " in plan:
     key = plan.split("plan module ")[1].strip()
-    entry = {"plan_module": key, "workload": workload, "snapshot": tag, "n_iter": 40, "source": f"profiles/{tag}_counters.md",
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from lenslesspicam_amd import build as _build
+
+    # bench.py reports an entry only while the kernels are the ones it was measured on (load_traffic)
+    entry = {"plan_module": key, "source_fingerprint": _build.fingerprint(), "workload": workload, "snapshot": tag, "n_iter": 40,
+             "source": f"profiles/{tag}_counters.md",
              "formula": "(2*FETCH_SIZE + WRITE_SIZE) KiB, separate --pmc passes, median per dispatch", "kernels": {}}
     for k, v in sorted(traffic.items(), key=lambda kv: ndisp.get(kv[0], 0)):      # the hot-loop kernel of an id is the
         kid = kid_of(k)                                                              # one dispatched most often (set-up
