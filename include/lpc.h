@@ -103,8 +103,14 @@ typedef struct lpc_config {
  *                      eight blocks apart on one XCD (measured: no gain)
  *   col_single=0|1     ADMM, float32: the whole column transform in ONE launch over whole columns (measured at 12 MP:
  *                      2.25 ms against 1.455 ms for pass A + middle + inverse pass A; default: off)
- *   row_lay=0|1|2      LDS layout of the compile-time row tiles: natural / i + i/8 (default where affine) / the conflict-free
- *                      xor layout (measured: no faster);  row_nt=N  lanes per row workgroup
+ *   row_lay=0|1|2|3    LDS layout of the compile-time row tiles: natural / i + i/8 (default where affine) / the conflict-free
+ *                      xor layout / i + i/16 (plans of radices 8 and 16; both measured: no faster);  row_nt=N  lanes per row
+ *                      workgroup
+ *   gd_v2=0            gradient-descent family: the first form of the two fused row kernels (default 1: the second form,
+ *                      lpc_gd_v2_kernels.h, wherever the row plan has one radix and the window offset / width are even)
+ *   stagger=N lds_pad=N     tuning of those kernels: sleep units between the start times of the workgroups of a launch's
+ *                      first generation that share a CU (measured: no gain; default 0); bytes of LDS claimed beyond the
+ *                      tile (fewer workgroups per CU; measured: no effect)
  *   module_max=N module_loaded_max=N               plan-module files kept per directory this library writes to (256, least
  *                      recently used removed first); modules kept loaded once no handle uses them (64)
  *   row_pf=N           ADMM inverse rows and the gradient-descent family's residual rows (half-length, float32, radices
@@ -113,6 +119,9 @@ typedef struct lpc_config {
  *   rpitch_pad=N       floats added to the row pitch of the padded real planes (measured: no faster; default 0)
  *   no_r2=1 no_skew=1 gd_no_fuse_fwd=1              run-time row plans without the folded radix-2 stage / the LDS skew;
  *                      gradient-descent update without the next iteration's forward rows
+ * Path-valued options (module_dir, compiler) are unescaped before use: %XX (two hex digits) stands for the byte XX, so the
+ * separators of this string can appear in a path -- "%2C" is ',', "%3B" ';', "%20" ' ' -- and a literal '%' that is
+ * followed by two hex digits must itself be written "%25".
  * An unknown key makes lpc_create fail. */
 
 /* ---- life cycle ------------------------------------------------------------------ */

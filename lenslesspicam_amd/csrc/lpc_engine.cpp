@@ -3,6 +3,7 @@
 // test-suite only, as plain C++ with -DLPC_SIMT_EMU (see lpc_rt.h).  The row / column / gradient-descent
 // launches live in lpc_rows.cpp, lpc_cols.cpp and lpc_gd.cpp (see lpc_engine.h).
 #include "lpc_engine.h"
+#include <mutex>
 #include "lpc_gd_kernels.h"
 #include "lpc_metric_kernels.h"
 #include "lpc_prep_kernels.h"
@@ -31,6 +32,20 @@ static int next_5smooth(int n) {  // scipy.fftpack.next_fast_len (rfft_convolve.
 static int upload(Engine* e, void* dst, const void* src, size_t bytes) {
   LPC_RT(rt::copy_h2d_async(dst, src, bytes, e->stream));
   LPC_RT(rt::stream_sync(e->stream));
+  return 0;
+}
+
+int big_smem_once(const void* fn, size_t smem) {
+  static std::mutex mu;
+  static std::unordered_set<uint64_t> done;
+  int dev = 0;
+  LPC_RT(rt::current_device(&dev));
+  const uint64_t key = (uint64_t)(uintptr_t)fn ^ ((uint64_t)(dev + 1) << 56);
+  std::lock_guard<std::mutex> lock(mu);
+  if (!done.count(key)) {
+    LPC_RT(rt::set_max_dyn_smem(fn, smem > 65536 ? 160 * 1024 : 65536));
+    done.insert(key);
+  }
   return 0;
 }
 
@@ -240,6 +255,17 @@ static void override_radices(const std::string& opt, int n, std::vector<int>& ra
   if (prod == n && (int)r.size() <= LPC_SPEC_MAX_ST) rad = r;
 }
 
+// compute units the launch plan is sized for: the device's when there is one, an MI355X's for the device-less
+// lpc_plan_module() path (build.py pre-building modules in a container without a GPU)
+static int plan_cu_count() {
+#if defined(LPC_SIMT_EMU)
+  return 256;       // (the emulator chooses the plans the MI355X would)
+#endif
+  int n = 0;
+  if (rt::device_count(&n) != lpcSuccess || n <= 0) return 256;
+  return rt::cu_count();
+}
+
 // `allow_static`: choose compile-time plans (-> e->spec, served by a plan module) wherever the kernels exist; false: the
 // run-time plans of the core library alone.  Sets N1, N2, T, rows_half and the spec; touches nothing on the device.
 static void choose_plan(Engine* e, bool allow_static) {
@@ -398,7 +424,7 @@ static void choose_plan(Engine* e, bool allow_static) {
     // 5-iteration call 0.243 -> 0.234 ms (profiles/r04t_ab_c1.log; 30.18 on 1024 lanes 19.8 us, 768 lanes 19.6 us).
     // Only while every workgroup has a CU of its own (256 on an MI355X): two frames = 366 tiles are 6 % SLOWER that way
     // (0.370 -> 0.392 ms, r04t_ab_c1c.log).
-    const bool one_wave_of_tiles = !seq && !single && e->N1 == 1 && (long)e->P * ((g.Wc + T - 1) / T) <= 256 && n * 2 * T > 8192;
+    const bool one_wave_of_tiles = !seq && !single && e->N1 == 1 && (long)e->P * ((g.Wc + T - 1) / T) <= plan_cu_count() && n * 2 * T > 8192;
     if (one_wave_of_tiles && n == 540) rad = {6, 10, 9};
     if (single) {                  // long columns: fat stages (plan_radices stops at radix 8)
       rad.clear();
@@ -426,7 +452,7 @@ static void choose_plan(Engine* e, bool allow_static) {
         // both tiles' loads up front when the launch is many waves of workgroups deep (C4, 64 frames: 11 712 workgroups
         // for 1 024 resident, middle 0.494 -> 0.473 ms; an 8-frame shard -- 1 464 workgroups -- is 1.5 % slower with it:
         // profiles/r04h_ab.log)
-        sp.mid_pre = o.mid_pre >= 0 ? (o.mid_pre ? 1 : 0) : ((long)e->P * ((g.Wc + T - 1) / T) >= 4096 && !single ? 1 : 0);
+        sp.mid_pre = o.mid_pre >= 0 ? (o.mid_pre ? 1 : 0) : ((long)e->P * ((g.Wc + T - 1) / T) >= 16L * plan_cu_count() && !single ? 1 : 0);
         const size_t lds = (size_t)n * (T + (sp.mid_twg ? 0 : 1)) * sizeof(real2);
         const int wgs = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
         // (512 lanes: 8 = a 64-VGPR allocation, four workgroups per CU as the LDS allows -- 68 registers without the

@@ -168,21 +168,15 @@ static inline int dev_alloc(Engine* e, Tp** out, size_t count) {
   return 0;
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of a kernel: the (device, function) pairs that have
+// it live in the CORE library (lpc_engine.cpp) -- launch_k is instantiated inside every plan module too, and a
+// thread_local set there would register a TLS destructor that pins the module: dlclose() would never unload it
+int big_smem_once(const void* fn, size_t smem);
+
 // generic launcher (+ optional event bracketing of hot-loop kernels)
 template <class K, class... A>
 static inline int launch_k(Engine* e, int kid, K kernel, dim3 grid, int nt, size_t smem, A... args) {
-  // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE attribute of the function: remember (device, function)
-  static thread_local std::unordered_set<uint64_t> big_smem_done;
-  if (smem > 48 * 1024) {
-    const void* fn = (const void*)kernel;
-    int dev = 0;
-    LPC_RT(rt::current_device(&dev));
-    const uint64_t key = (uint64_t)(uintptr_t)fn ^ ((uint64_t)(dev + 1) << 56);
-    if (!big_smem_done.count(key)) {
-      LPC_RT(rt::set_max_dyn_smem(fn, smem > 65536 ? 160 * 1024 : 65536));
-      big_smem_done.insert(key);
-    }
-  }
+  if (smem > 48 * 1024) LPC_OK(big_smem_once((const void*)kernel, smem));
 #if !defined(LPC_SIMT_EMU)
   const bool timed = e->timer.on && kid >= 0 && ((e->timer.mask >> kid) & 1u);
   size_t slot = 0;

@@ -68,9 +68,36 @@ struct GdV2 {
   static constexpr bool ok = uniform() && (R == 8 || R == 16) && L >= 2 && NB % 64 == 0 && NB <= 1024;
 };
 
+// The tangling twiddles of a lane, bins j + (M / R) m, m < R / 2 (the upper half is a swap away: w^(k + M/2) = -i w^k).
+// TC: ONE table entry, the others as products with exp(-2 pi i m / (2 R)) (M / R bins of a length-2M table are 1 / (2 R) of
+// a turn apart) -- the products are free here (removing every butterfly of these kernels does not change their time), the
+// loads are not (profiles/r05_notes.md section 2); !TC: the R / 2 table entries themselves.
+#ifndef LPC_V2_TC_RESID
+#define LPC_V2_TC_RESID 1
+#endif
+#ifndef LPC_V2_TC_UPDATE
+#define LPC_V2_TC_UPDATE 1
+#endif
+template <int N2R> struct V2Rot;
+template <> struct V2Rot<32> { static constexpr WPair w[8] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)9.80785280403230430579e-01, (real)-1.95090322016128248084e-01}, {(real)9.23879532511286738483e-01, (real)-3.82683432365089781779e-01}, {(real)8.31469612302545235671e-01, (real)-5.55570233019602177649e-01}, {(real)7.07106781186547572737e-01, (real)-7.07106781186547461715e-01}, {(real)5.55570233019602288671e-01, (real)-8.31469612302545235671e-01}, {(real)3.82683432365089837290e-01, (real)-9.23879532511286738483e-01}, {(real)1.95090322016128331351e-01, (real)-9.80785280403230430579e-01}}; };
+template <> struct V2Rot<16> { static constexpr WPair w[4] = {{(real)1.00000000000000000000e+00, (real)-0.00000000000000000000e+00}, {(real)9.23879532511286738483e-01, (real)-3.82683432365089781779e-01}, {(real)7.07106781186547572737e-01, (real)-7.07106781186547461715e-01}, {(real)3.82683432365089837290e-01, (real)-9.23879532511286738483e-01}}; };
+template <class P, bool TC>
+static __device__ __forceinline__ void v2_tangle_twiddles(const real2* LPC_RESTRICT twW, int j, real2* tw) {
+  constexpr int R = GdV2<P>::R, NB = GdV2<P>::NB;
+  if (TC) {
+    const real2 t0 = twW[j];
+    tw[0] = t0;
+#pragma unroll
+    for (int m = 1; m < R / 2; ++m) tw[m] = cmul(t0, make_real2(V2Rot<2 * R>::w[m].re, V2Rot<2 * R>::w[m].im));
+  } else {
+#pragma unroll
+    for (int m = 0; m < R / 2; ++m) tw[m] = twW[j + NB * m];
+  }
+}
+
 // X[k], X[M - k] of one half-spectrum row -> Z (irfft semantics, see tangle_half_load) -> first inverse stage
 // (radix R, no twiddles) -> tile.  No trailing barrier.
-template <class P, int SK>
+template <class P, int SK, bool TC>
 static __device__ __forceinline__ void v2_load_tangle_first(real2* s, const real2* LPC_RESTRICT in,
                                                             const real2* LPC_RESTRICT twW, int j) {
   constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB;
@@ -79,8 +106,7 @@ static __device__ __forceinline__ void v2_load_tangle_first(real2* s, const real
   for (int m = 0; m < R; ++m) zk[m] = in[j + NB * m];
 #pragma unroll
   for (int m = 0; m < R; ++m) zm[m] = in[M - j - NB * m];
-#pragma unroll
-  for (int m = 0; m < R / 2; ++m) tw[m] = twW[j + NB * m];
+  v2_tangle_twiddles<P, TC>(twW, j, tw);
   real2 v[R];
 #pragma unroll
   for (int m = 0; m < R; ++m) {
@@ -196,7 +222,7 @@ static __device__ __forceinline__ void v2_first_fwd(real2* s, int j, real2* r) {
 
 // X = FFT_M(z) (elements j + NB m in x[]) -> half spectrum of the real row (see untangle_half_store) -> o[0 .. M].
 // Precondition: every lane is done reading the tile.
-template <class P, int SK>
+template <class P, int SK, bool TC>
 static __device__ __forceinline__ void v2_untangle_store(real2* s, const real2* LPC_RESTRICT twW, int j, const real2* x,
                                                          real2* LPC_RESTRICT o) {
   constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB;
@@ -204,8 +230,7 @@ static __device__ __forceinline__ void v2_untangle_store(real2* s, const real2* 
   // index, a few integer instructions, instead of kept alive -- i.e. spilled -- across both transforms)
   j = lpc_opaque(j);
   real2 tw[R / 2];
-#pragma unroll
-  for (int m = 0; m < R / 2; ++m) tw[m] = twW[j + NB * m];
+  v2_tangle_twiddles<P, TC>(twW, j, tw);
 #pragma unroll
   for (int m = 0; m < R; ++m) v2_lds_st(s, lds_slot<SK>(j + NB * m), x[m]);
   v2_barrier();
@@ -232,8 +257,13 @@ static __device__ __forceinline__ int v2_data_plane(unsigned pl, FastDiv fdc, Fa
   return (int)(q * (unsigned)C + (pl - fd_div(pl, fc) * fc.d));
 }
 
+// (five waves per SIMD = at most 96 VGPRs: with the natural tile, 32 KB, five residual workgroups share a CU; same box,
+// 0.1678 -> 0.1596 ms per launch at 12 MP, profiles/r05o_tc.log)
+#ifndef LPC_V2_RESID_MINW
+#define LPC_V2_RESID_MINW 5
+#endif
 template <int NT, int SK, class PL>
-__global__ __launch_bounds__(NT, 4) void k_gd_resid_v2(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
+__global__ __launch_bounds__(NT, LPC_V2_RESID_MINW) void k_gd_resid_v2(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                                const real2* LPC_RESTRICT Sin,
                                                                real2* LPC_RESTRICT Sout, const real* LPC_RESTRICT Y,
                                                                FastDiv fdc, FastDiv fc, int stagger) {
@@ -248,7 +278,7 @@ __global__ __launch_bounds__(NT, 4) void k_gd_resid_v2(PlaneGeom g, PL plan, con
   const int sr = wrap_add(g.sh + u, g.Hp / 2, g.Hp);
   real2 wb[4];
   v2_tw_load<P, 1>(plan.tws, j, wb);
-  v2_load_tangle_first<P, SK>(s, Sin + (long)pl * g.cplane + (long)sr * g.cpitch, twW, j);
+  v2_load_tangle_first<P, SK, LPC_V2_TC_RESID != 0>(s, Sin + (long)pl * g.cplane + (long)sr * g.cpitch, twW, j);
   v2_barrier();
   v2_mid_chain<P, SK, true>(s, plan.tws, j, wb, std::make_integer_sequence<int, L - 2>{});
   // the measurement row, in flight across the last inverse stage (across two stages it costs the registers that the
@@ -274,7 +304,7 @@ __global__ __launch_bounds__(NT, 4) void k_gd_resid_v2(PlaneGeom g, PL plan, con
   v2_mid_chain<P, SK, false>(s, plan.tws, j, wb, std::make_integer_sequence<int, L - 2>{});
   v2_final_stage<P, SK, false, false>(s, plan.tws, j, wb, v);
   v2_barrier();
-  v2_untangle_store<P, SK>(s, twW, j, v, Sout + (long)pl * g.cplane + (long)(g.sh + u) * g.cpitch);
+  v2_untangle_store<P, SK, LPC_V2_TC_RESID != 0>(s, twW, j, v, Sout + (long)pl * g.cplane + (long)(g.sh + u) * g.cpitch);
 }
 
 // KIND (0 vanilla, 1 Nesterov, 2 FISTA) and FIRST (FISTA's first update, where x_k aliases the iterate: gd.py:233,236) are
@@ -301,7 +331,7 @@ __global__ __launch_bounds__(NT, 4) void k_gd_update_fwd_v2(PlaneGeom g, PL plan
   const int sr = wrap_add(g.sh + u, g.Hp / 2, g.Hp);
   real2 wb[4];
   v2_tw_load<P, 1>(plan.tws, j, wb);
-  v2_load_tangle_first<P, SK>(s, Sin + (long)pl * g.cplane + (long)sr * g.cpitch, twW, j);
+  v2_load_tangle_first<P, SK, LPC_V2_TC_UPDATE != 0>(s, Sin + (long)pl * g.cplane + (long)sr * g.cpitch, twW, j);
   v2_barrier();
   v2_mid_chain<P, SK, true>(s, plan.tws, j, wb, std::make_integer_sequence<int, L - 2>{});
   const real al = alpha[pl - fd_div(pl, fc) * fc.d];
@@ -348,7 +378,7 @@ __global__ __launch_bounds__(NT, 4) void k_gd_update_fwd_v2(PlaneGeom g, PL plan
   v2_mid_chain<P, SK, false>(s, plan.tws, j, wb, std::make_integer_sequence<int, L - 2>{});
   v2_final_stage<P, SK, false, false>(s, plan.tws, j, wb, v);
   v2_barrier();
-  v2_untangle_store<P, SK>(s, twW, j, v, Sout + (long)pl * g.cplane + (long)(g.sh + u) * g.cpitch);
+  v2_untangle_store<P, SK, LPC_V2_TC_UPDATE != 0>(s, twW, j, v, Sout + (long)pl * g.cplane + (long)(g.sh + u) * g.cpitch);
 }
 
 #endif   // !LPC_DOUBLE

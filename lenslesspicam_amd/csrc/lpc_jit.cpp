@@ -202,7 +202,8 @@ int build_plan_module(const PlanSpec& spec, const EngineOpts& opt, std::string* 
   }
 #endif
   const std::string cc = find_compiler(opt);
-  if (cc.empty() || ::access(cc.c_str(), X_OK) != 0) {
+  // (a bare name -- compiler=hipcc -- is resolved through PATH by the shell below: only a path is checked here)
+  if (cc.empty() || (cc.find('/') != std::string::npos && ::access(cc.c_str(), X_OK) != 0)) {
 #if !defined(LPC_SIMT_EMU)
     *path_or_error = "no hipcc (" + (cc.empty() ? std::string("option compiler=, $ROCM_PATH/bin/hipcc, /opt/rocm/bin/hipcc") : cc + " is not executable") + ")";
     return 1;
@@ -334,7 +335,10 @@ const LpcModule* get_plan_module(const PlanSpec& spec, const EngineOpts& opt, bo
           if (build_plan_module(spec, opt, &path) != 0) { note = path; path.clear(); }
         }
       }
-      if (!path.empty()) {
+      // a file that is on disk but does not load (truncated by a dying neighbour, built from other sources under this
+      // fingerprint, ...) must not be found again by every retry: it is removed and -- when this handle may compile --
+      // rebuilt once before the failure is recorded
+      for (int attempt = 0; attempt < 2 && !path.empty() && !s.mod; ++attempt) {
         void* h = ::dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
         if (!h) note = std::string("dlopen: ") + ::dlerror();
         else {
@@ -349,6 +353,16 @@ const LpcModule* get_plan_module(const PlanSpec& spec, const EngineOpts& opt, bo
             delete m;
             ::dlclose(h);
             note = "module " + path + " was built from other sources";
+          }
+        }
+        if (!s.mod) {
+          const bool removed = ::access(dir_of(path).c_str(), W_OK) == 0 && ::unlink(path.c_str()) == 0;
+          path.clear();
+          if (removed && allow_compile && attempt == 0) {
+            s.compile_tried = true;
+            std::string built;
+            if (build_plan_module(spec, opt, &built) == 0) path = built;
+            else note += "; rebuilding it failed: " + built;
           }
         }
       }

@@ -126,3 +126,35 @@ def test_option_values_with_separators():
     with pytest.raises(ValueError):
         _native._option_value("row_rad", "8,8")
     assert _native._option_value("hv_full", True) == "1"
+
+
+def test_a_module_file_that_does_not_load_is_replaced(backend, monkeypatch, tmp_path):
+    """A file under the module's name that is not a loadable module (truncated by a neighbour that died mid-write, ...):
+    found on disk, it fails dlopen -- it is removed and, when the handle may compile, rebuilt once; a jit=0 handle falls
+    back to the run-time plans and leaves no wreck behind for the next one."""
+    if backend.kind != "emu":
+        pytest.skip("emulator leg (the logic is lpc_jit.cpp's, identical in both builds)")
+    d = tmp_path / "m"
+    d.mkdir()
+    cfg = dict(algo=1, height=26, width=44, channels=1)
+    key = backend.lib.plan_module(build=False, options={"jit_min_points": 0, "module_dir": str(d)}, **cfg)
+    assert key
+    # the file name a module of this key carries: build it once elsewhere to learn it
+    ref_dir = tmp_path / "ref"
+    backend.lib.plan_module(build=True, options={"jit_min_points": 0, "module_dir": str(ref_dir)}, **cfg)
+    name = mods(str(ref_dir))[0]
+    (d / name).write_bytes(b"\x7fELF not really")
+    rng = np.random.default_rng(8)
+    psf = torch.from_numpy(rng.random((1, 26, 44, 1), dtype=np.float32) ** 4)
+    engine_opts(monkeypatch, jit_min_points=0, module_dir=str(d), jit=0)
+    monkeypatch.setattr(_native, "_warned", set())
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rec = lpa.ADMM(psf)
+    assert "run-time plans (" in rec._handle.plan_info() and "dlopen" in rec._handle.plan_info()
+    assert mods(str(d)) == []                                   # the wreck is gone
+    engine_opts(monkeypatch, jit_min_points=0, module_dir=str(d), jit=1)
+    (d / name).write_bytes(b"\x7fELF not really")               # again, and this handle may compile: replaced in place
+    rec = lpa.ADMM(psf)
+    assert "plan module " + key in rec._handle.plan_info(), rec._handle.plan_info()
+    assert mods(str(d)) == [name] and os.path.getsize(d / name) > 10000
