@@ -63,24 +63,28 @@ static int make_twiddles(Engine* e, int n, real2** out) {
 static int make_stage_twiddles(Engine* e, const StaticFft& f, real2** out) {
   *out = nullptr;
   std::vector<real2> h;
-  bool any = false;
   int ns = f.rad[0];
+  auto w = [&](long q) {
+    const double a = -2.0 * M_PI * (double)(q % f.n) / (double)f.n;
+    return make_real2((real)std::cos(a), (real)std::sin(a));
+  };
   for (int st = 1; st < f.nst; ++st) {
     const int R = f.rad[st], nb = f.n / R, step = f.n / (ns * R);
     const size_t base = h.size();
-    h.resize(base + (size_t)4 * nb, make_real2((real)0., (real)0.));
-    any = any || R == 8 || R == 16;
-    if (R == 8 || R == 16)     // (twiddle_mul reads exact table entries for the other radices: their blocks stay empty)
-    for (int hh = 0; hh < 2; ++hh)
-      for (int j = 0; j < nb; ++j)
-        for (int i = 0; i < 2; ++i) {
-          const long q = (long)(j % ns) * step * (1L << (2 * hh + i));     // q, 2q | 4q, 8q
-          const double a = -2.0 * M_PI * (double)(q % f.n) / (double)f.n;
-          h[base + ((size_t)hh * nb + j) * 2 + i] = make_real2((real)std::cos(a), (real)std::sin(a));
-        }
+    if (R == 8 || R == 16) {         // base powers {q, 2q}, {4q, 8q}: [pair][j][2]
+      h.resize(base + (size_t)4 * nb);
+      for (int hh = 0; hh < 2; ++hh)
+        for (int j = 0; j < nb; ++j)
+          for (int i = 0; i < 2; ++i)
+            h[base + ((size_t)hh * nb + j) * 2 + i] = w((long)(j % ns) * step * (1L << (2 * hh + i)));
+    } else {                         // every power: [m - 1][j]
+      h.resize(base + (size_t)(R - 1) * nb);
+      for (int m = 1; m < R; ++m)
+        for (int j = 0; j < nb; ++j) h[base + (size_t)(m - 1) * nb + j] = w((long)(j % ns) * step * m);
+    }
     ns *= R;
   }
-  if (h.empty() || !any) return 0;
+  if (h.empty()) return 0;
   LPC_OK(dev_alloc(e, out, h.size()));
   return upload(e, *out, h.data(), h.size() * sizeof(real2));
 }

@@ -265,18 +265,25 @@ static __device__ __forceinline__ void twiddle_mul(real2* v, const real2* LPC_RE
 // stage's block of a lane-ordered table (lpc_sfft.h: SPlan::tws_off), nb its butterflies, j this lane's butterfly.
 template <int R, bool INV>
 static __device__ __forceinline__ void twiddle_mul_lane(real2* v, const real2* LPC_RESTRICT blk, int nb, int j) {
-  static_assert(R == 8 || R == 16, "lane-ordered stage twiddles: radices 8 and 16");
-  const real4_t lo = *(const real4_t*)(blk + 2 * j), hi = *(const real4_t*)(blk + 2 * (nb + j));
-  real2 w[16];
-  w[1] = make_real2(lo.x, lo.y); w[2] = make_real2(lo.z, lo.w); w[4] = make_real2(hi.x, hi.y);
-  if (R == 16) w[8] = make_real2(hi.z, hi.w);
-  w[3] = cmul(w[1], w[2]); w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]);
-  if (R == 16) {
+  if constexpr (R == 8 || R == 16) {
+    const real4_t lo = *(const real4_t*)(blk + 2 * j), hi = *(const real4_t*)(blk + 2 * (nb + j));
+    real2 w[16];
+    w[1] = make_real2(lo.x, lo.y); w[2] = make_real2(lo.z, lo.w); w[4] = make_real2(hi.x, hi.y);
+    if (R == 16) w[8] = make_real2(hi.z, hi.w);
+    w[3] = cmul(w[1], w[2]); w[5] = cmul(w[1], w[4]); w[6] = cmul(w[2], w[4]); w[7] = cmul(w[3], w[4]);
+    if (R == 16) {
 #pragma unroll
-    for (int m = 9; m < 16; ++m) w[m] = cmul(w[m - 8], w[8]);
+      for (int m = 9; m < 16; ++m) w[m] = cmul(w[m - 8], w[8]);
+    }
+#pragma unroll
+    for (int m = 1; m < R; ++m) v[m] = INV ? cmul_conj(v[m], w[m]) : cmul(v[m], w[m]);
+  } else {      // every power w^(q m), m = 1 .. R - 1, as its own table row [m - 1][j] (the entries twiddle_mul gathers)
+    real2 t[R];
+#pragma unroll
+    for (int m = 1; m < R; ++m) t[m] = blk[(m - 1) * nb + j];
+#pragma unroll
+    for (int m = 1; m < R; ++m) v[m] = INV ? cmul_conj(v[m], t[m]) : cmul(v[m], t[m]);
   }
-#pragma unroll
-  for (int m = 1; m < R; ++m) v[m] = INV ? cmul_conj(v[m], w[m]) : cmul(v[m], w[m]);
 }
 
 // Row mode (one transform per workgroup, BT == 1) may store element i at LDS slot i + i/8: the

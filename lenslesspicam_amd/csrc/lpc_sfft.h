@@ -42,9 +42,13 @@ struct SPlan {
   // loads per stage are contiguous across the wave (8 cache lines per instruction) where the gathers tw[q], tw[2q], tw[4q],
   // tw[8q] touch up to 32 lines each -- measured on the row kernels' access pattern, 32 such gathers per lane cost as
   // much as the rows' HBM traffic itself (tools/probe/row_pattern.hip, profiles/r05_notes.md).
+  // (other radices: the R - 1 powers w^(q m) themselves, [m - 1][j])
+  static __host__ __device__ constexpr int tws_block(int st) {    // real2 entries of stage st's block
+    return ((radix(st) == 8 || radix(st) == 16) ? 4 : radix(st) - 1) * (n / radix(st));
+  }
   static __host__ __device__ constexpr int tws_off(int st) {      // offset of stage st's block, in real2
     int o = 0;
-    for (int i = 1; i < st; ++i) o += 4 * (n / radix(i));
+    for (int i = 1; i < st; ++i) o += tws_block(i);
     return o;
   }
   static constexpr int tws_size = tws_off(nst);
@@ -116,7 +120,7 @@ static __device__ __forceinline__ void sfft_stage(real2* s, const real2* LPC_RES
       const int rb = lds_slot<SKEW>(w);
 #pragma unroll
       for (int m = 0; m < R; ++m) v[b][m] = RAFF ? s[rb + m * RS] : s[lds_slot<SKEW>(w + m * IST)];
-      if constexpr (LANE && NS > 1 && BT == 1 && (R == 8 || R == 16)) twiddle_mul_lane<R, INV>(v[b], tws + P::tws_off(ST), NB, j);
+      if constexpr (LANE && NS > 1 && BT == 1) twiddle_mul_lane<R, INV>(v[b], tws + P::tws_off(ST), NB, j);
       else if (NS > 1) twiddle_mul<R, INV>(v[b], tw, k * TWSTEP);
       Dft<R, INV>::run(v[b]);
       const int oi = (jq * NS * R + k) * BT + c;
@@ -216,7 +220,7 @@ static __device__ __forceinline__ void sfft_last_fused(real2* s, const real2* LP
     if (!GUARD || w < NWORK) {
       const int j = w / BT, c = w % BT;
       const int jq = j / NS, k = j % NS;
-      if constexpr (LANE && NS > 1 && BT == 1 && (R == 8 || R == 16)) twiddle_mul_lane<R, INV>(v[b], tws + P::tws_off(ST), NB, j);
+      if constexpr (LANE && NS > 1 && BT == 1) twiddle_mul_lane<R, INV>(v[b], tws + P::tws_off(ST), NB, j);
       else if (NS > 1) twiddle_mul<R, INV>(v[b], tw, k * TWSTEP);
       Dft<R, INV>::run(v[b]);
       const int oi = jq * NS * R + k;
