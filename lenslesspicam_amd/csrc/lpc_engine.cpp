@@ -35,6 +35,13 @@ static int upload(Engine* e, void* dst, const void* src, size_t bytes) {
   return 0;
 }
 
+// Engine::k1_rows, automatic choice: padded points x planes up to which the TV / W half rides in the forward rows
+// (C1 1.6 M: -7.6 %, 380 x 507 x 3 2.4 M: -7 %, four frames of C1's size 6.2 M: -8 %; larger batches run their rows on
+// 128 lanes and are not eligible -- profiles/r05_notes.md section 5)
+#ifndef LPC_K1_ROWS_MAX_POINTS
+#define LPC_K1_ROWS_MAX_POINTS 8.0e6
+#endif
+
 int big_smem_once(const void* fn, size_t smem) {
   static std::mutex mu;
   static std::unordered_set<uint64_t> done;
@@ -43,7 +50,12 @@ int big_smem_once(const void* fn, size_t smem) {
   const uint64_t key = (uint64_t)(uintptr_t)fn ^ ((uint64_t)(dev + 1) << 56);
   std::lock_guard<std::mutex> lock(mu);
   if (!done.count(key)) {
-    LPC_RT(rt::set_max_dyn_smem(fn, smem > 65536 ? 160 * 1024 : 65536));
+    // (a kernel with static LDS of its own -- the stamped timing builds, lpc_rt.h: LPC_STAMP -- cannot have the whole
+    // 160 KiB as dynamic LDS: ask for what this launch needs then)
+    if (rt::set_max_dyn_smem(fn, smem > 65536 ? 160 * 1024 : 65536) != lpcSuccess) {
+      (void)rt::last_error();
+      LPC_RT(rt::set_max_dyn_smem(fn, smem));
+    }
     done.insert(key);
   }
   return 0;
@@ -532,6 +544,11 @@ static int setup_geometry(Engine* e) {
   // `a` compute xi' and a = mu1 X - xi' from xi, HV, HV_old, y themselves (-2R per iteration), the tiled kernel keeps
   // the stencil half at its own occupancy (option no_xhalf: the full stand-alone kernel) ...
   e->xhalf_rows = admm && e->mod && e->mod->admm_rows_fwd_x;
+  // ... small frames (every launch at most a few workgroups per CU: an iteration is a chain of launch boundaries and
+  // memory latencies, profiles/r05_notes.md section 5) hand it the TV / W half too: three launches per iteration
+  // (option k1_rows=0 / 1; modules whose row fits one quad per lane)
+  e->k1_rows = e->xhalf_rows && e->mod->k1_rows && g.Wp % 4 == 0 && !e->opt.k1_scalar &&
+               (e->opt.k1_rows >= 0 ? e->opt.k1_rows != 0 : (double)g.Hp * g.Wp * e->P <= LPC_K1_ROWS_MAX_POINTS);
   // ... outside the sensor window that half works from HV alone (AdmmScalars::xiw; option xi_full: every pixel alike) ...
   e->xi_window = e->xhalf_rows && !e->opt.xi_full;
   // ... and rows wholly outside it skip the H V row transforms in both directions: the kept rows of SB are rescaled by
@@ -760,8 +777,9 @@ static int admm_reset(Engine* e) {
 
 // (r_sp, a) in e->Rsp / e->Aarr  ->  Vout = irfft2(R_div (rfft2 r_sp + s H* rfft2 a)),  HVout = H Vout:
 // forward rows, [pass A], fused middle, [inverse pass A], inverse rows
-static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real* HVout, bool xhalf = false) {
-  if (xhalf) LPC_OK(admm_rows_fwd_x(e, sc));
+static int admm_spectral_step(Engine* e, const AdmmScalars& sc, real* Vout, real* HVout, bool xhalf = false,
+                              const K1Rows* k1 = nullptr) {
+  if (xhalf) LPC_OK(admm_rows_fwd_x(e, sc, k1));
   else LPC_OK(admm_rows_fwd(e));
   LPC_OK(admm_cols(e, sc));
   return admm_rows_inv(e, Vout, HVout, sc.skiphv != 0);
@@ -804,7 +822,11 @@ static int admm_iterate(Engine* e, int n_iter) {
     const bool k1_half = vec4 && e->xhalf_rows && e->opt.k1_half != 0;
     sc.half_in = (k1_half && it > 0) ? 1 : 0;
     sc.half_out = (k1_half && it + 1 < n_iter) ? 1 : 0;
-    if (sc.half_in)
+    // small frames: the forward rows take the TV / W half as well (Engine::k1_rows) -- same buffers, same ping-pong
+    const bool k1r = e->k1_rows && vec4;
+    const K1Rows k1 = {Vc, Vo, e->eta0[e->ecur], e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho};
+    if (k1r) {
+    } else if (sc.half_in)
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4X, NT, false, true>, k1_grid4x, NT, k1_smem4x / 2, g, sc, (const real*)Vc,
                       (const real*)Vo, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->eta0[e->ecur],
                       (const real*)e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
@@ -830,7 +852,7 @@ static int admm_iterate(Engine* e, int n_iter) {
     e->first = false;
     // (hcur still names the CURRENT H V here: the X half inside the forward rows reads HVb[hcur] and HVb[hcur ^ 1]
     // before the inverse rows of this same step overwrite HVb[hcur ^ 1] -- stream order)
-    LPC_OK(admm_spectral_step(e, sc, Vo, e->HVb[e->hcur ^ 1], vec4 && e->xhalf_rows));
+    LPC_OK(admm_spectral_step(e, sc, Vo, e->HVb[e->hcur ^ 1], vec4 && e->xhalf_rows, k1r ? &k1 : nullptr));
     e->vcur ^= 1;  // Vo now holds the new image estimate
     e->hcur ^= 1;  // ... and the other H V buffer its forward model
     sb_rows_valid = true;   // the inverse column passes of this step left rfft(H V row) / Wp in every row of SB
@@ -1536,7 +1558,9 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
       // rho and writes eta0, eta1, rho, r_sp = 9R (SURVEY's 15R + R0 minus its X part: reads HV, X, xi, y, writes xi, X,
       // a); the row kernel reads r_sp (R) and xi, HV, HV_old, y (3R + R0), writes xi (R) and the two spectra (2S).
       // ... and without V_old once the duals travel half-applied between the iterations of a call (k1_half): 8R
-      case LPC_K_SPATIAL: b = e->xhalf_rows ? ((e->opt.k1_half != 0 && g.Wp % 4 == 0 && !e->opt.k1_scalar) ? 8.0 : 9.0) * R
+      // ... k1_rows (small frames): not launched; the forward rows read V, eta0, eta1, rho (+ V_old without k1_half)
+      // instead of r_sp and write eta0, eta1, rho: + 6R (7R)
+      case LPC_K_SPATIAL: b = e->k1_rows ? 0.0 : e->xhalf_rows ? ((e->opt.k1_half != 0 && g.Wp % 4 == 0 && !e->opt.k1_scalar) ? 8.0 : 9.0) * R
                                             : 15.0 * R + R0; break;
       // ... with xi confined to the sensor window (AdmmScalars::xiw) the row kernel reads r_sp, HV everywhere (2R) and
       // xi, HV_old / writes xi only over the window (3 window-sized arrays per plane) and y: 2R + 3 Rw + R0 + 2S
@@ -1544,7 +1568,8 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
       // of a long call; fr = H / Hp): rows fwd (1 + fr) R + 3 Rw + R0 + (1 + fr) S, rows inv (1 + fr) (S + R)
       case LPC_K_ROW_FWD: b = (e->hv_skip ? (1.0 + fr) * R + 3.0 * eb * g.H * g.W * e->P + R0 + (1.0 + fr) * S
                                   : e->xi_window ? 2.0 * R + 3.0 * eb * g.H * g.W * e->P + R0 + 2.0 * S
-                                  : e->xhalf_rows ? 5.0 * R + R0 + 2.0 * S : 2.0 * R + 2.0 * S); break;
+                                  : e->xhalf_rows ? 5.0 * R + R0 + 2.0 * S : 2.0 * R + 2.0 * S)
+                                 + (e->k1_rows ? (e->opt.k1_half != 0 ? 6.0 : 7.0) * R : 0.0); break;
       case LPC_K_COL_A_FWD: b = split ? 4.0 * S : 0.0; break;
       case LPC_K_COL_MID: b = 4.0 * S + Sc + (e->g_sep ? 0. : eb * g.Hp * g.Wc); break;  // + H (complex) + |G| (real, one plane; two vectors when it separates)
       case LPC_K_COL_A_INV: b = split ? 4.0 * S : 0.0; break;
@@ -1582,7 +1607,8 @@ int lpc_plan_info(lpc_handle e, char* buf, size_t n) {
     s += reg ? ", middle in registers"
              : (e->mod && sp.mid_kind ? ", LDS middle [static " + radstr(sp.mid) + (sp.mid_kind == LPC_MID_SEQ ? ", one spectrum at a time]" : "]")
                                       : ", LDS middle");
-    s += e->xhalf_rows ? "; tiled TV / W kernel + X half inside the forward rows" : "; stand-alone image-domain kernel";
+    s += e->k1_rows ? "; TV / W half and X half inside the forward rows (three launches per iteration)"
+         : e->xhalf_rows ? "; tiled TV / W kernel + X half inside the forward rows" : "; stand-alone image-domain kernel";
     if (e->xi_window) s += e->hv_skip ? " (xi inside the sensor window only, H V row transforms skipped outside it)"
                                       : " (xi inside the sensor window only)";
   }

@@ -93,6 +93,7 @@ struct lpc_engine {
   const struct LpcModule* mod = nullptr;   // ... and the loaded plan module that holds them (null: run-time plans only)
   std::string mod_note;    // why there is no module, for lpc_plan_info
   bool xhalf_rows = false; // ADMM: xi / a = mu1 X - xi computed by the forward row kernel of the module
+  bool k1_rows = false;    // ... and the TV / W half too: three launches per iteration (small frames, option k1_rows)
   bool xi_window = false;  // ... which then skips xi / HV_old outside the sensor window (AdmmScalars::xiw)
   bool hv_skip = false;    // ... and rows wholly outside it skip the H V row transforms in both directions (AdmmScalars::skipa)
   bool mid_reg = true;  // register-resident fused middle where the pass-B length allows (option mid_lds=1: off)
@@ -244,13 +245,14 @@ struct LpcModule {
   int (*rows_fwd_single)(Engine*, const RealSrc*, real2* S, int nplanes, int kid);
   int (*rows_inv_single)(Engine*, const real2* S, const RealDst*, int nplanes, int kid);
   int (*admm_rows_fwd)(Engine*);
-  int (*admm_rows_fwd_x)(Engine*, const AdmmScalars*);
+  int (*admm_rows_fwd_x)(Engine*, const AdmmScalars*, const K1Rows* k1);   // k1: + the TV / W half (k1_rows)
   int (*admm_rows_inv)(Engine*, real* Vout, real* HVout, int skip_hv_outside);
   int (*gd_rows_mid)(Engine*);
   int (*gd_rows_update)(Engine*, const GdScalars*, const real* alpha);
   int (*gd_rows_update_fwd)(Engine*, const GdScalars*, const real* alpha);
   int (*cols_passA)(Engine*, const ColPass*, real2* S, int nplanes, int inverse, int kid);
   int (*admm_mid)(Engine*, const ColPass*, const AdmmScalars*, real sb_outside_scale);
+  int k1_rows;    // admm_rows_fwd_x takes the TV / W half of the image-domain work as well (k_rfwd_arrays_x<.., K1>)
   int gd_v2;      // the module holds k_gd_resid_v2 / k_gd_update_fwd_v2 for its row plan (lpc_gd_v2_kernels.h)
 };
 // lpc_jit.cpp: the module of `spec` -- from the process cache, from disk, or (allow_compile) compiled now; null + `why`
@@ -263,7 +265,7 @@ int build_plan_module(const PlanSpec& spec, const EngineOpts& opt, std::string* 
 int rows_fwd_single(Engine* e, const RealSrc& src, real2* S, int nplanes, int kid);
 int rows_inv_single(Engine* e, const real2* S, const RealDst& dst, int nplanes, int kid);
 int admm_rows_fwd(Engine* e);                                   // e->Rsp, e->Aarr -> the two work spectra
-int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc);          // e->Rsp and (xi, HV, HV_old, y) -> the two work spectra
+int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc, const K1Rows* k1 = nullptr);          // e->Rsp and (xi, HV, HV_old, y) -> the two work spectra
 int admm_rows_inv(Engine* e, real* Vout, real* HVout, bool skip_hv_outside = false);          // the two work spectra -> V, H V
 // lpc_cols.cpp
 int cols_passA(Engine* e, real2* S, int nplanes, bool inverse, int zr0, int zr1, int kid, bool crop_rows_only = false,

@@ -472,6 +472,7 @@ __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, PL plan,
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = LPC_TID(NT);
+  LPC_STAMP_BEGIN(3);
   const long pl = LPC_BY(g);
   const PairedRows pr = paired_rows_of(g, LPC_BX(g), window_only != 0);
   const bool vb = pr.second;
@@ -488,6 +489,7 @@ __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, PL plan,
   else
     fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out, NoFix{},
                                                     R2 ? 1 : 0, 0);
+  LPC_STAMP_END();
 }
 
 // ---- inverse, generic: spectrum rows -> ONE real sink with ifftshift (+ crop) -----------
@@ -568,6 +570,9 @@ __global__ __launch_bounds__(NT) void k_rinv_rows_half(PlaneGeom g, PL plan, con
 #endif
 #ifndef LPC_SEQ_FUSE1
 #define LPC_SEQ_FUSE1 false  // sequential ADMM middle: first stage of the forward transforms fused into the tile loads
+#endif
+#ifndef LPC_MID_CONSTS_LATE
+#define LPC_MID_CONSTS_LATE 1
 #endif
 #ifndef LPC_COLS_FUSEL
 #define LPC_COLS_FUSEL true
@@ -928,6 +933,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = LPC_TID(NT);
+  LPC_STAMP_BEGIN(2);
   // (compile-time plans: the tile width is a constant -- e / T, e % T are shifts, not reciprocal multiplies)
   const int T = is_static_plan<PL>::value ? SBT2 / 2 : cp.T, T2 = 2 * T;
   unsigned bid = cp.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;
@@ -949,58 +955,91 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   const unsigned r8 = (unsigned)rstep * c8, r4 = (unsigned)rstep * c4;
   real2 h[EP];
   real rd[EP];
+  // spectral constants: in flight during the forward FFT.  Compile-time plans issue them BEHIND the tile loads (hook of
+  // fft_tile): the memory counter is in order, and in front of them they delayed the first stage by their own latency --
+  // one small frame is a chain of latencies (profiles/r05_notes.md section 5)
+  // Branch-free: loads behind `if (e < npair)` / `if (c0 + j < Wc)` each got a `s_waitcnt vmcnt(0)` of their own (five
+  // latencies one after the other per lane at C1).  Lanes without an element load element 0, columns past the frame's edge
+  // the frame's last column; neither value is used.
+  const int jmax = g.Wc - 1 - c0;
+  auto consts_of = [&](auto terms_c) {
+    constexpr bool TERMS = decltype(terms_c)::value;
 #pragma unroll
-  for (int k = 0; k < EP; ++k) {      // spectral constants: in flight during the forward FFT
-    const int e = tid + k * NT;
-    h[k] = make_real2((real)0., (real)0.);
-    rd[k] = (real)0.;
-    if (e < npair) {
-      const int i = (is_static_plan<PL>::value ? e / T : (int)fd_div((unsigned)e, cp.tdiv));
-      const int j = e - i * T;
-      if (c0 + j < g.Wc) {                      // rd: |G| for now
-        if (O32) h[k] = ld_off(hb, mul24((unsigned)i, r8) + (unsigned)j * c8);
-        else h[k] = hb[i * rstep + j];
-        if (cp.ga) rd[k] = cp.ga[grp * cp.gstride + i * cp.istride] + cp.gb[c0 + j];
-        else if (O32) rd[k] = ld_off(rb, mul24((unsigned)i, r4) + (unsigned)j * c4);
-        else rd[k] = rb[i * rstep + j];
-      }
+    for (int k = 0; k < EP; ++k) {
+      const int e = tid + k * NT, ec = e < npair ? e : 0;
+      const int i = (is_static_plan<PL>::value ? ec / T : (int)fd_div((unsigned)ec, cp.tdiv));
+      const int j = ec - i * T, jc = j < jmax ? j : jmax;
+      if (O32) h[k] = ld_off(hb, mul24((unsigned)i, r8) + (unsigned)jc * c8);
+      else h[k] = hb[i * rstep + jc];
+      if (TERMS) rd[k] = cp.ga[grp * cp.gstride + i * cp.istride] + cp.gb[c0 + jc];      // rd: |G| for now
+      else if (O32) rd[k] = ld_off(rb, mul24((unsigned)i, r4) + (unsigned)jc * c4);
+      else rd[k] = rb[i * rstep + jc];
     }
-  }
+  };
+  auto consts = [&]() {
+    if (cp.ga) consts_of(std::true_type{});
+    else consts_of(std::false_type{});
+  };
+  if constexpr (!(is_static_plan<PL>::value && LPC_MID_CONSTS_LATE)) consts();
   // sb_outside_scale != 0 (AdmmScalars::skipa, single-pass columns only): the rows of SB outside the sensor window were
   // not re-transformed; they hold rfft(H V row) / Wp from the last inverse row pass, and a = mu1 H V there
   const real sb_k = sb_outside_scale != (real)0. ? sb_outside_scale : (real)1.;
+  // The tile loads carry neither a branch nor arithmetic (a column past the frame's edge is a copy of the frame's last
+  // column: an independent transform that is never stored); the scale of SB's rows is applied where the value goes into
+  // LDS (`fix` of fft_tile) -- with the product behind the load the one guarded element of a lane waited for ALL loads.
   auto in = [&](int i, int c) {
-    const int j = c < T ? c : c - T;
-    real2 x = make_real2((real)0., (real)0.);
-    if (c0 + j < g.Wc)
-      x = O32 ? ld_off(c < T ? ba : bb, mul24((unsigned)i, r8) + (unsigned)j * c8) : (c < T ? ba : bb)[i * rstep + j];
+    const int j = c < T ? c : c - T, jc = j < jmax ? j : jmax;
+    return O32 ? ld_off(c < T ? ba : bb, mul24((unsigned)i, r8) + (unsigned)jc * c8) : (c < T ? ba : bb)[i * rstep + jc];
+  };
+  auto in_fix = [&](int i, int c, real2 x) {
     return cscale(x, (c >= T && (unsigned)(i - g.sh) >= (unsigned)g.H) ? sb_k : (real)1.);
   };
-  if constexpr (is_static_plan<PL>::value && TWLDS) plan = twiddles_to_lds<NT>(plan, s + PL::n * SBT2, tid);
-  if constexpr (is_static_plan<PL>::value)
-    fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1, false, SBT2>(s, plan, T2, t2div, tid, in, LdsNatural{});
-  else
-    fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1>(s, plan, T2, t2div, tid, in, LdsNatural{});
+  if constexpr (is_static_plan<PL>::value) {
+    if constexpr (LPC_MID_CONSTS_LATE) {
+      // behind the tile loads: the twiddle table's loads (-> LDS, lpc_sfft.h), then the constants
+      const PL gplan = plan;
+      if constexpr (TWLDS) plan.tw = s + PL::n * SBT2;
+      real2* twl = s + PL::n * SBT2;
+      auto hook = [&]() {
+        if constexpr (TWLDS) twiddles_to_lds_around<NT>(gplan, twl, tid, consts);
+        else consts();
+      };
+      fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1, false, SBT2>(s, plan, T2, t2div, tid, in, LdsNatural{}, in_fix, hook);
+    } else {
+      if constexpr (TWLDS) plan = twiddles_to_lds<NT>(plan, s + PL::n * SBT2, tid);
+      fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1, false, SBT2>(s, plan, T2, t2div, tid, in, LdsNatural{}, in_fix);
+    }
+  } else
+    fft_tile<NT, EMAX, false, false, false, LPC_MID_FUSE1>(s, plan, T2, t2div, tid, in, LdsNatural{}, in_fix);
+  // (branch-free like the constants, only the two LDS stores are conditional; all phase factors are requested before the
+  // first is used: loaded where they were used, every element waited for its own pair)
+  real2 pr[EP], pc[EP];
 #pragma unroll
   for (int k = 0; k < EP; ++k) {
-    const int e = tid + k * NT;
-    if (e < npair) {
-      const int i = (is_static_plan<PL>::value ? e / T : (int)fd_div((unsigned)e, cp.tdiv));
-      const int j = e - i * T;
-      if (c0 + j < g.Wc) {
-        const real2 hh = h[k];
-        // R_divmat = 1 / (mu1 |H* H| + mu2 |PsiT Psi| + mu3)  (admm.py:186-190), formed on the fly so
-        // that per-iteration step sizes cost nothing; rscale folds the inverse FFT's 1/(Hp*Wp)
-        const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * rd[k] + mu3);
-        const real2 ph = cmul(phr[grp * cp.gstride + i * cp.istride], phc[c0 + j]);
-        const real2 rh = s[i * T2 + j];
-        const real2 ah = s[i * T2 + T + j];
-        real2 t = cmul(cmul_conj(ah, hh), ph);          // s * conj(H) * Ah
-        real2 vh = cscale(cadd(rh, t), rdiv);
-        real2 hv = cmul(cmul(vh, hh), ph);
-        s[i * T2 + j] = vh;
-        s[i * T2 + T + j] = hv;
-      }
+    const int e = tid + k * NT, ec = e < npair ? e : 0;
+    const int i = (is_static_plan<PL>::value ? ec / T : (int)fd_div((unsigned)ec, cp.tdiv));
+    const int j = ec - i * T, jc = j < jmax ? j : jmax;
+    pr[k] = phr[grp * cp.gstride + i * cp.istride];
+    pc[k] = phc[c0 + jc];
+  }
+#pragma unroll
+  for (int k = 0; k < EP; ++k) {
+    const int e = tid + k * NT, ec = e < npair ? e : 0;
+    const int i = (is_static_plan<PL>::value ? ec / T : (int)fd_div((unsigned)ec, cp.tdiv));
+    const int j = ec - i * T, jc = j < jmax ? j : jmax;
+    const real2 hh = h[k];
+    // R_divmat = 1 / (mu1 |H* H| + mu2 |PsiT Psi| + mu3)  (admm.py:186-190), formed on the fly so
+    // that per-iteration step sizes cost nothing; rscale folds the inverse FFT's 1/(Hp*Wp)
+    const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * rd[k] + mu3);
+    const real2 ph = cmul(pr[k], pc[k]);
+    const real2 rh = s[i * T2 + jc];
+    const real2 ah = s[i * T2 + T + jc];
+    real2 t = cmul(cmul_conj(ah, hh), ph);          // s * conj(H) * Ah
+    real2 vh = cscale(cadd(rh, t), rdiv);
+    real2 hv = cmul(cmul(vh, hh), ph);
+    if (e < npair && j <= jmax) {
+      s[i * T2 + j] = vh;
+      s[i * T2 + T + j] = hv;
     }
   }
   __syncthreads();
@@ -1015,6 +1054,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
     fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL, SBT2>(s, plan, T2, t2div, tid, LdsNatural{}, out);
   else
     fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL>(s, plan, T2, t2div, tid, LdsNatural{}, out);
+  LPC_STAMP_END();
 }
 
 // ---- the same fused middle, ONE ARRAY AT A TIME through a tile of T image columns (single-pass columns only) ------
@@ -1041,6 +1081,7 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   const int tid = threadIdx.x;
   constexpr int T = SBT, N = PL::n, NELEM = N * T, EM = (NELEM + NT - 1) / NT;
   static_assert(EM <= EMAX, "tile does not fit the workgroup shape");
+  LPC_STAMP_BEGIN(2);
   // 1-D grid of (column tiles x planes) workgroups, FRAMES FASTEST: all frames of a batch share H and |G|, and block b
   // runs on XCD b % 8 -- consecutive blocks are the same column tile of the same PSF plane in different frames, so each
   // XCD's L2 fetches that tile of H / |G| from HBM once and serves it to the frames it owns.  (With the tile index
@@ -1196,6 +1237,7 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   __syncthreads();
   auto outB = [=](int i, int j, real2 x) { if (j < wc) st_off(bb, mul24((unsigned)i, r8) + (unsigned)j * c8, x); };
   fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, outB);
+  LPC_STAMP_END();
 }
 
 // ============================================================ ADMM spatial kernel ==
@@ -1701,6 +1743,115 @@ __global__ __launch_bounds__(NT) void k_rfwd_half_x(PlaneGeom g, AdmmScalars p, 
   untangle_half_store<NT, SK>(s, g.Wp >> 1, twW, SB + pl * g.cplane + (long)gr * g.cpitch, tid);
 }
 
+// ---- the TV / W half of the image-domain work on the quads of TWO adjacent rows (k_rfwd_arrays_x<.., K1 = true>) ----
+// Small frames are a chain of dependent launches, each a chain of memory latencies (profiles/r05_notes.md section 5):
+// here the forward row block of r_sp rows (r0, r0 + 1) forms them itself -- the statements of k_admm_spatial_v4<..,
+// XHALF = false>, quad by quad, with the stencil's neighbours read straight from global memory (L2-resident at these
+// sizes) instead of a staged tile -- so that an iteration is three launches instead of four and r_sp never exists in
+// memory.  v, vo, eta*, rho: plane bases; q: the lane's quad (columns 4 q .. 4 q + 3); second: row r0 + 1 exists; the
+// rows go into the tile s as z = r_sp[r0] + i r_sp[r0 + 1].  Rows wrap circularly like the tiled kernel's; eta is read at
+// rows owned by other blocks, hence eta*_out (ping-pong).
+template <int SK>
+static __device__ __forceinline__ void k1_two_rows(const PlaneGeom& g, const AdmmScalars& p, const real* LPC_RESTRICT v,
+                                                   const real* LPC_RESTRICT vo, const real* LPC_RESTRICT eta0,
+                                                   const real* LPC_RESTRICT eta1, real* LPC_RESTRICT eta0_out,
+                                                   real* LPC_RESTRICT eta1_out, real* rho, int r0, bool second, int q,
+                                                   real2* s) {
+  constexpr unsigned eb = (unsigned)sizeof(real);
+  const int gc = 4 * q;
+  // 32-bit byte offsets from the plane bases (a plane is < 4 GB); circular column / row neighbours (a row that does not
+  // exist is never used: `second`)
+  const unsigned bq = (unsigned)gc * eb;
+  const unsigned bl = (unsigned)(gc == 0 ? g.Wp - 1 : gc - 1) * eb, br = (unsigned)(gc + 4 >= g.Wp ? 0 : gc + 4) * eb;
+  const unsigned rp = (unsigned)g.rpitch * eb;
+  unsigned ro[4];
+  ro[0] = (unsigned)(r0 == 0 ? g.Hp - 1 : r0 - 1) * rp;
+  ro[1] = (unsigned)r0 * rp;
+  ro[2] = (unsigned)(r0 + 1 >= g.Hp ? r0 + 1 - g.Hp : r0 + 1) * rp;
+  ro[3] = (unsigned)(r0 + 2 >= g.Hp ? r0 + 2 - g.Hp : r0 + 2) * rp;
+  auto L4 = [](const real* b, unsigned off) { return *(const real4*)((const char*)b + off); };
+  auto L1 = [](const real* b, unsigned off) { return *(const real*)((const char*)b + off); };
+  auto S4 = [](real* b, unsigned off, real4 x) { *(real4*)((char*)b + off) = x; };
+  const bool need_old = !p.first && !p.half_in;
+  // every load of both rows first -- except V_old's, which only a call's first iteration without a reset (or k1_half=0)
+  // reads: those are requested row by row below (their registers would otherwise cost every launch a workgroup per CU)
+  real4 v4[4], e04[3], e14[2], rh4[2];
+  real vl[2], vr[2], e1r[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) v4[k] = L4(v, ro[k] + bq);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) { vl[k] = L1(v, ro[1 + k] + bl); vr[k] = L1(v, ro[1 + k] + br); }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) e04[k] = L4(eta0, ro[1 + k] + bq);
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    e14[k] = L4(eta1, ro[1 + k] + bq);
+    e1r[k] = L1(eta1, ro[1 + k] + br);
+    rh4[k] = L4(rho, ro[1 + k] + bq);
+  }
+#pragma unroll
+  for (int row = 0; row < 2; ++row) {
+    if (row == 1 && !second) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[lds_slot<SK>(gc + i)].y = (real)0.;
+      break;
+    }
+    const int gr = r0 + row;
+    const real4 z4 = make_real4((real)0., (real)0., (real)0., (real)0.);
+    real4 om4 = z4, oc4 = z4, op4 = z4;
+    real ol = (real)0., orr = (real)0.;
+    if (need_old) {
+      om4 = L4(vo, ro[row] + bq); oc4 = L4(vo, ro[row + 1] + bq); op4 = L4(vo, ro[row + 2] + bq);
+      ol = L1(vo, ro[row + 1] + bl); orr = L1(vo, ro[row + 1] + br);
+    }
+    const real4 vm4 = v4[row], vc4 = v4[row + 1], vp4 = v4[row + 2];
+    const real vcs[6] = {vl[row], vc4.x, vc4.y, vc4.z, vc4.w, vr[row]};       // cols gc-1 .. gc+4 of row gr
+    const real ocs[6] = {ol, oc4.x, oc4.y, oc4.z, oc4.w, orr};
+    const real vms[4] = {vm4.x, vm4.y, vm4.z, vm4.w}, vps[4] = {vp4.x, vp4.y, vp4.z, vp4.w};
+    const real oms[4] = {om4.x, om4.y, om4.z, om4.w}, ops[4] = {op4.x, op4.y, op4.z, op4.w};
+    const real4 rho4 = rh4[row], e0c4 = e04[row], e0d4 = e04[row + 1], e1c4 = e14[row];
+    const real rhs[4] = {rho4.x, rho4.y, rho4.z, rho4.w};
+    const real e0s[4] = {e0c4.x, e0c4.y, e0c4.z, e0c4.w}, e0ds[4] = {e0d4.x, e0d4.y, e0d4.z, e0d4.w};
+    const real e1s[5] = {e1c4.x, e1c4.y, e1c4.z, e1c4.w, e1r[row]};
+    real q1[5], e1n[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i)   // column-difference component at cols gc .. gc+4 (the 5th only for q)
+      tv_component(p, vcs[i + 1], vcs[i], ocs[i + 1], ocs[i], e1s[i], e1n[i], q1[i]);
+    real e0n[4], rhn[4];
+    const bool row_in = (gr >= g.sh) && (gr < g.sh + g.H);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      real q0c, q0d, dummy;
+      tv_component(p, vcs[i + 1], vms[i], ocs[i + 1], oms[i], e0s[i], e0n[i], q0c);   // this pixel
+      tv_component(p, vps[i], vcs[i + 1], ops[i], ocs[i + 1], e0ds[i], dummy, q0d);   // the pixel below
+      const real vc = vcs[i + 1];
+      real rhov = rhs[i];
+      const int cc = gc + i;
+      const bool inside = row_in && (cc >= g.sw) && (cc < g.sw + g.W);
+      if (!p.first) {
+        if (p.half_in) {
+          rhov = rhov + p.mu3p * vc;                // stored: rho - mu3p W_old (AdmmScalars::half_in)
+        } else {
+          const real wo = rmax(div_by(rhov, p.mu3p, p.r_mu3p) + w_sees(ocs[i + 1], p.clamp_old, inside), (real)0.);
+          rhov = rhov + p.mu3p * (vc - wo);
+        }
+      }
+      const real wn = rmax(div_by(rhov, p.mu3, p.r_mu3) + w_sees(vc, p.clamp_cur, inside), (real)0.);
+      const real d1 = q0d - q0c;
+      const real d2 = q1[i + 1] - q1[i];
+      rhn[i] = p.half_out ? rhov - p.mu3 * wn : rhov;
+      const real rs = (p.mu3 * wn - rhov) + (d1 + d2);
+      // z = r_sp[r0] + i r_sp[r0 + 1]: the tile entry's real / imaginary part
+      if (row == 0) s[lds_slot<SK>(gc + i)].x = rs;
+      else s[lds_slot<SK>(gc + i)].y = rs;
+    }
+    const unsigned o = ro[1 + row] + bq;
+    S4(rho, o, make_real4(rhn[0], rhn[1], rhn[2], rhn[3]));
+    S4(eta0_out, o, make_real4(e0n[0], e0n[1], e0n[2], e0n[3]));
+    S4(eta1_out, o, make_real4(e1n[0], e1n[1], e1n[2], e1n[3]));
+  }
+}
+
 // ---- paired forward rows with the X half computed on the fly (narrow frames: C1 / C4, 760 x 1014) ---------------
 // Same split of the image-domain work as k_rfwd_half_x, for frames whose rows ride in pairs (paired_rows_of: two rows of
 // ONE array per transform).  Blocks of array 0 transform two stored rows of r_sp (k_admm_spatial_v4<.., XHALF = false>
@@ -1708,18 +1859,47 @@ __global__ __launch_bounds__(NT) void k_rfwd_half_x(PlaneGeom g, AdmmScalars p, 
 // the source functor of the first FFT stage (which also stores xi').  p.skipa: `a` on the rows of the sensor window
 // alone -- outside it a = mu1 HV needs no transform, SB keeps the row spectra the last inverse row pass read and the
 // fused middle rescales them (AdmmScalars::skipa).  Compile-time plans only.
-template <int NT, int EMAX, int SK, class PL>
-__global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p, PL plan, const real* LPC_RESTRICT Rsp,
+#ifndef LPC_K1ROWS_MINW
+#define LPC_K1ROWS_MINW 1
+#endif
+#ifndef LPC_RFWDX_MINW
+#define LPC_RFWDX_MINW 1
+#endif
+// K1 (rows of at most 4 NT columns): the blocks of array 0 form their two rows of r_sp themselves (k1_two_rows: V,
+// V_old, eta, rho in; eta', rho' out) instead of reading what the tiled kernel stored -- that kernel is not launched.
+struct K1Rows {
+  const real *V, *Vold, *eta0, *eta1;
+  real *eta0_out, *eta1_out, *rho;
+};
+template <int NT, int EMAX, int SK, class PL, bool K1 = false>
+__global__ __launch_bounds__(NT, K1 ? LPC_K1ROWS_MINW : NT == 256 ? LPC_RFWDX_MINW : 1) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p, PL plan, const real* LPC_RESTRICT Rsp,
                                                        const real* LPC_RESTRICT HV, const real* LPC_RESTRICT HVold,
                                                        real* LPC_RESTRICT xi, const real* LPC_RESTRICT Y,
-                                                       real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB) {
+                                                       real2* LPC_RESTRICT SA, real2* LPC_RESTRICT SB, K1Rows k1) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   const int tid = LPC_TID(NT);
+  LPC_STAMP_BEGIN(1);
   const long pl = LPC_BY(g);
   const PairedRows pr = paired_rows_of(g, LPC_BX(g), p.skipa != 0);
   const bool v1 = pr.second;
   const long o_row = pl * g.rplane + (long)pr.r0 * g.rpitch;
+  if (K1 && pr.arr == 0) {
+    if constexpr (K1) {
+      static_assert((PL::n >> 2) <= NT, "one quad per lane and row");
+      if (tid < (PL::n >> 2)) {
+        const long po = pl * g.rplane;
+        k1_two_rows<SK>(g, p, k1.V + po, k1.Vold + po, k1.eta0 + po, k1.eta1 + po, k1.eta0_out + po, k1.eta1_out + po,
+                        k1.rho + po, pr.r0, v1, tid, s);
+      }
+      __syncthreads();
+      fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
+      real2* o0 = SA + pl * g.cplane + (long)pr.r0 * g.cpitch;
+      untangle_store<NT, SK>(s, g.Wp, g.Wc, o0, o0 + g.cpitch, v1, tid);
+      LPC_STAMP_END();
+    }
+    return;
+  }
   if (pr.arr == 0) {
     const real* ra = Rsp + o_row;
     const real* rb = ra + g.rpitch;
@@ -1727,6 +1907,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p
     fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, two, LdsNatural{});
     real2* o0 = SA + pl * g.cplane + (long)pr.r0 * g.cpitch;
     untangle_store<NT, SK>(s, g.Wp, g.Wc, o0, o0 + g.cpitch, v1, tid);
+    LPC_STAMP_END();
     return;
   }
   // two rows of a = mu1 X - xi' (xhalf_load / xhalf_apply): every 16-byte load of both rows is in flight before the
@@ -1741,29 +1922,49 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p
   const real* y1 = y0 + g.W;
   const long o_row1 = o_row + g.rpitch;
   const bool y4 = ((g.sw | g.W) & 3) == 0;
-  const int q0 = tid < n4 ? tid : 0;
-  XQuad n0 = xhalf_load(g, p, HV, HVold, xi, y0, o_row, in0, y4, q0);
-  XQuad n1 = xhalf_load(g, p, HV, HVold, xi, y1, v1 ? o_row1 : o_row, in1, y4, q0);
-#pragma unroll 1
-  for (int q = tid; q < n4; q += NT) {
-    const int gc = 4 * q;
-    const XQuad c0 = n0, c1 = n1;
-    if (q + NT < n4) {
-      n0 = xhalf_load(g, p, HV, HVold, xi, y0, o_row, in0, y4, q + NT);
-      n1 = xhalf_load(g, p, HV, HVold, xi, y1, v1 ? o_row1 : o_row, in1, y4, q + NT);
-    }
-    real x0[4], a0[4], x1[4], a1[4];
-    xhalf_apply(p, c0, x0, a0);
-    xhalf_apply(p, c1, x1, a1);
-    if (!c0.skip || p.xi_store) st4(xi + o_row + gc, make_real4(x0[0], x0[1], x0[2], x0[3]));
-    if (v1 && (!c1.skip || p.xi_store)) st4(xi + o_row1 + gc, make_real4(x1[0], x1[1], x1[2], x1[3]));
+  // (compile-time plans: Wp == PL::n.  One quad per lane when the row fits the workgroup -- no loop, no second set of
+  // quads in flight: 88 -> VGPRs of the one-trip form, and with them the number of workgroups a CU holds; at C1 1620
+  // workgroups are launched and only 1280 of the two-set form were resident, profiles/r05_notes.md section 5)
+  constexpr int N4C = PL::n >> 2;
+  if constexpr (N4C <= NT) {
+    if (tid < N4C) {
+      const int gc = 4 * tid;
+      const XQuad c0 = xhalf_load(g, p, HV, HVold, xi, y0, o_row, in0, y4, tid);
+      const XQuad c1 = xhalf_load(g, p, HV, HVold, xi, y1, v1 ? o_row1 : o_row, in1, y4, tid);
+      real x0[4], a0[4], x1[4], a1[4];
+      xhalf_apply(p, c0, x0, a0);
+      xhalf_apply(p, c1, x1, a1);
+      if (!c0.skip || p.xi_store) st4(xi + o_row + gc, make_real4(x0[0], x0[1], x0[2], x0[3]));
+      if (v1 && (!c1.skip || p.xi_store)) st4(xi + o_row1 + gc, make_real4(x1[0], x1[1], x1[2], x1[3]));
 #pragma unroll
-    for (int i = 0; i < 4; ++i) s[lds_slot<SK>(gc + i)] = make_real2(a0[i], v1 ? a1[i] : (real)0.);
+      for (int i = 0; i < 4; ++i) s[lds_slot<SK>(gc + i)] = make_real2(a0[i], v1 ? a1[i] : (real)0.);
+    }
+  } else {
+    const int q0 = tid < n4 ? tid : 0;
+    XQuad n0 = xhalf_load(g, p, HV, HVold, xi, y0, o_row, in0, y4, q0);
+    XQuad n1 = xhalf_load(g, p, HV, HVold, xi, y1, v1 ? o_row1 : o_row, in1, y4, q0);
+#pragma unroll 1
+    for (int q = tid; q < n4; q += NT) {
+      const int gc = 4 * q;
+      const XQuad c0 = n0, c1 = n1;
+      if (q + NT < n4) {
+        n0 = xhalf_load(g, p, HV, HVold, xi, y0, o_row, in0, y4, q + NT);
+        n1 = xhalf_load(g, p, HV, HVold, xi, y1, v1 ? o_row1 : o_row, in1, y4, q + NT);
+      }
+      real x0[4], a0[4], x1[4], a1[4];
+      xhalf_apply(p, c0, x0, a0);
+      xhalf_apply(p, c1, x1, a1);
+      if (!c0.skip || p.xi_store) st4(xi + o_row + gc, make_real4(x0[0], x0[1], x0[2], x0[3]));
+      if (v1 && (!c1.skip || p.xi_store)) st4(xi + o_row1 + gc, make_real4(x1[0], x1[1], x1[2], x1[3]));
+#pragma unroll
+      for (int i = 0; i < 4; ++i) s[lds_slot<SK>(gc + i)] = make_real2(a0[i], v1 ? a1[i] : (real)0.);
+    }
   }
   __syncthreads();
   fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
   real2* o1 = SB + pl * g.cplane + (long)pr.r0 * g.cpitch;
   untangle_store<NT, SK>(s, g.Wp, g.Wc, o1, o1 + g.cpitch, v1, tid);
+  LPC_STAMP_END();
 }
 
 // ---- plug-and-play ADMM: the U-prox is an external denoiser (admm.py:126-133,235-243,266-275,300-311) ----------

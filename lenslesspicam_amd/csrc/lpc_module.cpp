@@ -80,7 +80,8 @@ static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outsi
                   e->planW.tw, (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
 }
 #if LPC_MOD_ROW_X
-static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
+static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc, const K1Rows* k1) {
+  if (k1) return fail("internal: half-length rows do not hold the TV / W half");
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
@@ -175,16 +176,25 @@ static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outsi
                   row_arg(e), (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
 }
 #if LPC_MOD_ROW_X
-static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc) {
+constexpr bool kK1Rows = (RowP::n >> 2) <= RNT;     // one quad per lane and row: the TV / W half can ride along
+static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc, const K1Rows* k1) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   // sc->skipa: `a` on the rows of the sensor window alone
   const int xrows = paired_rows_grid(g, sc->skipa != 0);
+  if (k1) {
+    if constexpr (kK1Rows)
+      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA, true>, dim3(xrows, e->P), RNT, kRowSmem,
+                      geom_rev(e, e->opt.rev_rows & 1), *sc,
+                      row_arg(e), (const real*)e->Rsp, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1],
+                      e->xi, (const real*)e->Y, SA, SB, *k1);
+    return fail("internal: this module's rows do not hold the TV / W half");
+  }
   return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA>, dim3(xrows, e->P), RNT, kRowSmem,
                   geom_rev(e, e->opt.rev_rows & 1), *sc,
                   row_arg(e), (const real*)e->Rsp, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1],
-                  e->xi, (const real*)e->Y, SA, SB);
+                  e->xi, (const real*)e->Y, SA, SB, K1Rows{});
 }
 #endif
 #endif   // paired rows
@@ -237,6 +247,14 @@ static int m_admm_mid(Engine* e, const ColPass* cp, const AdmmScalars* sc, real 
 #endif
 
 // ================================================================================ table ==
+#if defined(LPC_STAMP)
+// timing builds (lpc_rt.h: LPC_STAMP; tools/stamp_timeline.py): the stamps of the last launch of every stamped kernel
+extern "C" int lpc_module_stamps(unsigned long long* dst, size_t bytes) {
+  if (bytes > sizeof(lpc_stamp_buf)) bytes = sizeof(lpc_stamp_buf);
+  if (hipDeviceSynchronize() != hipSuccess) return 1;
+  return hipMemcpyFromSymbol(dst, HIP_SYMBOL(lpc_stamp_buf), bytes, 0, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
+}
+#endif
 extern "C" int lpc_module_init(LpcModule* m, size_t engine_size, const char* src_fp) {
   if (!m || engine_size != sizeof(Engine) || !src_fp || std::strcmp(src_fp, LPC_SRC_FP) != 0) return 1;
   std::memset((void*)m, 0, sizeof(*m));
@@ -249,6 +267,9 @@ extern "C" int lpc_module_init(LpcModule* m, size_t engine_size, const char* src
   m->admm_rows_inv = m_admm_rows_inv;
 #if LPC_MOD_ROW_X
   m->admm_rows_fwd_x = m_admm_rows_fwd_x;
+#if LPC_MOD_ROW_KIND == LPC_ROWS_PAIRED
+  m->k1_rows = kK1Rows ? 1 : 0;
+#endif
 #endif
 #endif
 #if LPC_MOD_ROW_KIND == LPC_ROWS_HALF && LPC_MOD_FAMILY == LPC_FAM_GD

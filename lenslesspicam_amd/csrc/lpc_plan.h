@@ -140,6 +140,7 @@ struct EngineOpts {
   int hv_full = 0;            // every row of H V transformed in every iteration
   int xi_full = 0;            // xi kept on the whole padded frame
   int no_xhalf = 0;           // stand-alone image-domain kernel (no X half inside the forward rows)
+  int k1_rows = -1;           // TV / W half inside the forward rows (three launches per iteration): -1 small frames only
   int k1_half = 1;            // duals half-applied between the iterations of one call: the tiled kernel does not read V_old
                               // (9R -> 8R); 0: plain duals in every iteration (round 3)
   int k1_scalar = 0;          // ... in its scalar-lane form
@@ -223,6 +224,7 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "xi_full") o.xi_full = (int)iv;
       else if (k == "no_xhalf") o.no_xhalf = (int)iv;
       else if (k == "k1_half") o.k1_half = (int)iv;
+      else if (k == "k1_rows") o.k1_rows = (int)iv;
       else if (k == "k1_scalar") o.k1_scalar = (int)iv;
       else if (k == "no_r2") o.no_r2 = (int)iv;
       else if (k == "no_skew") o.no_skew = (int)iv;

@@ -66,8 +66,8 @@ int admm_rows_fwd(Engine* e) {
 
 // ---- ADMM: forward rows of r_sp (stored) and of a = mu1 X - xi' (computed in the kernel from xi, HV, HV_old, y) ------
 // compile-time plans only: k_rfwd_half_x (half-length rows) / k_rfwd_arrays_x (paired rows)
-int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc) {
-  if (e->mod && e->mod->admm_rows_fwd_x) return e->mod->admm_rows_fwd_x(e, &sc);
+int admm_rows_fwd_x(Engine* e, const AdmmScalars& sc, const K1Rows* k1) {
+  if (e->mod && e->mod->admm_rows_fwd_x) return e->mod->admm_rows_fwd_x(e, &sc, k1);
   return fail("internal: the X-half row kernel lives in the plan module");
 }
 

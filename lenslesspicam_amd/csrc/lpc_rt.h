@@ -113,6 +113,41 @@ static __device__ __forceinline__ int lpc_tid_below(unsigned nt) {
 }
 #define LPC_TID(nt) lpc_tid_below((unsigned)(nt))
 
+// LPC_STAMP (timing builds of a plan module only, tools/stamp_timeline.py): lane 0 of every workgroup writes the 100-MHz
+// real-time counter at kernel entry, behind every barrier and -- after its stores have been acknowledged -- at exit into
+// lpc_stamp_buf[kernel][workgroup][slot]; the last launch of each kernel stays readable through lpc_module_stamps().
+#if defined(LPC_STAMP)
+#define LPC_STAMP_KERNELS 4
+#define LPC_STAMP_WGS 4096
+#define LPC_STAMP_SLOTS 32
+static __device__ unsigned long long lpc_stamp_buf[LPC_STAMP_KERNELS * LPC_STAMP_WGS * LPC_STAMP_SLOTS];
+__shared__ unsigned lpc_stamp_lds[2];
+static __device__ __forceinline__ void lpc_stamp_put() {
+  if (threadIdx.x == 0) {
+    const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y, n = lpc_stamp_lds[1];
+    if (wg < LPC_STAMP_WGS && n < LPC_STAMP_SLOTS - 1)
+      lpc_stamp_buf[((size_t)lpc_stamp_lds[0] * LPC_STAMP_WGS + wg) * LPC_STAMP_SLOTS + 1 + n] = __builtin_amdgcn_s_memrealtime();
+    lpc_stamp_lds[1] = n + 1;
+  }
+}
+static __device__ __forceinline__ void lpc_stamp_begin(unsigned kid) {
+  if (threadIdx.x == 0) { lpc_stamp_lds[0] = kid; lpc_stamp_lds[1] = 0; }
+  lpc_stamp_put();
+}
+static __device__ __forceinline__ void lpc_stamp_end() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  lpc_stamp_put();
+  if (threadIdx.x == 0) {
+    const unsigned wg = blockIdx.x + gridDim.x * blockIdx.y;
+    if (wg < LPC_STAMP_WGS) lpc_stamp_buf[((size_t)lpc_stamp_lds[0] * LPC_STAMP_WGS + wg) * LPC_STAMP_SLOTS] = lpc_stamp_lds[1];
+  }
+}
+static __device__ __forceinline__ void lpc_sync_stamped() { __syncthreads(); lpc_stamp_put(); }
+#define __syncthreads() lpc_sync_stamped()
+#define LPC_STAMP_BEGIN(kid) lpc_stamp_begin(kid)
+#define LPC_STAMP_END() lpc_stamp_end()
+#endif
+
 // LDS-DMA: every active lane of the wave copies 16 bytes from ITS global address `gsrc` to LDS at the WAVE-UNIFORM byte
 // address of `lds_wave_base` + 16 * lane (global_load_lds_dwordx4: no VGPR destination, counted by vmcnt).  Written as
 // inline assembly so that the compiler does not know about the pending LDS write: a `__syncthreads()` then stays a bare
@@ -349,3 +384,8 @@ static __host__ __device__ __forceinline__ FastDiv make_fastdiv_dev1() {
 static __device__ __forceinline__ unsigned fd_div(unsigned n, FastDiv f) {
   return f.d == 1 ? n : __umulhi(n, f.m);
 }
+
+#ifndef LPC_STAMP_BEGIN
+#define LPC_STAMP_BEGIN(kid) ((void)0)
+#define LPC_STAMP_END() ((void)0)
+#endif

@@ -92,6 +92,26 @@ static __device__ __forceinline__ SPlanArg<P, LANE> twiddles_to_lds(SPlanArg<P, 
 }
 template <int NT>
 static __device__ __forceinline__ Fft1dPlan twiddles_to_lds(const Fft1dPlan& p, real2*, int) { return p; }
+// The same copy in two halves around `mid()`: the table's loads are ISSUED (no branch: lanes past the table read entry 0),
+// mid() issues whatever else the caller wants in flight, then the values go to LDS.  In straight-line code the compiler
+// waits with a count, not for everything -- twiddles_to_lds() in front of a kernel's tile loads cost every workgroup one
+// memory latency before its first tile load went out (profiles/r05_notes.md section 5).  The caller points pa.tw at dst.
+template <int NT, class P, bool LANE, class Mid>
+static __device__ __forceinline__ void twiddles_to_lds_around(const SPlanArg<P, LANE>& src, real2* dst, int tid, Mid mid) {
+  constexpr int TN = (P::n + NT - 1) / NT;
+  real2 v[TN];
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int q = tid + t * NT;
+    v[t] = src.tw[q < P::n ? q : 0];
+  }
+  mid();
+#pragma unroll
+  for (int t = 0; t < TN; ++t) {
+    const int q = tid + t * NT;
+    if (q < P::n) dst[q] = v[t];
+  }
+}
 
 template <class T> struct is_static_plan : std::false_type {};
 template <class P, bool LANE> struct is_static_plan<SPlanArg<P, LANE>> : std::true_type {};
@@ -351,10 +371,15 @@ static __device__ __forceinline__ void sfft_last_fused_h(real2* s, const LdsTw<P
 // ---- fft_tile, static-plan overload: same template parameters and call shape as the run-time one ----------------
 // EMAX must be n * BT / NT rounded up (the kernels' launch tables guarantee it); BT is passed as a run-time value for
 // source compatibility but MUST equal the compile-time SBT the kernel was instantiated for.
+// hook(): called once, right behind the issue of the tile loads (loads of constants a later step needs queue up BEHIND
+// the data the first stage waits for instead of in front of it)
+struct NoHook {
+  __device__ __forceinline__ void operator()() const {}
+};
 template <int NT, int EMAX, bool INV, int SKEW, bool SRC_LDS, bool FUSE1 = false, bool FUSEL = false, int SBT = 1,
-          class P, bool LANE, class Src, class Dst, class Fix = NoFix>
+          class P, bool LANE, class Src, class Dst, class Fix = NoFix, class Hook = NoHook>
 static __device__ __forceinline__ void fft_tile(real2* s, const SPlanArg<P, LANE>& pa, int /*BT*/, FastDiv /*btdiv*/, int tid,
-                                                 Src src, Dst dst, Fix fix = Fix()) {
+                                                 Src src, Dst dst, Fix fix = Fix(), Hook hook = Hook()) {
   constexpr int BT = SBT;
   constexpr int NELEM = P::n * BT;
   constexpr int EM = (NELEM + NT - 1) / NT;
@@ -366,6 +391,7 @@ static __device__ __forceinline__ void fft_tile(real2* s, const SPlanArg<P, LANE
   const real2* tw = pa.tw;
   if constexpr (fuse1) {
     sfft_first_fused<P, NT, BT, INV, SKEW, SRC_LDS>(s, tid, src, fix);
+    hook();
   } else if constexpr (!src_lds) {
     real2 v[EM];
 #pragma unroll
@@ -373,6 +399,7 @@ static __device__ __forceinline__ void fft_tile(real2* s, const SPlanArg<P, LANE
       const int e = tid + k * NT;
       if (!GUARD || e < NELEM) v[k] = src(e / BT, e % BT);
     }
+    hook();
     if (SRC_LDS) __syncthreads();
 #pragma unroll
     for (int k = 0; k < EM; ++k) {

@@ -378,7 +378,8 @@ def test_random_batches_through_the_sequential_middle(seed):
         o.set_data(frames[b])
         assert rel(full[b], o.apply(7)) <= 1e-5, (H, W, C, B, b, info)
     if "one spectrum at a time" in info:
-        opts = {"mid_seq": 1, "mid_pre": int(info.rstrip().endswith("p"))}
+        # (the same kernels: a single small frame would otherwise take the three-launch plan, option k1_rows)
+        opts = {"mid_seq": 1, "mid_pre": int(info.rstrip().endswith("p")), "k1_rows": int("three launches" in info)}
         if "128 threads" in info.split("columns:")[0]:
             opts["prow_nt128"] = 1
         single = lpa.ADMM(torch.from_numpy(psf).cuda(), engine_options=opts, **kw)

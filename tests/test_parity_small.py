@@ -789,6 +789,46 @@ def test_tiny_frames_circular_neighbours(backend, shape):
     assert rel(rec.apply(n_iter=8, disp_iter=None), want) <= 1e-5, rec._handle.plan_info()
 
 
+@pytest.mark.parametrize("shape", [(24, 32, 3), (13, 40, 1), (5, 128, 3), (2, 36, 1), (33, 50, 1)])
+def test_tv_half_inside_forward_rows(backend, monkeypatch, shape):
+    """Small frames run an ADMM iteration in three launches: the forward row blocks of r_sp form their two rows
+    themselves (k_rfwd_arrays_x<.., K1>, k1_two_rows: the tiled kernel's TV / W statements with the stencil's circular
+    neighbours read from global memory) and the tiled kernel is not launched (option k1_rows=1; automatic below 4 M padded
+    points).  Against the float64 oracle with the TV term active, across two calls (plain duals at the call boundary,
+    half-applied ones inside), with the duals stored plain throughout (k1_half=0: the V_old path), and against the
+    four-launch plan of the same engine; frames of 2 ... 33 rows, an odd number of padded rows included."""
+    H, W, C = shape
+    rng = np.random.default_rng(H * 100 + W)
+    psf = orc.synthetic_psf(1, H, W, C, seed=H + 3 * W)
+    y = rng.random((H, W, C), dtype=np.float32)
+    kw = dict(tau=5e-3, mu1=1e-2, mu2=1e-2, mu3=1e-2)
+    o = orc.ADMMOracle(psf, dtype=torch.float64, **kw)
+    o.set_data(y)
+    want5 = np.asarray(o.apply(5)).copy()
+    want8 = np.asarray(o.apply(3, reset=False)).copy()
+    assert float(np.abs(want8).max()) > 0
+    outs = {}
+    for tag, opts in (("rows", dict(k1_rows=1)), ("rows_plain_duals", dict(k1_rows=1, k1_half=0)), ("tiled", dict(k1_rows=0))):
+        engine_opts(monkeypatch, jit_min_points=0, **opts)
+        rec = lpa.ADMM(torch.from_numpy(psf), **kw)
+        rec.set_data(torch.from_numpy(y))
+        info = rec._handle.plan_info()
+        assert ("three launches per iteration" in info) == (tag != "tiled"), info
+        got5 = np.asarray(rec.apply(n_iter=5, disp_iter=None)).copy()
+        got8 = np.asarray(rec.apply(n_iter=3, disp_iter=None, reset=False)).copy()
+        assert rel(got5, want5) <= 1e-5 and rel(got8, want8) <= 1e-5, (tag, info)
+        outs[tag] = got8
+    assert rel(outs["rows"], outs["tiled"]) <= 2e-6
+
+
+@pytest.mark.parametrize("name", ["admm_24x32x3_tv", "admm_24x32x3_init_bg", "admm_24x32x3_default"])
+def test_tv_half_inside_forward_rows_golden(backend, monkeypatch, name):
+    """... and the reference's own trajectories (golden vectors: TV term, initial estimate + background, defaults) through
+    the three-launch plan."""
+    engine_opts(monkeypatch, jit_min_points=0, k1_rows=1)
+    test_admm_matches_reference_golden(backend, name)
+
+
 def test_gram_as_row_and_column_terms(backend, monkeypatch):
     """The reference's finite-difference gram |PsiT Psi| (admm.py:385-397) is a row term plus a column term; the engine
     detects that at set-up and its fused middles read two vectors instead of the plane (option g_plane=1: the plane).

@@ -11,7 +11,7 @@ import module_asm
 key, masks = sys.argv[1], sys.argv[2:]      # a mask may also be a -D list: "tag:-DLPC_V2_TC_RESID=0,-DX=1"
 csrc = os.path.join(ROOT, "lenslesspicam_amd", "csrc")
 lib = build.OUT_F64 if key.startswith("f64") else build.OUT
-fp = build.fingerprint()
+fp = open(os.path.join(os.path.dirname(lib), "BUILD_FP")).read().strip().split()[0] if os.path.exists(os.path.join(os.path.dirname(lib), "BUILD_FP")) else build.fingerprint()
 for m in masks:
     extra = ["-DLPC_V2_KNOCK_MASK=" + m]
     if ":" in m:

@@ -1,6 +1,6 @@
 """gfx950 assembly of one plan module: python tools/module_asm.py <plan-module key> [out.s] [csrc dir]
 (the key as lpc_plan_info() / build.py print it, e.g. f32_admm_rp960r8.8.5.3t1w128x8sx_ms540r6.10.9t8w256x17m4);
-feed the listing to tools/instmix.py."""
+feed the listing to tools/instmix.py.  LPC_ASM_EXTRA="-DX=1 ...": more compiler arguments."""
 import os
 import re
 import subprocess
@@ -52,7 +52,7 @@ def main():
     csrc = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "lenslesspicam_amd", "csrc")
     cmd = ["/opt/rocm/bin/hipcc", "-std=c++17", "-O3", "--offload-arch=gfx950", "-x", "hip", "-S", "--cuda-device-only",
            "-I", os.path.join(ROOT, "include"), "-I", csrc, '-DLPC_SRC_FP="asm"'] + defines(key) + [
-               os.path.join(csrc, "lpc_module.cpp"), "-o", out]
+               os.path.join(csrc, "lpc_module.cpp"), "-o", out] + os.environ.get("LPC_ASM_EXTRA", "").split()
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         sys.exit(r.stderr[-3000:])
