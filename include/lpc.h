@@ -98,8 +98,9 @@ typedef struct lpc_config {
  *   row_rad=16.16.8 passa_rad=16.8 mid_rad=6.10.9   radices of the compile-time row / pass-A / LDS-middle plan (tuning)
  *   k1_half=0          ADMM duals stored plain between the iterations of one call (default 1: half-applied, the tiled
  *                      kernel then does not read V_old: 9R -> 8R)
- *   k1_rows=0|1        ADMM: the TV / W half of the image-domain work inside the forward rows as well -- three launches per
- *                      iteration, r_sp never stored (default: padded points x planes <= 8 M, rows of one quad per lane)
+ *   k1_rows=0          ADMM: keep the tiled TV / W kernel (default 1: paired rows of one quad per lane -- padded widths up to
+ *                      1024 -- take that half of the image-domain work as well: three launches per iteration, r_sp never
+ *                      stored; such rows then run on 256 lanes at every batch size)
  *   mid_pre=0|1 mid_twg=1 seq_pair=1               sequential middle: both tiles' loads before the first transform (default:
  *                      launches of >= 4096 workgroups); twiddles from global memory; the two 64-byte tiles of a cache line
  *                      eight blocks apart on one XCD (measured: no gain)

@@ -35,13 +35,6 @@ static int upload(Engine* e, void* dst, const void* src, size_t bytes) {
   return 0;
 }
 
-// Engine::k1_rows, automatic choice: padded points x planes up to which the TV / W half rides in the forward rows
-// (C1 1.6 M: -7.6 %, 380 x 507 x 3 2.4 M: -7 %, four frames of C1's size 6.2 M: -8 %; larger batches run their rows on
-// 128 lanes and are not eligible -- profiles/r05_notes.md section 5)
-#ifndef LPC_K1_ROWS_MAX_POINTS
-#define LPC_K1_ROWS_MAX_POINTS 8.0e6
-#endif
-
 int big_smem_once(const void* fn, size_t smem) {
   static std::mutex mu;
   static std::unordered_set<uint64_t> done;
@@ -393,9 +386,13 @@ static void choose_plan(Engine* e, bool allow_static) {
     // short rows (960 = 8.8.5.3: 120 first-stage butterflies): 128 threads x 8 points for batches, where every lane
     // then owns a butterfly of the stage that issues the global loads (forward rows 0.642 -> 0.576 ms at 64 frames);
     // ONE frame is faster on 256 x 4 (0.460 vs 0.470 ms per 5 iterations, profiles/r02_notes.md)
+    // Round 5: ... unless the rows can take the TV / W half of the image-domain work as well (Engine::k1_rows: one
+    // quad per lane and row, i.e. 256 lanes here) -- three launches per iteration beat the better row shape at every batch
+    // size (64 frames 33.1 -> 31.0 ms per 20 iterations, 8 frames 4.27 -> 4.00 ms; profiles/r05_notes.md section 5)
     if (nt < 256 && n >= 512) {
       const bool batch = (long)e->P * g.Hp >= 8192;
-      if (o.prow_nt128 == 0 || (o.prow_nt128 < 0 && !batch)) nt = 256;
+      const bool k1r = xhalf && o.k1_rows != 0 && n % 4 == 0 && !o.k1_scalar;
+      if (o.prow_nt128 == 0 || (o.prow_nt128 < 0 && (!batch || k1r))) nt = 256;
     }
     if (o.row_nt >= 64 && o.row_nt <= 1024 && o.row_nt % 64 == 0) nt = o.row_nt;
     set_static_fft(sp.row, n, rad, 1, nt, (n + nt - 1) / nt);
@@ -544,11 +541,11 @@ static int setup_geometry(Engine* e) {
   // `a` compute xi' and a = mu1 X - xi' from xi, HV, HV_old, y themselves (-2R per iteration), the tiled kernel keeps
   // the stencil half at its own occupancy (option no_xhalf: the full stand-alone kernel) ...
   e->xhalf_rows = admm && e->mod && e->mod->admm_rows_fwd_x;
-  // ... small frames (every launch at most a few workgroups per CU: an iteration is a chain of launch boundaries and
-  // memory latencies, profiles/r05_notes.md section 5) hand it the TV / W half too: three launches per iteration
-  // (option k1_rows=0 / 1; modules whose row fits one quad per lane)
-  e->k1_rows = e->xhalf_rows && e->mod->k1_rows && g.Wp % 4 == 0 && !e->opt.k1_scalar &&
-               (e->opt.k1_rows >= 0 ? e->opt.k1_rows != 0 : (double)g.Hp * g.Wp * e->P <= LPC_K1_ROWS_MAX_POINTS);
+  // ... narrow frames (paired rows of one quad per lane: padded widths up to 1024) hand it the TV / W half too: three
+  // launches per iteration, r_sp never stored.  One small frame is a chain of launch boundaries and memory latencies
+  // (C1 -7.6 %), a batch saves the trip of r_sp through memory and the tiled kernel's launch (C4 -6.3 %);
+  // profiles/r05_notes.md section 5 (option k1_rows=0: off)
+  e->k1_rows = e->xhalf_rows && e->mod->k1_rows && g.Wp % 4 == 0 && !e->opt.k1_scalar && e->opt.k1_rows != 0;
   // ... outside the sensor window that half works from HV alone (AdmmScalars::xiw; option xi_full: every pixel alike) ...
   e->xi_window = e->xhalf_rows && !e->opt.xi_full;
   // ... and rows wholly outside it skip the H V row transforms in both directions: the kept rows of SB are rescaled by

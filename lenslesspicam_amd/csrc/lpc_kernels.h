@@ -571,6 +571,9 @@ __global__ __launch_bounds__(NT) void k_rinv_rows_half(PlaneGeom g, PL plan, con
 #ifndef LPC_SEQ_FUSE1
 #define LPC_SEQ_FUSE1 false  // sequential ADMM middle: first stage of the forward transforms fused into the tile loads
 #endif
+#ifndef LPC_SEQ_STEP3_BATCH
+#define LPC_SEQ_STEP3_BATCH 0
+#endif
 #ifndef LPC_MID_CONSTS_LATE
 #define LPC_MID_CONSTS_LATE 1
 #endif
@@ -1206,6 +1209,55 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   fft_tile<NT, EMAX, false, false, false, LPC_SEQ_FUSE1, false, SBT>(s, plan, T, cp.tdiv, tid, inA, LdsNatural{});
   }
   // 3. Vh = Rdiv (Rh + s conj(H) Ah) -> tile;  HVh = s H Vh -> the registers that held Ah
+#if LPC_SEQ_STEP3_BATCH > 0
+  // Timing experiment (tools/knock_modules.py -DLPC_SEQ_STEP3_BATCH=n; profiles/r05_notes.md section 5): ONE lane-constant
+  // branch around the step (a lane's column is tid % T in every round) and, inside it, the loads of n elements requested
+  // before the first product -- the default form below waits for each element's H, |G| and phase factor separately.
+  static_assert(NT % T == 0, "a lane keeps its column");
+  const int j0 = tid % T;
+  if (j0 < wc) {
+    constexpr int SB3 = LPC_SEQ_STEP3_BATCH, KFULL = NELEM / NT;
+    const real2 pc = ld_off(phc, (unsigned)(c0 + j0) * c8);
+    auto step3 = [&](auto terms_c) {
+      constexpr bool TERMS = decltype(terms_c)::value;
+      real gbv = (real)0.;
+      if constexpr (TERMS) gbv = ld_off(cp.gb, (unsigned)(c0 + j0) * c4);
+#pragma unroll
+      for (int k0 = 0; k0 < EM; k0 += SB3) {
+        real2 hh[SB3], pr[SB3];
+        real gk[SB3];
+#pragma unroll
+        for (int q = 0; q < SB3; ++q) {
+          const int k = k0 + q < EM ? k0 + q : EM - 1;
+          const int e = tid + k * NT, ec = (k < KFULL || e < NELEM) ? e : 0;
+          const int i = ec / T;
+          hh[q] = ld_off(hb, mul24((unsigned)i, r8) + (unsigned)j0 * c8);
+          if constexpr (TERMS) gk[q] = ld_off(cp.ga, (unsigned)i * c4) + gbv;
+          else gk[q] = ld_off(rb, mul24((unsigned)i, r4) + (unsigned)j0 * c4);
+          pr[q] = ld_off(phr, (unsigned)i * c8);
+        }
+#pragma unroll
+        for (int q = 0; q < SB3; ++q) {
+          const int k = k0 + q;
+          if (k < EM) {
+            const int e = tid + k * NT, ec = (k < KFULL || e < NELEM) ? e : 0;
+            const real rdiv = rscale * recip_pos(mu1 * rabs(hh[q].x * hh[q].x + hh[q].y * hh[q].y) + mu2 * gk[q] + mu3);
+            const real2 ph = cmul(pr[q], pc);
+            const real2 t = cmul(cmul_conj(a[k], hh[q]), ph);
+            const real2 vh = cscale(cadd(s[ec], t), rdiv);
+            a[k] = cmul(cmul(vh, hh[q]), ph);
+            if (k < KFULL || e < NELEM) s[e] = vh;
+          }
+        }
+#if LPC_SEQ_STEP3_FENCE
+        LPC_SCHED_FENCE();
+#endif
+      }
+    };
+    if (cp.ga) step3(std::true_type{});
+    else step3(std::false_type{});
+  }
+#else
 #pragma unroll
   for (int k = 0; k < EM; ++k) {
     const int e = tid + k * NT;
@@ -1223,6 +1275,7 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
       }
     }
   }
+#endif
   __syncthreads();
   // 4. V-hat back through the inverse transform, straight to SA
   auto outA = [=](int i, int j, real2 x) { if (j < wc) st_off(ba, mul24((unsigned)i, r8) + (unsigned)j * c8, x); };

@@ -140,7 +140,7 @@ struct EngineOpts {
   int hv_full = 0;            // every row of H V transformed in every iteration
   int xi_full = 0;            // xi kept on the whole padded frame
   int no_xhalf = 0;           // stand-alone image-domain kernel (no X half inside the forward rows)
-  int k1_rows = -1;           // TV / W half inside the forward rows (three launches per iteration): -1 small frames only
+  int k1_rows = 1;            // TV / W half inside the paired forward rows where a row is one quad per lane (three launches per iteration)
   int k1_half = 1;            // duals half-applied between the iterations of one call: the tiled kernel does not read V_old
                               // (9R -> 8R); 0: plain duals in every iteration (round 3)
   int k1_scalar = 0;          // ... in its scalar-lane form

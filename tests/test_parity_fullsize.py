@@ -344,11 +344,12 @@ def test_c4_batch64_vs_oracle_and_singles(c4_inputs):
         o.set_data(frames[b])
         assert rel(full[b], o.apply(20)) <= 1e-5, b
     # batch == singles (test/test_algos.py:198-229).  Bit for bit when the single-frame solver runs the kernels the
-    # batch ran: the engine picks the one-spectrum-at-a-time middle (with both tiles' loads issued up front) and the
-    # 128-thread paired rows for large batches only; the options mid_seq / mid_pre / prow_nt128 select them for one frame too.  The default single-frame plan (two spectra side
-    # by side, 8 columns each, 256-thread rows) is another instruction stream for the same arithmetic: equal to float32
-    # round-off.
-    single = lpa.ADMM(psf_d, engine_options={"mid_seq": 1, "prow_nt128": 1, "mid_pre": 1})
+    # batch ran: the engine picks the one-spectrum-at-a-time middle (with both tiles' loads issued up front) for large
+    # batches only; the options mid_seq / mid_pre select it for one frame too (the rows are the same since round 5: 256
+    # lanes with the TV / W half inside, at every batch size).  The default single-frame plan (two spectra side by side,
+    # 8 columns each) is another instruction stream for the same arithmetic: equal to float32 round-off.
+    single = lpa.ADMM(psf_d, engine_options={"mid_seq": 1, "mid_pre": 1})
+    assert "three launches per iteration" in rec._handle.plan_info()
     assert "one spectrum at a time" in single._handle.plan_info() and "one spectrum at a time" in rec._handle.plan_info()
     assert "row transforms skipped" in single._handle.plan_info() and "row transforms skipped" in rec._handle.plan_info()
     assert single._handle.plan_info().split("plan module")[1] == rec._handle.plan_info().split("plan module")[1]

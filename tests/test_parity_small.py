@@ -698,7 +698,9 @@ def test_c4_rows_on_128_threads(backend, monkeypatch):
     y = torch.from_numpy(rng.random((270, 480, 1), dtype=np.float32))
     outs = []
     for nt128 in (0, 1):
-        rec = lpa.ADMM(psf, engine_options={"prow_nt128": nt128})
+        # (k1_rows=0: the same kernels on both shapes -- one quad per lane and row, the three-launch plan's condition,
+        # holds on 256 lanes only)
+        rec = lpa.ADMM(psf, engine_options={"prow_nt128": nt128, "k1_rows": 0})
         assert f"{128 if nt128 else 256} threads" in rec._handle.plan_info()
         rec.set_data(y)
         outs.append(rec.apply(n_iter=3, disp_iter=None, plot=False))
@@ -793,10 +795,11 @@ def test_tiny_frames_circular_neighbours(backend, shape):
 def test_tv_half_inside_forward_rows(backend, monkeypatch, shape):
     """Small frames run an ADMM iteration in three launches: the forward row blocks of r_sp form their two rows
     themselves (k_rfwd_arrays_x<.., K1>, k1_two_rows: the tiled kernel's TV / W statements with the stencil's circular
-    neighbours read from global memory) and the tiled kernel is not launched (option k1_rows=1; automatic below 4 M padded
-    points).  Against the float64 oracle with the TV term active, across two calls (plain duals at the call boundary,
-    half-applied ones inside), with the duals stored plain throughout (k1_half=0: the V_old path), and against the
-    four-launch plan of the same engine; frames of 2 ... 33 rows, an odd number of padded rows included."""
+    neighbours read from global memory) and the tiled kernel is not launched (default wherever a paired row is one quad
+    per lane; option k1_rows=0: the tiled kernel).  Against the float64 oracle with the TV term active, across two calls
+    (plain duals at the call boundary, half-applied ones inside), with the duals stored plain throughout (k1_half=0: the
+    V_old path), and against the four-launch plan of the same engine; frames of 2 ... 33 rows, an odd number of padded
+    rows included."""
     H, W, C = shape
     rng = np.random.default_rng(H * 100 + W)
     psf = orc.synthetic_psf(1, H, W, C, seed=H + 3 * W)

@@ -25,19 +25,17 @@ EMU_DIR = os.path.join(ROOT, "tests", "simt_emu")
 SAN_LIB = os.path.join(EMU_DIR, "_build_san", "liblpc_emu.so")
 
 # one case of every kernel family, run-time plans and plan modules: paired and half-length ADMM rows with the X half and
-# the sensor-window structure, the tiled image-domain kernel, pass A + the LDS / register / sequential middles, the
-# gradient-descent family's fused rows (both forms), the operator, random odd shapes (about two minutes; LPC_SAN_FULL=1
-# adds everything else, the world-size-2 gloo tests included)
+# the sensor-window structure, the tiled image-domain kernel and its form inside the forward rows, the LDS / sequential
+# middles, the gradient-descent family's fused rows (both forms), a random odd shape (LPC_SAN_FULL=1 adds everything
+# else: pass A, the register middles, the operator, tiny frames, the world-size-2 gloo tests)
 SUBSET = " or ".join([
-    "test_convolver_golden and emu-a",
     "test_admm_matches_reference_golden and admm_24x32x3_tv",
     "test_gd_family_matches_reference_golden and fista_24x32x3",
     "test_admm_half_length_row_kernels and admm_24x32x3_tv and static_plan",
     "test_c4_sequential_middle_on_one_frame",
-    "test_forced_four_step_column_split and 48",
     "test_gd_fused_rows_second_form and shape0",
-    "test_random_small_shapes_through_plan_modules and (emu-0 or emu-1)",
-    "test_tiny_frames_circular_neighbours",
+    "test_tv_half_inside_forward_rows and shape0",
+    "test_random_small_shapes_through_plan_modules and emu-0",
 ])
 FILES = ["tests/test_parity_small.py"]
 FULL_FILES = ["tests/test_parity_small.py", "tests/test_norm_scale.py", "tests/test_parity_large.py", "tests/test_dist.py"]
