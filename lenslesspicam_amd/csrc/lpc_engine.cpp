@@ -821,7 +821,8 @@ static int admm_iterate(Engine* e, int n_iter) {
     sc.half_out = (k1_half && it + 1 < n_iter) ? 1 : 0;
     // small frames: the forward rows take the TV / W half as well (Engine::k1_rows) -- same buffers, same ping-pong
     const bool k1r = e->k1_rows && vec4;
-    const K1Rows k1 = {Vc, Vo, e->eta0[e->ecur], e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho};
+    const K1Rows k1 = {Vc, Vo, e->eta0[e->ecur], e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
+                       (long)paired_rows_grid(g, false) * e->P <= 8192 ? 1 : 0};
     if (k1r) {
     } else if (sc.half_in)
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4X, NT, false, true>, k1_grid4x, NT, k1_smem4x / 2, g, sc, (const real*)Vc,

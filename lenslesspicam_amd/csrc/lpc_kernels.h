@@ -1923,6 +1923,7 @@ static __device__ __forceinline__ void k1_two_rows(const PlaneGeom& g, const Adm
 struct K1Rows {
   const real *V, *Vold, *eta0, *eta1;
   real *eta0_out, *eta1_out, *rho;
+  int xcd_order;      // hand the row blocks out XCD by XCD (small launches, see the kernel)
 };
 template <int NT, int EMAX, int SK, class PL, bool K1 = false>
 __global__ __launch_bounds__(NT, K1 ? LPC_K1ROWS_MINW : NT == 256 ? LPC_RFWDX_MINW : 1) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p, PL plan, const real* LPC_RESTRICT Rsp,
@@ -1933,8 +1934,21 @@ __global__ __launch_bounds__(NT, K1 ? LPC_K1ROWS_MINW : NT == 256 ? LPC_RFWDX_MI
   real2* s = (real2*)smem;
   const int tid = LPC_TID(NT);
   LPC_STAMP_BEGIN(1);
-  const long pl = LPC_BY(g);
-  const PairedRows pr = paired_rows_of(g, LPC_BX(g), p.skipa != 0);
+  unsigned bx = LPC_BX(g), by = LPC_BY(g);
+  if (K1 && k1.xcd_order) {
+    // XCD-aware order (workgroup w runs on XCD w % 8, each with its own L2): the blocks of r_sp read V at rows r0 - 1 and
+    // r0 + 2 and eta at row r0 + 2 -- rows that belong to the neighbouring row pairs, which in launch order sit on OTHER
+    // XCDs.  Here every XCD walks a contiguous eighth of the (plane, row pair) space.  The host asks for it on small
+    // launches only (same box, trees: C1 0.217 -> 0.212 ms, 380 x 507 0.281 -> 0.269 ms per 5 iterations; 8 frames
+    // unchanged; C4's 64 frames 0.815 -> 0.855 ms per launch -- profiles/r05zb_xcd_order_trees.log)
+    const unsigned gx = gridDim.x, total = gx * gridDim.y, lin = bx + gx * by;
+    const unsigned qd = total >> 3, rm = total & 7u, xcd = lin & 7u, idx = lin >> 3;
+    const unsigned l2 = (xcd < rm ? xcd * (qd + 1u) : rm * (qd + 1u) + (xcd - rm) * qd) + idx;
+    by = l2 / gx;
+    bx = l2 - by * gx;
+  }
+  const long pl = by;
+  const PairedRows pr = paired_rows_of(g, bx, p.skipa != 0);
   const bool v1 = pr.second;
   const long o_row = pl * g.rplane + (long)pr.r0 * g.rpitch;
   if (K1 && pr.arr == 0) {

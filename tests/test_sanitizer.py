@@ -11,7 +11,7 @@ and a report is fatal.  The reference's counterpart is the anomaly check its own
 
 The default CPU suite runs a part of the parity suite on that flavour in a child process (the ASan runtime must be the
 first library of the process: LD_PRELOAD); `LPC_SAN_FULL=1` runs all of test_parity_small.py, test_norm_scale.py, the
-random-shape tests of test_parity_large.py and test_dist.py (about 25 minutes; last full run recorded in
+random-shape tests of test_parity_large.py and test_dist.py (about 50 minutes on 16 cores; last full run recorded in
 profiles/r05_sanitizer_full.log).
 """
 import os
