@@ -27,10 +27,11 @@ Rank 0 prints ONE JSON line.  On top of the driver's contract it carries:
                 (rows other than the roofline kernel's: one extra step after the timed region, all launches bracketed)
   cpu_baseline  the CPU oracle (torch-CPU float32 restatement of the reference, kind "port")
                 timed on this host for a bounded sample of the same workload
-  parity        full size (12 MP): engine vs the float32 oracle after >= 30 iterations (default AND TV-active
-                parameters; the oracle keeps stepping after the baseline sample, inside a time budget), vs the float64
-                oracle after 5, and the 100-iteration call vs the float64 build of the engine; plus the PSNR delta after
-                100 iterations on the 270x480x3 DiffuserCam-sized frame (configs[0] size)
+  parity        the timed call's own output (100 iterations at 12 MP) against the samples the REFERENCE produced on the same
+                closed-form inputs (tests/golden/longrun_c2.npz, made by tests/golden/gen_longrun.py from the imported
+                reference in float64 and float32): distance to the reference's float64 run, the reference's own float32
+                distance to it, PSNR delta vs the scene.  No CPU solver runs for it (tests/test_longrun_pins.py asserts the
+                same, and more, in the GPU suite).
 """
 import argparse
 import json
@@ -139,12 +140,6 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=3,
                     help="timed CPU-oracle iterations (SURVEY 8d: >= 3); two more are spent choosing the thread count")
     ap.add_argument("--no-parity", action="store_true")
-    ap.add_argument("--parity-iters", type=int, default=5, help="float64-oracle iterations at full size")
-    ap.add_argument("--parity-long-iters", type=int, default=30,
-                    help="float32-oracle iterations at full size the engine is compared after (per parameter set)")
-    ap.add_argument("--parity-budget-s", type=float, default=240.0,
-                    help="host seconds the float32 oracle may spend stepping towards --parity-long-iters, per parameter "
-                         "set; it stops early when the budget is spent and the comparison is made at the count reached")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the short C1 / C3 / C4 / C5 legs reported under 'other_configs'")
     ap.add_argument("--test-shape", type=lambda v: tuple(int(x) for x in v.split(",")), default=None,
@@ -153,19 +148,45 @@ def parse():
 
 
 def synth_inputs(H, W, C, seed, device):
-    """PSF: rng.random**12, L2-normalised (io.py:375).  Scene: Gaussian blobs.  Measurement:
-    clip(crop(scene (*) psf), 0)/max (io.py:196-197), produced with the engine's own operator
-    (it is only input data)."""
-    import lenslesspicam_amd as lpa
-    from oracle import lensless_oracle as orc
+    """Closed-form inputs (tests/golden/longrun_inputs.py; exact float32 operations, the same bits on every machine):
+    PSF = uniform**12 scaled to unit energy (lensless/utils/io.py:375), measurement = broad bumps + sensor
+    noise, clipped and divided by its maximum (io.py:196-197), scene = what PSNR is quoted against.  Rank r (seed r)
+    gets its own measurement; seed 0 is the frame the reference's 100-iteration run is on file for."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import longrun_inputs as li
 
-    psf = torch.from_numpy(orc.synthetic_psf(1, H, W, C, seed=0)).to(device)
-    scene = torch.from_numpy(orc.synthetic_scene(H, W, C, seed=1 + seed)).to(device)
-    conv = lpa.RealFFTConvolve2D(psf, pad=True, norm="backward")
-    y = conv.convolve(scene[None, None])[0, 0].clamp_(min=0)
-    y = y / y.max()
-    del conv
-    return psf, scene, y.contiguous()
+    psf = torch.from_numpy(li.psf12(1, H, W, C, seed=0)).to(device)
+    y = torch.from_numpy(li.measurement(H, W, C, seed=seed)).to(device)
+    return psf, li.scene(H, W, C), y
+
+
+def reference_parity(out, scene, H, W, n_iter, algo):
+    """the engine's output against the samples of the reference's own run at this size and length, if on file"""
+    if (H, W) != (3040, 4056):
+        return None
+    tag, name = ("c2", "admm") if algo == "admm" else ("c3", "fista")
+    path = os.path.join(ROOT, "tests", "golden", f"longrun_{tag}.npz")
+    if not os.path.exists(path):
+        return None
+    import longrun_inputs as li
+
+    fx = np.load(path)
+    if n_iter not in [int(v) for v in fx[f"{name}_iters"]]:
+        return None
+    img = out.detach().cpu().numpy()[0]
+    r64c, r64l, r64s = (fx[f"{name}_f64_it{n_iter}_{k}"] for k in ("crops", "lattice", "stats"))
+    r32c, r32l = (fx[f"{name}_f32_it{n_iter}_{k}"] for k in ("crops", "lattice"))
+    crops, lat = li.samples(img)
+    top = float(r64s[2])
+    d32 = max(np.abs(crops - r64c).max(), np.abs(lat - r64l).max()) / top
+    dref = max(np.abs(r32c - r64c).max(), np.abs(r32l - r64l).max()) / top
+    st = li.stats(img, scene)
+    return {"against": f"tests/golden/longrun_{tag}.npz: the imported reference, torch-CPU, {n_iter} iterations on these inputs "
+                       "(8 crops of 32x32x3 + a stride-61 lattice over the frame)",
+            "engine_f32_vs_reference_f64": float(d32), "reference_f32_vs_reference_f64": float(dref),
+            "psnr_db": {"engine": float(st[4]), "reference_f64": float(r64s[4]),
+                        "reference_f32": float(fx[f"{name}_f32_it{n_iter}_stats"][4])},
+            "psnr_delta_db": float(st[4] - r64s[4])}
 
 
 def rank_stats(dist, dev, elapsed, units_per_rank):
@@ -218,8 +239,10 @@ def run_c4(args, rank, world, dev, dist):
     lo, hi = shard_bounds(B, world, rank)
     elapsed, stats = rank_stats(dist, dev, elapsed, (hi - lo) * n_iter * args.steps)
     assert out.shape == (B, 1, H, W, C)
+    roof, kern = dominant_roofline(sharded.rec._handle, lambda: sharded(frames, n_iter=n_iter), rank == 0)
     if rank == 0:
         emit({
+            "roofline": roof, "kernels": kern,
             "metric": "ADMM frame-iterations/sec, batch of 64 frames 270x480x3, 20 iters (BASELINE config 4)",
             "value": round(B * n_iter * args.steps / elapsed, 1), "unit": "frame-iterations/s", "n_gpus": world,
             "steps": args.steps, "warmup": max(args.warmup, 1), "ms_per_step": round(elapsed / args.steps * 1e3, 3),
@@ -254,8 +277,15 @@ def run_c5_planes(args, rank, world, dev, dist):
     lo, hi = shard_bounds(D * C, world, rank)
     elapsed, stats = rank_stats(dist, dev, elapsed, (hi - lo) * n_iter * args.steps)
     assert out.shape == (D, H, W, C)
+    first = next(iter(sharded._solvers.values()), None)          # (a rank without units has no solver: rank 0 always has)
+    if first is not None:
+        roof, kern = dominant_roofline(first._handle, lambda: sharded(y, n_iter=n_iter), rank == 0)
+    else:
+        sharded(y, n_iter=n_iter)
+        roof = kern = None
     if rank == 0:
         emit({
+            "roofline": roof, "kernels": kern,
             "metric": "ADMM iterations/sec, one 1080x1920x3 frame against 16 depth planes, 50 iters (BASELINE config 5), "
                       "its 48 planes sharded over the GPUs",
             "value": round(n_iter * args.steps / elapsed, 2), "unit": "iterations/s", "n_gpus": world,
@@ -314,6 +344,27 @@ def kernel_table(handle, prof, traffic=None):
                 kernels[name].update(traffic_GB=round(t["hbm_bytes_per_launch"] / 1e9, 3),
                                      traffic_over_alg=round(t["hbm_bytes_per_launch"] / b, 3), pmc_kernel=t["kernel"])
     return kernels
+
+
+def dominant_roofline(handle, call, emit_it):
+    """`roofline` of a sharded config's line: one more step after the timed region (every rank takes part: the step holds
+    the collective) with this rank's launches bracketed; the kernel with the largest share of the step."""
+    handle.profile_enable(True)
+    call()
+    prof = handle.profile_read()
+    handle.profile_enable(False)
+    if not emit_it:
+        return None, None
+    kern = kernel_table(handle, prof, load_traffic(handle.plan_info()))
+    if not kern:        # (the SIMT emulator has no event timer: the line keeps its shape)
+        return {"bound": "hbm", "kernel": None, "achieved": 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": 0.0,
+                "traffic": None, "note": "no launch was timed on this backend"}, kern
+    name = max(kern, key=lambda k: kern[k]["ms"] * kern[k]["launches"])
+    v = kern[name]
+    return {"bound": "hbm", "kernel": name, "achieved": v["GBps"] or 0.0, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": v["frac_of_peak"] or 0.0, "alg_bytes_per_launch": round(v["alg_GB"] * 1e9), "avg_launch_ms": v["ms"],
+            "launches_timed": v["launches"], "traffic": round(v["traffic_GB"] * 1e9) if "traffic_GB" in v else None,
+            "note": "rank 0's shard, one extra step after the timed region with every launch bracketed by HIP events"}, kern
 
 
 def timed_config(name, rec, call, units_per_call, unit, reps, note, groups=3):
@@ -462,7 +513,6 @@ def main():
 
     import lenslesspicam_amd as lpa
     from lenslesspicam_amd import _native
-    from oracle import lensless_oracle as orc
 
     if args.config == "c4":
         return run_c4(args, rank, world, dev, dist)
@@ -513,7 +563,7 @@ def main():
     # HIP events inside the timed region only around the kernel the roofline reports: bracketing all six to eight launches
     # of an iteration costs the timed rate 1.4 % (ADMM) to 3.4 % (FISTA) (tools/probe/event_overhead.py); the other kernels'
     # rows of `kernels` come from one more step after the clock has stopped
-    rec._handle.profile_enable(True, kernels=["spatial"])
+    rec._handle.profile_enable(True, kernels=["spatial", "row_fwd"] if args.algo == "admm" else ["spatial"])
     if dist:
         dist.barrier()
     RT.sync()
@@ -540,7 +590,9 @@ def main():
     wait_gather()
     prof = rec._handle.profile_read()
     rec._handle.profile_enable(False)
-    prof["spatial"] = prof_live["spatial"]          # the roofline kernel: the timed region's own launches
+    for k in ("spatial", "row_fwd"):                  # the roofline kernel(s): the timed region's own launches
+        if prof_live.get(k, (0, 0))[1]:
+            prof[k] = prof_live[k]
 
     # achievable-HBM yardstick measured in the same run: plain device-to-device copy
     copy_gbps = None
@@ -575,8 +627,9 @@ def main():
         if args.algo == "admm" and "spatial" in kernels and "row_fwd" in kernels and kernels["row_fwd"]["ms"]:
             cb = (kernels["spatial"]["alg_GB"] + kernels["row_fwd"]["alg_GB"])
             cm = kernels["spatial"]["ms"] + kernels["row_fwd"]["ms"]
-            combined = {"scope": "SURVEY 8(d)'s whole prox / update kernel = tiled TV / W kernel + forward rows with the X half",
-                        "alg_GB": round(cb, 3), "ms": round(cm, 4), "achieved": round(cb / (cm * 1e-3), 1),
+            combined = {"scope": "SURVEY 8(d)'s whole prox / update kernel = tiled TV / W kernel + forward rows with the X half; "
+                                 "both timed by HIP events inside the timed region",
+                        "bytes": round(cb * 1e9), "ms": round(cm, 4), "achieved": round(cb / (cm * 1e-3), 1),
                         "frac": round(cb / (cm * 1e-3) / HBM_PEAK_GBS, 4)}
         moved_gb = sum(v["alg_GB"] for v in kernels.values())
         result = {
@@ -609,10 +662,10 @@ def main():
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "alg_bytes_per_launch": kbytes, "avg_launch_ms": round(k_ms, 4), "launches_timed": k_n,
                 "traffic": traffic, "traffic_source": traffic_src,
-                "combined": combined,
+                "prox_update_scope": combined,
             },
             "kernels": kernels,
-            "kernels_note": "spatial: HIP events inside the timed region (the roofline kernel); the other rows: one more "
+            "kernels_note": "spatial, row_fwd: HIP events inside the timed region (the roofline scope); the other rows: one more "
                             "step after the timed region with every launch bracketed",
             "alg_GB_per_iteration": round(sum(v["alg_GB"] for v in kernels.values()), 3),
             "survey_model_GB_per_iteration": round(rec._handle.model_bytes() / 1e9, 3),
@@ -632,9 +685,19 @@ def main():
             **rstats,
         }
 
-    # ---- CPU baseline + parity: rank 0, N == 1 only --------------------------------------
+    if rank == 0 and not args.no_parity and args.dtype == "float32":
+        par = reference_parity(out, scene, H, W, n_iter, args.algo)
+        if par:
+            result["parity"] = par
+            log(f"parity vs the reference's samples: {par['engine_f32_vs_reference_f64']:.2e} (the reference's own float32: "
+                f"{par['reference_f32_vs_reference_f64']:.2e}), PSNR delta {par['psnr_delta_db']:+.2e} dB")
+            assert abs(par["psnr_delta_db"]) <= 0.01, par
+
+    # ---- CPU baseline: rank 0, N == 1 only -------------------------------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.algo == "admm" and args.dtype == "float32":
         import psutil
+
+        from oracle import lensless_oracle as orc      # the CPU restatement: the baseline leg only
 
         cores = os.cpu_count() or 1
         avail_gb = psutil.virtual_memory().available / 1e9
@@ -679,127 +742,7 @@ def main():
                       f"{sorted(trial)} on a 1-iteration trial{note}",
         }
         result["speedup_vs_cpu"] = round(result["value"] / cpu_ips, 1) if (bH, bW) == (H, W) else None
-        if not args.no_parity:
-            parity = {}
-            if (bH, bW) == (H, W):
-                sc = scene.cpu().numpy()
-
-                def rel_psnr(got, ref):
-                    got, ref = got.cpu(), ref.cpu()
-                    e = float((got.double() - ref.double()).abs().max() / ref.double().abs().max())
-                    return e, orc.psnr(got[0].float().numpy(), sc) - orc.psnr(ref[0].float().numpy(), sc)
-
-                def long_leg(o, done, kw):
-                    """the float32 oracle keeps stepping (time budget), then the engine runs the same count in ONE call"""
-                    t0 = time.perf_counter()
-                    while done < args.parity_long_iters and time.perf_counter() - t0 < args.parity_budget_s:
-                        o.step()
-                        done += 1
-                    host_s = time.perf_counter() - t0
-                    solver = rec
-                    if kw:
-                        solver = lpa.ADMM(psf, **kw)
-                        solver.set_data(y)
-                    got = solver.apply(n_iter=done, disp_iter=None)
-                    u_nz = float((o.U != 0).float().mean())
-                    ref32 = o.form_image()
-                    e, d = rel_psnr(got, ref32)
-                    # attribution at the SAME iteration count: the float64 build of the engine (window structure off;
-                    # anchored to the float64 oracle at this size by tests/test_parity_fullsize.py) is the truth both
-                    # float32 runs are measured against -- whose rounding is the distance between them?
-                    r64 = lpa.ADMM(psf.double(), dtype="float64", engine_options={"hv_full": 1, "xi_full": 1}, **kw)
-                    r64.set_data(y.double())
-                    t64 = r64.apply(n_iter=done, disp_iter=None)
-                    del r64
-                    e_o, d_o = rel_psnr(ref32, t64)
-                    e_g, d_g = rel_psnr(got, t64)
-                    del t64
-                    torch.cuda.empty_cache()
-                    log(f"parity: {done} iterations {kw or 'default parameters'}: engine vs float32 oracle {e:.2e} "
-                        f"({d:+.2e} dB); float32 oracle vs float64 build {e_o:.2e}; engine vs float64 build {e_g:.2e} "
-                        f"({host_s:.0f} s of oracle)")
-                    # asserted, not just reported (VERDICT r04): the engine stays within 1e-4 of float64 truth after >= 30
-                    # iterations at 12 MP, and it is the ORACLE's float32 rounding that makes up the distance between them
-                    assert e_g <= 1e-4, f"engine float32 vs float64 build after {done} iterations: {e_g:.2e} > 1e-4"
-                    assert e_o >= e_g or e <= 2e-5, f"float32 oracle closer to truth ({e_o:.2e}) than the engine ({e_g:.2e})"
-                    assert abs(d_g) <= 0.01, f"PSNR delta vs float64 build {d_g:+.2e} dB"
-                    return {"iters": done, "params": kw or "defaults", "rel_err_vs_float32_oracle": e, "psnr_delta_db": d,
-                            "oracle_f32_vs_f64_build": {"rel_err": e_o, "psnr_delta_db": d_o},
-                            "engine_f32_vs_f64_build": {"rel_err": e_g, "psnr_delta_db": d_g},
-                            "oracle_U_nonzero_frac": u_nz, "engine_plan_has_window_structure":
-                            "row transforms skipped" in solver._handle.plan_info()}
-
-                # (1) default parameters: the oracle that ran the baseline sample continues to >= 30 iterations
-                log(f"parity: float32 oracle continues to {args.parity_long_iters} iterations (default parameters)")
-                parity["full_size_default_params"] = long_leg(o, cpu_done, {})
-                del o
-                # (2) TV-active parameters (with the defaults tau / mu2 = 10 the soft-threshold never fires: SURVEY
-                # section 7 caveat).  The largest tau of a decade ladder that leaves a sizeable part of U non-zero after 5
-                # iterations, decided on the engine (milliseconds), confirmed on the oracle (oracle_U_nonzero_frac).
-                tv = None
-                for tau in (2e-6, 2e-7, 2e-8, 2e-9, 2e-10, 2e-11, 2e-12):
-                    probe = lpa.ADMM(psf, tau=tau, mu2=1e-4)
-                    probe.set_data(y)
-                    probe._iterate(5)
-                    frac = float((probe._U != 0).float().mean())
-                    del probe
-                    torch.cuda.empty_cache()
-                    if frac > 0.05:
-                        tv = dict(tau=tau, mu2=1e-4)
-                        break
-                if tv:
-                    log(f"parity: float32 oracle, {args.parity_long_iters} iterations with TV-active parameters {tv}")
-                    o = orc.ADMMOracle(psf_c, **tv)
-                    o.set_data(y_c)
-                    parity["full_size_tv_active"] = long_leg(o, 0, tv)
-                    del o
-                # (3) float64 oracle = truth (the float32 CPU backend itself drifts ~4e-5 at this size)
-                log(f"parity: {args.parity_iters} iterations of the float64 oracle at full size")
-                o64 = orc.ADMMOracle(psf_c, dtype=torch.float64)
-                o64.set_data(y_c)
-                t64 = o64.apply(args.parity_iters)
-                del o64
-                e, d = rel_psnr(rec.apply(n_iter=args.parity_iters, disp_iter=None), t64)
-                parity["full_size_rel_err_vs_float64_oracle"] = e
-                parity["full_size_iters_float64"] = args.parity_iters
-                parity["full_size_psnr_delta_db"] = d
-                del t64
-                # (4) the headline call itself: n_iter iterations in one call (all but four on the steady-state path of
-                # the launch plan) vs the float64 build of the engine with the window structure switched off (anchored
-                # to the float64 oracle by tests/test_parity_fullsize.py), default and TV-active parameters
-                for tag, kw in (("defaults", {}), ("tv_active", tv)):
-                    if kw is None:
-                        continue
-                    r32 = rec if not kw else lpa.ADMM(psf, **kw)
-                    r32.set_data(y)
-                    g32 = r32.apply(n_iter=n_iter, disp_iter=None)
-                    r64 = lpa.ADMM(psf.double(), dtype="float64", engine_options={"hv_full": 1, "xi_full": 1}, **kw)
-                    r64.set_data(y.double())
-                    e, d = rel_psnr(g32, r64.apply(n_iter=n_iter, disp_iter=None))
-                    parity[f"full_size_{n_iter}it_vs_float64_build_{tag}"] = {"rel_err": e, "psnr_delta_db": d}
-                    del r64, g32
-                    if kw:
-                        del r32
-                    torch.cuda.empty_cache()
-            else:
-                del o
-            # PSNR delta after the full iteration count on the DiffuserCam-sized frame
-            torch.set_num_threads(min(cores, 16))  # small FFTs: 256 threads only thrash
-            log("parity: 100-iteration oracle run at 270x480x3")
-            h2, w2 = 270, 480
-            psf2 = orc.synthetic_psf(1, h2, w2, C, seed=0)
-            scene2 = orc.synthetic_scene(h2, w2, C, seed=1)
-            y2 = orc.synthetic_measurement(psf2, scene2)
-            r2 = lpa.ADMM(torch.from_numpy(psf2).to(dev))
-            r2.set_data(torch.from_numpy(y2).to(dev))
-            g2 = r2.apply(n_iter=n_iter, disp_iter=None).cpu().numpy()
-            o2 = orc.ADMMOracle(psf2)
-            o2.set_data(y2)
-            c2 = o2.apply(n_iter).numpy()
-            parity["psnr_delta_db_270x480_100it"] = orc.psnr(g2[0], scene2) - orc.psnr(c2[0], scene2)
-            parity["rel_err_270x480_100it"] = float(np.abs(g2 - c2).max() / np.abs(c2).max())
-            result["parity"] = parity
-            log("parity done")
+        del o
 
     if rank == 0 and world == 1 and not args.no_other_configs and args.algo == "admm" and args.dtype == "float32":
         log("other BASELINE configs (C1, C3, C4, C5)")

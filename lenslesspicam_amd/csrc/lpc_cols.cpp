@@ -95,7 +95,7 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
     cp.ga = e->g_sep ? e->Ga : nullptr;
     cp.gb = e->g_sep ? e->Gb : nullptr;
     cp.rev = (e->opt.rev_order & 8) ? 1 : 0;
-    cp.swz = e->opt.mid_swz >= 0 ? e->opt.mid_swz : ((size_t)cp.T * sizeof(real2) < 128 ? 1 : 0);
+    cp.swz = e->opt.mid_swz >= 0 ? e->opt.mid_swz : ((size_t)cp.T * sizeof(real2) < 128 && !g.slay ? 1 : 0);
     const dim3 grid(cp.G * cp.ntile_c, e->P);
     const FastDiv t2 = make_fastdiv((unsigned)(2 * cp.T));
     auto reg_mid = [&](auto kernel) {

@@ -4,6 +4,7 @@
 // launches live in lpc_rows.cpp, lpc_cols.cpp and lpc_gd.cpp (see lpc_engine.h).
 #include "lpc_engine.h"
 #include <mutex>
+#include <unordered_map>
 #include "lpc_gd_kernels.h"
 #include "lpc_metric_kernels.h"
 #include "lpc_prep_kernels.h"
@@ -37,19 +38,22 @@ static int upload(Engine* e, void* dst, const void* src, size_t bytes) {
 
 int big_smem_once(const void* fn, size_t smem) {
   static std::mutex mu;
-  static std::unordered_set<uint64_t> done;
+  static std::unordered_map<uint64_t, size_t> granted;      // (function, device) -> dynamic LDS the kernel may use
   int dev = 0;
   LPC_RT(rt::current_device(&dev));
   const uint64_t key = (uint64_t)(uintptr_t)fn ^ ((uint64_t)(dev + 1) << 56);
   std::lock_guard<std::mutex> lock(mu);
-  if (!done.count(key)) {
+  size_t& have = granted[key];
+  if (have < smem) {            // first launch, or a later one (another handle, a wider tile) that needs more
     // (a kernel with static LDS of its own -- the stamped timing builds, lpc_rt.h: LPC_STAMP -- cannot have the whole
     // 160 KiB as dynamic LDS: ask for what this launch needs then)
-    if (rt::set_max_dyn_smem(fn, smem > 65536 ? 160 * 1024 : 65536) != lpcSuccess) {
+    size_t want = smem > 65536 ? (size_t)160 * 1024 : (size_t)65536;
+    if (rt::set_max_dyn_smem(fn, want) != lpcSuccess) {
       (void)rt::last_error();
-      LPC_RT(rt::set_max_dyn_smem(fn, smem));
+      want = smem;
+      LPC_RT(rt::set_max_dyn_smem(fn, want));
     }
-    done.insert(key);
+    have = want;
   }
   return 0;
 }
@@ -391,7 +395,7 @@ static void choose_plan(Engine* e, bool allow_static) {
     // size (64 frames 33.1 -> 31.0 ms per 20 iterations, 8 frames 4.27 -> 4.00 ms; profiles/r05_notes.md section 5)
     if (nt < 256 && n >= 512) {
       const bool batch = (long)e->P * g.Hp >= 8192;
-      const bool k1r = xhalf && o.k1_rows != 0 && n % 4 == 0 && !o.k1_scalar;
+      const bool k1r = xhalf && o.k1_rows != 0 && n % 4 == 0 && n / 4 <= 256 && !o.k1_scalar;   // (lpc_module.cpp: kK1Rows)
       if (o.prow_nt128 == 0 || (o.prow_nt128 < 0 && (!batch || k1r))) nt = 256;
     }
     if (o.row_nt >= 64 && o.row_nt <= 1024 && o.row_nt % 64 == 0) nt = o.row_nt;
@@ -465,7 +469,7 @@ static void choose_plan(Engine* e, bool allow_static) {
         // both tiles' loads up front when the launch is many waves of workgroups deep (C4, 64 frames: 11 712 workgroups
         // for 1 024 resident, middle 0.494 -> 0.473 ms; an 8-frame shard -- 1 464 workgroups -- is 1.5 % slower with it:
         // profiles/r04h_ab.log)
-        sp.mid_pre = o.mid_pre >= 0 ? (o.mid_pre ? 1 : 0) : ((long)e->P * ((g.Wc + T - 1) / T) >= 16L * plan_cu_count() && !single ? 1 : 0);
+        sp.mid_pre = o.mid_pre >= 0 ? (o.mid_pre ? 1 : 0) : 1;     // (round 6: the 8-frame shard too, 3.86 -> 3.83 ms per 20 iterations)
         const size_t lds = (size_t)n * (T + (sp.mid_twg ? 0 : 1)) * sizeof(real2);
         const int wgs = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
         // (512 lanes: 8 = a 64-VGPR allocation, four workgroups per CU as the LDS allows -- 68 registers without the
@@ -479,6 +483,10 @@ static void choose_plan(Engine* e, bool allow_static) {
     }
   }
   if (seq && sp.mid_kind != LPC_MID_SEQ) e->T = 8;   // (no module kernel for it after all: back to the two-spectra tile)
+  // pair-line work spectra (lpc_kernels.h: spec_col): paired rows + the 8-column sequential middle, float32 (a tile row
+  // of 8 complex128 columns is a whole line already)
+  sp.slay = (admm && f32 && sp.row_kind == LPC_ROWS_PAIRED && sp.mid_kind != LPC_MID_RUNTIME && e->N1 == 1 && sp.mid.T == 8 &&
+             !single && o.spec_lay != 0) ? 1 : 0;
 }
 
 // frame geometry (rfft_convolve.py:110-117) and the launch plan -- no device work (also serves lpc_plan_module)
@@ -494,7 +502,8 @@ static int setup_shape(Engine* e, bool* want_static_out) {
   g.rpitch = (g.Wp + 3) / 4 * 4 + (e->opt.rpitch_pad > 0 ? e->opt.rpitch_pad / 4 * 4 : 0);
   g.cpitch = (g.Wc + 15) / 16 * 16;
   g.rplane = (long)g.Hp * g.rpitch;
-  g.cplane = (long)g.Hp * g.cpitch;
+  g.cplane = (long)((g.Hp + 1) & ~1) * g.cpitch;      // whole row pairs (PlaneGeom::slay)
+  g.slay = 0;
   g.uplane = (long)g.H * g.W;
   g.DC = c.depth * c.channels;
   g.C = c.channels;
@@ -523,6 +532,7 @@ static int setup_geometry(Engine* e) {
     if (!e->mod) choose_plan(e, false);
   }
   if (!e->mod) e->spec = PlanSpec{};
+  e->g.slay = (e->mod && e->mod->slay) ? 1 : 0;
   const bool admm = c.algo == LPC_ALGO_ADMM;
   LPC_OK(build_plan(e, e->planW, g.Wp));
   e->rows_r2 = e->planW.nst >= 2 && e->planW.radix[e->planW.nst - 1] == 2 && !e->opt.no_r2;
@@ -698,6 +708,10 @@ static int admm_alloc(Engine* e) {
   real** bufs[] = {&e->eta0[1], &e->eta1[1], &e->Rsp, &e->Aarr};
   for (real** b : bufs) LPC_OK(dev_alloc(e, b, rp));
   LPC_OK(dev_alloc(e, &e->Gabs, (size_t)g.cplane));
+  if (g.slay) {
+    LPC_OK(dev_alloc(e, &e->Gabs_t, (size_t)g.cplane));
+    LPC_OK(dev_alloc(e, &e->Hs_t, (size_t)g.cplane * e->Ppsf));
+  }
   LPC_OK(dev_alloc(e, &e->Ga, (size_t)g.Hp));
   LPC_OK(dev_alloc(e, &e->Gb, (size_t)g.cpitch));
   LPC_OK(dev_alloc(e, &e->Gpart, (size_t)2 * kGsepBlocks));
@@ -709,6 +723,9 @@ static int admm_alloc(Engine* e) {
 static int admm_split_gram(Engine* e) {
   const PlaneGeom& g = e->g;
   e->g_sep = 0;
+  if (g.slay)       // the 8-column middle reads the plane in pair lines
+    LPC_OK(launch_k(e, -1, k_to_pair_lines<256, real>, grid1d((long)g.Hp * g.cpitch, 256), 256, 0, (const real*)e->Gabs,
+                    e->Gabs_t, g.Hp, g.cpitch, g.cplane));
   // Measured (r03z_ab.log): at 12 MP (100-MB plane, 64-byte tile rows fetched as whole lines once per colour plane) the
   // terms take 0.5 GB off the middle's HBM traffic, 0.622 -> 0.563 ms; on DiffuserCam-sized frames the 1-MB plane lives
   // in the L2 and one load beats two (C1 middle 0.0206 -> 0.0221 ms with the terms)
@@ -801,6 +818,10 @@ static int admm_iterate(Engine* e, int n_iter) {
   const dim3 k1_grid4x(tiles_x4 * ((g.Hp + TH4X - 1) / TH4X), e->P, 1);
   const size_t k1_smem4x = (size_t)2 * (TH4X + 2) * (TW4 + 8) * sizeof(real);
   bool sb_rows_valid = false;   // AdmmScalars::skipa may rely on the rows of SB only after a step of this very call
+  // K1Rows::xcd_order.  (The XCD-aware block orders assume the MI355X's 8 XCDs x 32 CUs and its dispatch rule "workgroup w
+  // on XCD w % 8"; any other part gets launch order: the orders are permutations, results are the same.)
+  const int k1_xcd_order = plan_cu_count() != 256 ? 0
+                           : (long)paired_rows_grid(g, false) * e->P <= 8192 ? -1 : std::max(0, e->opt.k1_group);
   for (int it = 0; it < n_iter; ++it) {
     real* Vc = e->V[e->vcur];
     real* Vo = e->V[e->vcur ^ 1];
@@ -822,7 +843,7 @@ static int admm_iterate(Engine* e, int n_iter) {
     // small frames: the forward rows take the TV / W half as well (Engine::k1_rows) -- same buffers, same ping-pong
     const bool k1r = e->k1_rows && vec4;
     const K1Rows k1 = {Vc, Vo, e->eta0[e->ecur], e->eta1[e->ecur], e->eta0[e->ecur ^ 1], e->eta1[e->ecur ^ 1], e->rho,
-                       (long)paired_rows_grid(g, false) * e->P <= 8192 ? 1 : 0};
+                       k1_xcd_order};
     if (k1r) {
     } else if (sc.half_in)
       LPC_OK(launch_k(e, LPC_K_SPATIAL, k_admm_spatial_v4<TH4X, NT, false, true>, k1_grid4x, NT, k1_smem4x / 2, g, sc, (const real*)Vc,
@@ -979,6 +1000,9 @@ int lpc_set_psf(lpc_handle e, const real* dev_psf, void* stream) {
     LPC_OK(launch_k(e, -1, k_scale_complex<256>, grid1d(n, 256), 256, 0, e->Hs, n, (real)sc));
   }
   e->psf_set = true;
+  if (g.slay)
+    LPC_OK(launch_k(e, -1, k_to_pair_lines<256, real2>, grid1d((long)g.Hp * g.cpitch, 256, e->Ppsf), 256, 0,
+                    (const real2*)e->Hs, e->Hs_t, g.Hp, g.cpitch, g.cplane));
   if (e->cfg.algo == LPC_ALGO_ADMM) LPC_OK(admm_setup_constants(e));
   if (e->cfg.algo >= LPC_ALGO_GD) LPC_OK(gd_setup_constants(e));
   if (e->cfg.algo != LPC_ALGO_CONV) return lpc_reset(e, stream);
@@ -1603,7 +1627,7 @@ int lpc_plan_info(lpc_handle e, char* buf, size_t n) {
   if (e->cfg.algo == LPC_ALGO_ADMM) {
     const bool reg = e->N1 > 1 && e->mid_reg && sizeof(real) == 4 && e->N2 == 24;
     s += reg ? ", middle in registers"
-             : (e->mod && sp.mid_kind ? ", LDS middle [static " + radstr(sp.mid) + (sp.mid_kind == LPC_MID_SEQ ? ", one spectrum at a time]" : "]")
+             : (e->mod && sp.mid_kind ? ", LDS middle [static " + radstr(sp.mid) + (sp.mid_kind == LPC_MID_SEQ ? ", one spectrum at a time" : "") + (g.slay ? ", pair-line spectra]" : "]")
                                       : ", LDS middle");
     s += e->k1_rows ? "; TV / W half and X half inside the forward rows (three launches per iteration)"
          : e->xhalf_rows ? "; tiled TV / W kernel + X half inside the forward rows" : "; stand-alone image-domain kernel";

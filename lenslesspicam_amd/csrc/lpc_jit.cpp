@@ -300,6 +300,22 @@ void unload_surplus(int keep_loaded) {     // g_table_mu held
     victim->dl = nullptr;
   }
 }
+// a shared object cut short (written by a process that died, a full disk): not an ELF header, or its section header
+// table lies beyond the end of the file
+static bool elf_truncated(const std::string& path) {
+  FILE* f = std::fopen(path.c_str(), "rb");
+  if (!f) return false;                       // unreadable here is not "bad"
+  unsigned char h[64];
+  const size_t got = std::fread(h, 1, sizeof(h), f);
+  std::fseek(f, 0, SEEK_END);
+  const long size = std::ftell(f);
+  std::fclose(f);
+  if (got < sizeof(h) || std::memcmp(h, "\177ELF", 4) != 0 || h[4] != 2) return true;     // ELFCLASS64
+  unsigned long long shoff = 0;
+  for (int i = 7; i >= 0; --i) shoff = (shoff << 8) | h[0x28 + i];
+  const unsigned shentsize = h[0x3A] | (h[0x3B] << 8), shnum = h[0x3C] | (h[0x3D] << 8);
+  return shoff == 0 || (long long)(shoff + (unsigned long long)shentsize * shnum) > (long long)size;
+}
 }  // namespace
 
 const LpcModule* get_plan_module(const PlanSpec& spec, const EngineOpts& opt, bool allow_compile, std::string* why) {
@@ -339,9 +355,15 @@ const LpcModule* get_plan_module(const PlanSpec& spec, const EngineOpts& opt, bo
       // fingerprint, ...) must not be found again by every retry: it is removed and -- when this handle may compile --
       // rebuilt once before the failure is recorded
       for (int attempt = 0; attempt < 2 && !path.empty() && !s.mod; ++attempt) {
+        // ... only a file that is PROVABLY bad, though: a truncated ELF image, or one whose lpc_module_init is missing or
+        // refuses this library.  A dlopen() that fails for a reason of this node or moment (a ROCm runtime library that
+        // does not resolve here, no memory) leaves a module directory shared between nodes or ranks untouched.
+        bool bad_file = false;
         void* h = ::dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
-        if (!h) note = std::string("dlopen: ") + ::dlerror();
-        else {
+        if (!h) {
+          note = std::string("dlopen: ") + ::dlerror();
+          bad_file = elf_truncated(path);
+        } else {
           typedef int (*init_fn)(LpcModule*, size_t, const char*);
           init_fn init = (init_fn)::dlsym(h, "lpc_module_init");
           LpcModule* m = new LpcModule();
@@ -353,10 +375,11 @@ const LpcModule* get_plan_module(const PlanSpec& spec, const EngineOpts& opt, bo
             delete m;
             ::dlclose(h);
             note = "module " + path + " was built from other sources";
+            bad_file = true;
           }
         }
         if (!s.mod) {
-          const bool removed = ::access(dir_of(path).c_str(), W_OK) == 0 && ::unlink(path.c_str()) == 0;
+          const bool removed = bad_file && ::access(dir_of(path).c_str(), W_OK) == 0 && ::unlink(path.c_str()) == 0;
           path.clear();
           if (removed && allow_compile && attempt == 0) {
             s.compile_tried = true;

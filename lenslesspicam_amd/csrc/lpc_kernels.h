@@ -29,7 +29,23 @@ struct PlaneGeom {
   int C;           // channels (data plane of state plane q = (q / DC) * C + q % C)
   int rev;         // per launch (the launcher sets it on its copy): the row kernels that honour it hand their workgroups
                    // out from the last (plane, row) to the first (see ColPass::rev)
+  int slay;        // layout of the ADMM work spectra (and of the copies of H / |G| the fused middle reads): 0 rows of cpitch
+                   // elements; 1 PAIR LINES (spec_col below) -- kernels take it as a template argument, the host and
+                   // paired_rows_of read this copy
 };
+// ---- pair-line layout of a half spectrum (paired rows + 8-column middles: DiffuserCam-sized frames) --------------------
+// The single-pass fused middle of a 540-row frame holds 8 image columns per tile: 64-byte row segments, half a cache line
+// per access, and a line whose two halves are written by different workgroups is evicted half-dirty in between (the other
+// half is fetched and the whole line written back: 1.19 x the algorithmic traffic at C4, profiles/r05_notes.md section 3).
+// Here rows (2p, 2p + 1) x columns [8c, 8c + 8) share ONE 128-byte line:
+//     element (r, k)  at  (r >> 1) * 2 cpitch + (k >> 3) * 16 + (r & 1) * 8 + (k & 7)
+// -- a tile row pair is a full line for the middle (16 consecutive lanes), and the paired row kernels, which hold rows
+// 2p and 2p + 1 of one array in one transform, still write / read whole lines (their two stores per bin are the two
+// halves of the same line).  The base of a row pair is r0 * cpitch as before (r0 even: paired_rows_of aligns the
+// window's pairs), SL = 0 is the plain layout.
+template <int SL>
+static __host__ __device__ __forceinline__ int spec_col(int k) { return SL ? k + (k & ~7) : k; }
+
 // block coordinates of a kernel that honours PlaneGeom::rev
 #define LPC_BX(g) ((g).rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x)
 #define LPC_BY(g) ((g).rev ? gridDim.y - 1u - blockIdx.y : blockIdx.y)
@@ -65,23 +81,25 @@ static __device__ __forceinline__ int wrap_add(int i, int d, int n) {  // (i + d
 #define LPC_ROW_SMEM_BYTES(Wp, skew) ((size_t)lds_slots_of((Wp), (int)(skew)) * sizeof(real2))
 
 // s[] holds Z = FFT(a + i b) in natural order; writes A[k], B[k] for k in [0, Wc)
-template <int NT, int SK>
+// (SL = 1: outA = the pair's base, outB = base + 8, see spec_col; validA: row A exists -- the first pair of a window that
+// starts on an odd row holds the row above it, which is not stored)
+template <int NT, int SK, int SL = 0>
 static __device__ __forceinline__ void untangle_store(const real2* s, int Wp, int Wc, real2* outA,
-                                                       real2* outB, bool validB, int tid) {
+                                                       real2* outB, bool validB, int tid, bool validA = true) {
   for (int k = tid; k < Wc; k += NT) {
     real2 zk = s[lds_slot<SK>(k)];
     real2 zn = s[lds_slot<SK>(k == 0 ? 0 : Wp - k)];
-    outA[k] = make_real2((real)0.5 * (zk.x + zn.x), (real)0.5 * (zk.y - zn.y));
-    if (validB) outB[k] = make_real2((real)0.5 * (zk.y + zn.y), -(real)0.5 * (zk.x - zn.x));
+    if (validA) outA[spec_col<SL>(k)] = make_real2((real)0.5 * (zk.x + zn.x), (real)0.5 * (zk.y - zn.y));
+    if (validB) outB[spec_col<SL>(k)] = make_real2((real)0.5 * (zk.y + zn.y), -(real)0.5 * (zk.x - zn.x));
   }
 }
 
 // builds Z[k] = A[k] + i B[k] over the full length from two half spectra (irfft semantics:
 // imaginary parts of the DC and Nyquist bins are ignored).  All loads are issued before the
 // first LDS write (unrolled to the compile-time bound) so they overlap in flight.
-template <int NT, int EMAX, int SK>
+template <int NT, int EMAX, int SK, int SL = 0>
 static __device__ __forceinline__ void tangle_load(real2* s, int Wp, int Wc, const real2* inA,
-                                                    const real2* inB, bool validB, int tid) {
+                                                    const real2* inB, bool validB, int tid, bool validA = true) {
   constexpr int EH = EMAX / 2 + 1;
   real2 a[EH], b[EH];
 #pragma unroll
@@ -90,8 +108,8 @@ static __device__ __forceinline__ void tangle_load(real2* s, int Wp, int Wc, con
     a[q] = make_real2((real)0., (real)0.);
     b[q] = make_real2((real)0., (real)0.);
     if (k < Wc) {
-      a[q] = inA[k];
-      if (validB) b[q] = inB[k];
+      if (validA) a[q] = inA[spec_col<SL>(k)];
+      if (validB) b[q] = inB[spec_col<SL>(k)];
     }
   }
 #pragma unroll
@@ -184,24 +202,34 @@ static __device__ __forceinline__ void tangle_r2_load(real2* s, int Wp, const re
 // (nB = nA) or on the rows of the sensor window alone: pairs (sh + 2j, sh + 2j + 1), j < nB = ceil(H / 2)
 // (AdmmScalars::skipa / skiphv).  grid.x = nA + nB; the first 2 nB blocks alternate between the arrays (block b runs on
 // XCD b % 8, flipped every eighth block so that every XCD gets both kinds), the rest are array 0.
-struct PairedRows { int arr, r0; bool second; };
+// Pair-line spectra (PlaneGeom::slay) need r0 even: the window's pairs then start at sh & ~1, and a pair that straddles the
+// window's edge has one row that is neither formed nor stored (first / second).
+struct PairedRows { int arr, r0; bool first, second; };
 static inline int paired_rows_count(int rows) { return (rows + 1) >> 1; }
+static __host__ __device__ __forceinline__ int paired_rows_window(const PlaneGeom& g) {
+  return g.slay ? ((g.sh + g.H + 1) >> 1) - (g.sh >> 1) : (g.H + 1) >> 1;
+}
 static inline int paired_rows_grid(const PlaneGeom& g, bool window_b) {
-  return paired_rows_count(g.Hp) + paired_rows_count(window_b ? g.H : g.Hp);
+  return paired_rows_count(g.Hp) + (window_b ? paired_rows_window(g) : paired_rows_count(g.Hp));
 }
 static __device__ __forceinline__ PairedRows paired_rows_of(const PlaneGeom& g, unsigned bx, bool window_b) {
-  const int nB = ((window_b ? g.H : g.Hp) + 1) >> 1;
+  const int nB = window_b ? paired_rows_window(g) : (g.Hp + 1) >> 1;
   PairedRows r;
   int idx;
   if ((int)bx < 2 * nB) { r.arr = (int)((bx ^ (bx >> 3)) & 1u); idx = (int)(bx >> 1); }
   else { r.arr = 0; idx = (int)bx - nB; }
-  if (r.arr == 1 && window_b) { r.r0 = g.sh + 2 * idx; r.second = r.r0 + 1 < g.sh + g.H; }
+  r.first = true;
+  if (r.arr == 1 && window_b) {
+    r.r0 = (g.slay ? g.sh & ~1 : g.sh) + 2 * idx;
+    r.first = r.r0 >= g.sh;
+    r.second = r.r0 + 1 < g.sh + g.H;
+  }
   else { r.r0 = 2 * idx; r.second = r.r0 + 1 < g.Hp; }
   return r;
 }
 
 // ---- forward, ADMM: rows (r, r + 1) of array A -> SA, of array B -> SB ------------
-template <int NT, int EMAX, int SK, bool R2, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, bool R2, class PL = Fft1dPlan, int SL = 0>
 __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, PL plan,
                                                      const real* LPC_RESTRICT A,
                                                      const real* LPC_RESTRICT B,
@@ -222,9 +250,10 @@ __global__ __launch_bounds__(NT) void k_rfwd_arrays(PlaneGeom g, PL plan,
     fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, src, LdsNatural{}, NoFix{}, 0,
                                                R2 ? 1 : 0);
   real2* oa = (pr.arr ? SB : SA) + pl * g.cplane + (long)pr.r0 * g.cpitch;
-  real2* ob = oa + g.cpitch;
+  real2* ob = oa + (SL ? 8 : g.cpitch);
+  static_assert(!(R2 && SL), "pair-line spectra: compile-time plans only");
   if (R2) untangle_r2_store<NT, SK>(s, g.Wp, plan.tw, oa, ob, v1, tid);
-  else untangle_store<NT, SK>(s, g.Wp, g.Wc, oa, ob, v1, tid);
+  else untangle_store<NT, SK, SL>(s, g.Wp, g.Wc, oa, ob, v1, tid);
 }
 
 // ---- ADMM rows, one real row per HALF-length complex transform ---------------------------------------
@@ -464,7 +493,7 @@ __global__ __launch_bounds__(NT) void k_rfwd_rows_half(PlaneGeom g, PL plan, con
 // R2: `plan` is the inverse-row plan whose FIRST stage is the radix-2 one (fused into the tangling); SK is
 // false in that case (the skew is not affine for ns = 2).
 // window_only (AdmmScalars::skiphv): B (= H V) is produced on the rows of the sensor window alone (paired_rows_of).
-template <int NT, int EMAX, int SK, bool R2, class PL = Fft1dPlan>
+template <int NT, int EMAX, int SK, bool R2, class PL = Fft1dPlan, int SL = 0>
 __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, PL plan,
                                                      const real2* LPC_RESTRICT SA,
                                                      const real2* LPC_RESTRICT SB,
@@ -475,15 +504,16 @@ __global__ __launch_bounds__(NT) void k_rinv_arrays(PlaneGeom g, PL plan,
   LPC_STAMP_BEGIN(3);
   const long pl = LPC_BY(g);
   const PairedRows pr = paired_rows_of(g, LPC_BX(g), window_only != 0);
-  const bool vb = pr.second;
+  const bool va = pr.first, vb = pr.second;
   const real2* ia = (pr.arr ? SB : SA) + pl * g.cplane + (long)pr.r0 * g.cpitch;
-  const real2* ib = ia + g.cpitch;
+  const real2* ib = ia + (SL ? 8 : g.cpitch);
+  static_assert(!(R2 && SL), "pair-line spectra: compile-time plans only");
   if (R2) tangle_r2_load<NT>(s, g.Wp, ia, ib, vb, tid);
-  else tangle_load<NT, EMAX, SK>(s, g.Wp, g.Wc, ia, ib, vb, tid);
+  else tangle_load<NT, EMAX, SK, SL>(s, g.Wp, g.Wc, ia, ib, vb, tid, va);
   __syncthreads();
   real* a = (pr.arr ? B : A) + pl * g.rplane + (long)pr.r0 * g.rpitch;
   real* b = a + g.rpitch;
-  auto out = [&](int i, int, real2 v) { a[i] = v.x; if (vb) b[i] = v.y; };
+  auto out = [&](int i, int, real2 v) { if (va) a[i] = v.x; if (vb) b[i] = v.y; };
   if constexpr (is_static_plan<PL>::value)
     fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
   else
@@ -923,7 +953,9 @@ __global__ __launch_bounds__(64) void k_cols_mid_admm_reg(PlaneGeom g, Fft1dPlan
 // then inverse pass B; SA <- Vh path, SB <- HVh path.
 // Tile: [N][2T] -- columns 0..T-1 belong to SA, T..2T-1 to SB.
 // PL / SBT2: run-time plan, or a compile-time plan with SBT2 == 2 * cp.T tile columns (both arrays)
-template <int NT, int EMAX, class PL = Fft1dPlan, int SBT2 = 0, bool TWLDS = false>
+// SL = 1 (single-pass columns, T == 8, compile-time plans): the work spectra and the copies of H / |G| passed in are in
+// the pair-line layout (spec_col): the tile's rows (2p, 2p + 1) of either array are one 128-byte line.
+template <int NT, int EMAX, class PL = Fft1dPlan, int SBT2 = 0, bool TWLDS = false, int SL = 0>
 __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColPass cp,
                                                        real2* LPC_RESTRICT SA,
                                                        real2* LPC_RESTRICT SB,
@@ -944,7 +976,8 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   if (cp.swz && bid < (gridDim.x & ~15u)) bid = (bid & ~15u) + ((bid & 7u) << 1) + ((bid >> 3) & 1u);   // ColPass::swz
   const int grp = (int)fd_div(bid, cp.tcdiv);
   const int c0 = ((int)bid - grp * cp.ntile_c) * T;
-  const long rowoff = ((long)grp * cp.gstride) * g.cpitch + c0;
+  static_assert(!SL || (is_static_plan<PL>::value && SBT2 == 16), "pair lines: 8 columns per array, compile-time plans");
+  const long rowoff = ((long)grp * cp.gstride) * g.cpitch + (SL ? 2 * c0 : c0);      // (SL: single pass, grp == 0)
   real2* ba = SA + (long)by * g.cplane + rowoff;
   real2* bb = SB + (long)by * g.cplane + rowoff;
   const int pp = (int)by % g.DC;
@@ -956,6 +989,15 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   constexpr bool O32 = is_static_plan<PL>::value;      // 32-bit byte offsets, see k_cols
   constexpr unsigned c8 = (unsigned)sizeof(real2), c4 = (unsigned)sizeof(real);
   const unsigned r8 = (unsigned)rstep * c8, r4 = (unsigned)rstep * c4;
+  // byte offsets of (row i, column j of the array's 8): see k_cols_mid_admm_seq
+  auto off8 = [=](int i, int j) {
+    const unsigned e8 = ((unsigned)i << 3) | (unsigned)j;
+    return SL ? mul24(e8 >> 4, 2u * r8) + ((e8 & 15u) << 3) : mul24((unsigned)i, r8) + (unsigned)j * c8;
+  };
+  auto off4 = [=](int i, int j) {
+    const unsigned e8 = ((unsigned)i << 3) | (unsigned)j;
+    return SL ? mul24(e8 >> 4, 2u * r4) + ((e8 & 15u) << 2) : mul24((unsigned)i, r4) + (unsigned)j * c4;
+  };
   real2 h[EP];
   real rd[EP];
   // spectral constants: in flight during the forward FFT.  Compile-time plans issue them BEHIND the tile loads (hook of
@@ -972,10 +1014,10 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
       const int e = tid + k * NT, ec = e < npair ? e : 0;
       const int i = (is_static_plan<PL>::value ? ec / T : (int)fd_div((unsigned)ec, cp.tdiv));
       const int j = ec - i * T, jc = j < jmax ? j : jmax;
-      if (O32) h[k] = ld_off(hb, mul24((unsigned)i, r8) + (unsigned)jc * c8);
+      if (O32) h[k] = ld_off(hb, off8(i, jc));
       else h[k] = hb[i * rstep + jc];
       if (TERMS) rd[k] = cp.ga[grp * cp.gstride + i * cp.istride] + cp.gb[c0 + jc];      // rd: |G| for now
-      else if (O32) rd[k] = ld_off(rb, mul24((unsigned)i, r4) + (unsigned)jc * c4);
+      else if (O32) rd[k] = ld_off(rb, off4(i, jc));
       else rd[k] = rb[i * rstep + jc];
     }
   };
@@ -992,7 +1034,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   // LDS (`fix` of fft_tile) -- with the product behind the load the one guarded element of a lane waited for ALL loads.
   auto in = [&](int i, int c) {
     const int j = c < T ? c : c - T, jc = j < jmax ? j : jmax;
-    return O32 ? ld_off(c < T ? ba : bb, mul24((unsigned)i, r8) + (unsigned)jc * c8) : (c < T ? ba : bb)[i * rstep + jc];
+    return O32 ? ld_off(c < T ? ba : bb, off8(i, jc)) : (c < T ? ba : bb)[i * rstep + jc];
   };
   auto in_fix = [&](int i, int c, real2 x) {
     return cscale(x, (c >= T && (unsigned)(i - g.sh) >= (unsigned)g.H) ? sb_k : (real)1.);
@@ -1049,7 +1091,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   auto out = [&](int i, int c, real2 x) {
     const int j = c < T ? c : c - T;
     if (c0 + j < g.Wc) {
-      if (O32) st_off(c < T ? ba : bb, mul24((unsigned)i, r8) + (unsigned)j * c8, x);
+      if (O32) st_off(c < T ? ba : bb, off8(i, j), x);
       else (c < T ? ba : bb)[i * rstep + j] = x;
     }
   };
@@ -1070,12 +1112,14 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
 // tiles that share a cache line on the same XCD 1.5 MB apart (C4: 0.608 -> 0.550 ms per launch, r03_notes.md section 15).
 // H and |G| are shared by all frames of a batch (L2-resident) and are loaded where they are used.  Compile-time plans
 // only (SBT == cp.T).
-template <int NT, int EMAX, class PL, int SBT, int MINW = 1, bool TWLDS = false, bool PRE = false>
+// SL = 1: the work spectra AND the copies of H / |G| passed in are in the pair-line layout (spec_col; T == 8): a tile's
+// rows (2p, 2p + 1) are one 128-byte line.
+template <int NT, int EMAX, class PL, int SBT, int MINW = 1, bool TWLDS = false, bool PRE = false, int SL = 0>
 __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL plan, ColPass cp, real2* LPC_RESTRICT SA,
                                                            real2* LPC_RESTRICT SB, const real2* LPC_RESTRICT Hs,
                                                            const real* LPC_RESTRICT Gabs, const real2* LPC_RESTRICT phr,
                                                            const real2* LPC_RESTRICT phc, real mu1, real mu2, real mu3,
-                                                           real rscale, real sb_outside_scale, int tiles_first) {
+                                                           real rscale, real sb_outside_scale) {
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   // (plain threadIdx.x, not LPC_TID: knowing tid < NT the optimiser keeps all 17 row indices of a lane -- as 64-bit
@@ -1091,183 +1135,103 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   // fastest, the 64 frames of C4 re-read H 64 times: PMC traffic 2.29 GB per launch against 1.60 GB algorithmic.)
   const int nfr = (int)(gridDim.x / (unsigned)(cp.ntile_c * g.DC));       // frames
   const unsigned bx = cp.rev ? gridDim.x - 1u - blockIdx.x : blockIdx.x;   // ColPass::rev
-  int fr = (int)(bx % (unsigned)nfr), rest = (int)(bx / (unsigned)nfr);
-  int tile = rest % cp.ntile_c, pp = rest / cp.ntile_c;                   // column tile, PSF plane
-  if (tiles_first == 3) {
-    // Half-line tiles (T x 8 bytes = 64): the two tiles that share every 128-byte line of a frame run on the same XCD
-    // EIGHT blocks apart instead of `frames` blocks apart -- within 16 consecutive blocks, blocks 0-7 are one tile of
-    // eight frames (one per XCD), blocks 8-15 the neighbouring tile of the same eight frames; then the next eight frames
-    // of that tile pair (H and |G| of the pair stay in the L2s meanwhile).  The second half of a line is then an L2 hit
-    // while the first is still in flight, not a fetch from the memory side after the line has been evicted.  Needs
-    // frames % 8 == 0; an odd last tile is handed out frames-fastest at the end of its plane.
-    const int per_pp = cp.ntile_c * nfr, npair = cp.ntile_c >> 1, paired = npair * nfr * 2;
-    pp = (int)(bx / (unsigned)per_pp);
-    const int r = (int)(bx % (unsigned)per_pp);
-    if (r < paired) {
-      const int q = r >> 4, g8 = nfr >> 3;
-      fr = (q % g8) * 8 + (r & 7);
-      tile = 2 * (q / g8) + ((r >> 3) & 1);
-    } else {
-      fr = (r - paired) % nfr;
-      tile = cp.ntile_c - 1;
-    }
-  } else if (tiles_first) {     // A/B option seq_tiles_first: column tiles fastest, then planes (the order of round 2)
-    tile = (int)(bx % (unsigned)cp.ntile_c);
-    const int q = (int)(bx / (unsigned)cp.ntile_c);
-    fr = q / g.DC; pp = q % g.DC;
-    // tiles_first == 2 (whole long columns, T x 8 bytes < one 128-byte line): the L = 128 / (8 T) tiles that share every
-    // cache line of their rows run on ONE XCD (block b runs on XCD b % 8): within 8 L consecutive blocks, block
-    // 8 y + x takes tile L x + y -- the line is fetched from HBM once into that XCD's L2 and served to its L users
-    if (tiles_first == 2) {
-      constexpr int L = (128 / (int)sizeof(real2)) / T > 1 ? (128 / (int)sizeof(real2)) / T : 1;
-      const int t0 = tile - tile % (8 * L);
-      if (t0 + 8 * L <= cp.ntile_c) { const int l = tile - t0; tile = t0 + (l % 8) * L + l / 8; }
-    }
-  }
+  const int fr = (int)(bx % (unsigned)nfr), rest = (int)(bx / (unsigned)nfr);
+  const int tile = rest % cp.ntile_c, pp = rest / cp.ntile_c;             // column tile, PSF plane
   const long pl = (long)fr * g.DC + pp;
   const int c0 = tile * T;
-  real2* ba = SA + pl * g.cplane + c0;
-  real2* bb = SB + pl * g.cplane + c0;
-  const real2* hb = Hs + (long)pp * g.cplane + c0;
-  const real* rb = Gabs + c0;
+  static_assert(!SL || T == 8, "pair lines hold 8 columns of two rows");
+  const int cb = SL ? 2 * c0 : c0;                  // first element of the tile's column chunk within a row (pair)
+  real2* ba = SA + pl * g.cplane + cb;
+  real2* bb = SB + pl * g.cplane + cb;
+  const real2* hb = Hs + (long)pp * g.cplane + cb;
+  const real* rb = Gabs + cb;
   // 32-bit byte offsets from workgroup-uniform bases (a plane is < 4 GB): one v_mad_u32 per access instead of a
   // 64-bit multiply-add (quarter rate) + 64-bit shift-add
   const unsigned r8 = (unsigned)g.cpitch * (unsigned)sizeof(real2), r4 = (unsigned)g.cpitch * (unsigned)sizeof(real);
   constexpr unsigned c8 = (unsigned)sizeof(real2), c4 = (unsigned)sizeof(real);
+  // byte offset of tile element (row i, column j) of an array of 8- / 4-byte elements.  Pair lines: with e = 8 i + j (the
+  // element's index in the [N][8] tile) the pair is e >> 4 (2 cpitch elements each) and the place in its line e & 15 --
+  // the same two operations as the plain layout's i * pitch + j
+  auto off8 = [=](int i, int j) {
+    const unsigned e8 = ((unsigned)i << 3) | (unsigned)j;
+    return SL ? mul24(e8 >> 4, 2u * r8) + ((e8 & 15u) << 3) : mul24((unsigned)i, r8) + (unsigned)j * c8;
+  };
+  auto off4 = [=](int i, int j) {
+    const unsigned e8 = ((unsigned)i << 3) | (unsigned)j;
+    return SL ? mul24(e8 >> 4, 2u * r4) + ((e8 & 15u) << 2) : mul24((unsigned)i, r4) + (unsigned)j * c4;
+  };
+  // A lane's elements in tile order, e = tid + k NT, keep their column j0 and advance RSTEP rows per round: every tile-order
+  // access is (uniform base + k * rstep elements) + ONE lane-constant byte offset -- no address arithmetic, no address
+  // registers per access (under the 64-VGPR bound of four workgroups per CU a per-access v_mad spilled: 44-88 bytes of
+  // scratch with the pair-line offsets, the 8-frame shard's middle 0.068 -> 0.089 ms)
+  static_assert(NT % T == 0 && (!SL || (NT / T) % 2 == 0), "a lane keeps its column (and its row parity) from round to round");
+  constexpr int RSTEP = NT / T, KFULL = NELEM / NT;   // (KFULL: rounds in which every lane has an element)
+  const int i0 = tid / T, j0 = tid % T;
+  const unsigned l8 = off8(i0, j0), l4 = off4(i0, j0);
+  const long rstep = (long)RSTEP * g.cpitch;
   // sb_outside_scale != 0 (AdmmScalars::skipa): the rows of SB outside the sensor window were not re-transformed; they
   // hold rfft(H V row) / Wp from the last inverse row pass, and a = mu1 H V there
   const real sb_k = sb_outside_scale != (real)0. ? sb_outside_scale : (real)1.;
-  // (the closures copy what they use: captured by reference they end up in scratch and every access through them
-  // becomes a flat_load that also counts against the LDS wait counter)
   const int wc = g.Wc - c0, sh = g.sh, hwin = g.H;
   // Loads are UNCONDITIONAL and carry no arithmetic: the columns of a tile are independent transforms, so a column past
   // the frame's edge may hold whatever the row padding holds (cpitch is a multiple of 16 >= every tile width: the
-  // address is always inside the plane) -- it is never stored.  The scale of SB's rows is applied where the value goes
-  // into LDS.  With `if (j < wc)` around the load and the product behind it, every load that MIGHT lie outside the
-  // sensor window had its own `s_waitcnt vmcnt(0)`: the first and last five of a lane's 17 loads went out one full
-  // HBM latency after the other (round 3's kernel).
+  // address is always inside the plane) -- it is never stored; the tail lanes of the last round load the round's first
+  // element.  The scale of SB's rows is applied where the value goes into LDS.
   static_assert(16 % T == 0, "tile columns must stay inside the padded row pitch");
-  auto inB = [=](int i, int j) { return ld_off(bb, mul24((unsigned)i, r8) + (unsigned)j * c8); };
-  auto fixB = [=](int i, int, real2 x) {
+  auto tile_ld = [=](const real2* base, int k) {
+    return ld_off(base + k * rstep, (k < KFULL || tid + k * NT < NELEM) ? l8 : 0u);
+  };
+  auto fixB = [=](int i, real2 x) {
     return cscale(x, (unsigned)(i - sh) >= (unsigned)hwin ? sb_k : (real)1.);   // one compare, one select, one product
   };
-  auto inA = [=](int i, int j) { return ld_off(ba, mul24((unsigned)i, r8) + (unsigned)j * c8); };
   // the twiddle table moves into LDS behind the tile (lpc_sfft.h twiddles_to_lds)
   if (TWLDS) plan = twiddles_to_lds<NT>(plan, s + NELEM, tid);
   real2 a[EM];
-  if constexpr (PRE) {
-    // Both tiles' loads are issued up front, `a` first, r_sp right behind it: the transform of `a` then runs while the
-    // tile of r_sp is still in flight (the wait for `a` is a vmcnt(EM), not a vmcnt(0)), instead of every workgroup
-    // sitting out two full load latencies.  The registers that later park Ah hold the r_sp tile until then.
+  {
+    // PRE: both tiles' loads are issued up front, `a` first, r_sp right behind it: the transform of `a` then runs while
+    // the tile of r_sp is still in flight (the wait for `a` is a vmcnt(EM), not a vmcnt(0)), instead of every workgroup
+    // sitting out two full load latencies.  The registers that later park Ah hold the r_sp tile until then.  Otherwise
+    // (launches of few workgroups per CU) r_sp's loads go out behind the transform of `a`.
     real2 pb[EM], pa[EM];
 #pragma unroll
-    for (int k = 0; k < EM; ++k) {
-      const int e = tid + k * NT;
-      const int ec = (!(NELEM % NT) || e < NELEM) ? e : 0;        // (the tail lanes of the last round load element 0)
-      pb[k] = inB(ec / T, ec % T);
+    for (int k = 0; k < EM; ++k) pb[k] = tile_ld(bb, k);
+    if constexpr (PRE) {
+#pragma unroll
+      for (int k = 0; k < EM; ++k) pa[k] = tile_ld(ba, k);
     }
 #pragma unroll
-    for (int k = 0; k < EM; ++k) {
-      const int e = tid + k * NT;
-      const int ec = (!(NELEM % NT) || e < NELEM) ? e : 0;
-      pa[k] = inA(ec / T, ec % T);
-    }
-#pragma unroll
-    for (int k = 0; k < EM; ++k) {
-      const int e = tid + k * NT;
-      if (!(NELEM % NT) || e < NELEM) s[e] = fixB(e / T, e % T, pb[k]);
-    }
+    for (int k = 0; k < EM; ++k)
+      if (k < KFULL || tid + k * NT < NELEM) s[tid + k * NT] = fixB(i0 + k * RSTEP, pb[k]);
     __syncthreads();
-    // 1. Ah = FFT(a)
+    // 1. Ah = FFT(a), parked in registers in tile order
     fft_tile<NT, EMAX, false, false, false, false, false, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, LdsNatural{});
 #pragma unroll
     for (int k = 0; k < EM; ++k) {
-      const int e = tid + k * NT;
       a[k] = make_real2((real)0., (real)0.);
-      if (e < NELEM) a[k] = s[e];
+      if (k < KFULL || tid + k * NT < NELEM) a[k] = s[tid + k * NT];
+    }
+    if constexpr (!PRE) {
+#pragma unroll
+      for (int k = 0; k < EM; ++k) pa[k] = tile_ld(ba, k);
     }
     __syncthreads();
     // 2. Rh = FFT(r_sp) in the same tile
 #pragma unroll
-    for (int k = 0; k < EM; ++k) {
-      const int e = tid + k * NT;
-      if (!(NELEM % NT) || e < NELEM) s[e] = pa[k];
-    }
+    for (int k = 0; k < EM; ++k)
+      if (k < KFULL || tid + k * NT < NELEM) s[tid + k * NT] = pa[k];
     __syncthreads();
     fft_tile<NT, EMAX, false, false, false, false, false, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, LdsNatural{});
-  } else {
-  // 1. Ah = FFT(a), parked in registers in tile order e = tid + k NT
-  fft_tile<NT, EMAX, false, false, false, LPC_SEQ_FUSE1, false, SBT>(s, plan, T, cp.tdiv, tid, inB, LdsNatural{}, fixB);
-#pragma unroll
-  for (int k = 0; k < EM; ++k) {
-    const int e = tid + k * NT;
-    a[k] = make_real2((real)0., (real)0.);
-    if (e < NELEM) a[k] = s[e];
-  }
-  __syncthreads();
-  // 2. Rh = FFT(r_sp) in the same tile
-  fft_tile<NT, EMAX, false, false, false, LPC_SEQ_FUSE1, false, SBT>(s, plan, T, cp.tdiv, tid, inA, LdsNatural{});
   }
   // 3. Vh = Rdiv (Rh + s conj(H) Ah) -> tile;  HVh = s H Vh -> the registers that held Ah
-#if LPC_SEQ_STEP3_BATCH > 0
-  // Timing experiment (tools/knock_modules.py -DLPC_SEQ_STEP3_BATCH=n; profiles/r05_notes.md section 5): ONE lane-constant
-  // branch around the step (a lane's column is tid % T in every round) and, inside it, the loads of n elements requested
-  // before the first product -- the default form below waits for each element's H, |G| and phase factor separately.
-  static_assert(NT % T == 0, "a lane keeps its column");
-  const int j0 = tid % T;
-  if (j0 < wc) {
-    constexpr int SB3 = LPC_SEQ_STEP3_BATCH, KFULL = NELEM / NT;
-    const real2 pc = ld_off(phc, (unsigned)(c0 + j0) * c8);
-    auto step3 = [&](auto terms_c) {
-      constexpr bool TERMS = decltype(terms_c)::value;
-      real gbv = (real)0.;
-      if constexpr (TERMS) gbv = ld_off(cp.gb, (unsigned)(c0 + j0) * c4);
-#pragma unroll
-      for (int k0 = 0; k0 < EM; k0 += SB3) {
-        real2 hh[SB3], pr[SB3];
-        real gk[SB3];
-#pragma unroll
-        for (int q = 0; q < SB3; ++q) {
-          const int k = k0 + q < EM ? k0 + q : EM - 1;
-          const int e = tid + k * NT, ec = (k < KFULL || e < NELEM) ? e : 0;
-          const int i = ec / T;
-          hh[q] = ld_off(hb, mul24((unsigned)i, r8) + (unsigned)j0 * c8);
-          if constexpr (TERMS) gk[q] = ld_off(cp.ga, (unsigned)i * c4) + gbv;
-          else gk[q] = ld_off(rb, mul24((unsigned)i, r4) + (unsigned)j0 * c4);
-          pr[q] = ld_off(phr, (unsigned)i * c8);
-        }
-#pragma unroll
-        for (int q = 0; q < SB3; ++q) {
-          const int k = k0 + q;
-          if (k < EM) {
-            const int e = tid + k * NT, ec = (k < KFULL || e < NELEM) ? e : 0;
-            const real rdiv = rscale * recip_pos(mu1 * rabs(hh[q].x * hh[q].x + hh[q].y * hh[q].y) + mu2 * gk[q] + mu3);
-            const real2 ph = cmul(pr[q], pc);
-            const real2 t = cmul(cmul_conj(a[k], hh[q]), ph);
-            const real2 vh = cscale(cadd(s[ec], t), rdiv);
-            a[k] = cmul(cmul(vh, hh[q]), ph);
-            if (k < KFULL || e < NELEM) s[e] = vh;
-          }
-        }
-#if LPC_SEQ_STEP3_FENCE
-        LPC_SCHED_FENCE();
-#endif
-      }
-    };
-    if (cp.ga) step3(std::true_type{});
-    else step3(std::false_type{});
-  }
-#else
 #pragma unroll
   for (int k = 0; k < EM; ++k) {
-    const int e = tid + k * NT;
-    if (e < NELEM) {
-      const int i = e / T, j = e % T;
-      if (c0 + j < g.Wc) {
-        const real2 hh = ld_off(hb, mul24((unsigned)i, r8) + (unsigned)j * c8);
-        const real gk = cp.ga ? cp.ga[i] + cp.gb[c0 + j] : ld_off(rb, mul24((unsigned)i, r4) + (unsigned)j * c4);
+    if (k < KFULL || tid + k * NT < NELEM) {
+      if (j0 < wc) {
+        const int e = tid + k * NT, i = i0 + k * RSTEP;
+        const real2 hh = ld_off(hb + k * rstep, l8);
+        const real gk = cp.ga ? cp.ga[i] + cp.gb[c0 + j0] : ld_off(rb + k * rstep, l4);
         const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * gk + mu3);
-        const real2 ph = cmul(phr[i], phc[c0 + j]);
+        const real2 ph = cmul(phr[i], phc[c0 + j0]);
         const real2 t = cmul(cmul_conj(a[k], hh), ph);
         const real2 vh = cscale(cadd(s[e], t), rdiv);
         s[e] = vh;
@@ -1275,10 +1239,9 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
       }
     }
   }
-#endif
   __syncthreads();
   // 4. V-hat back through the inverse transform, straight to SA
-  auto outA = [=](int i, int j, real2 x) { if (j < wc) st_off(ba, mul24((unsigned)i, r8) + (unsigned)j * c8, x); };
+  auto outA = [=](int i, int j, real2 x) { if (j < wc) st_off(ba, off8(i, j), x); };
   fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, outA);
   __syncthreads();
   // 5. H V-hat: registers -> tile -> inverse transform -> SB
@@ -1288,7 +1251,7 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
     if (e < NELEM) s[e] = a[k];
   }
   __syncthreads();
-  auto outB = [=](int i, int j, real2 x) { if (j < wc) st_off(bb, mul24((unsigned)i, r8) + (unsigned)j * c8, x); };
+  auto outB = [=](int i, int j, real2 x) { if (j < wc) st_off(bb, off8(i, j), x); };
   fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, outB);
   LPC_STAMP_END();
 }
@@ -1923,9 +1886,10 @@ static __device__ __forceinline__ void k1_two_rows(const PlaneGeom& g, const Adm
 struct K1Rows {
   const real *V, *Vold, *eta0, *eta1;
   real *eta0_out, *eta1_out, *rho;
-  int xcd_order;      // hand the row blocks out XCD by XCD (small launches, see the kernel)
+  int xcd_order;      // hand the row blocks out XCD by XCD: -1 an eighth of the launch each (small launches), G > 0 runs of G
+                      // blocks (see the kernel), 0 launch order
 };
-template <int NT, int EMAX, int SK, class PL, bool K1 = false>
+template <int NT, int EMAX, int SK, class PL, bool K1 = false, int SL = 0>
 __global__ __launch_bounds__(NT, K1 ? LPC_K1ROWS_MINW : NT == 256 ? LPC_RFWDX_MINW : 1) void k_rfwd_arrays_x(PlaneGeom g, AdmmScalars p, PL plan, const real* LPC_RESTRICT Rsp,
                                                        const real* LPC_RESTRICT HV, const real* LPC_RESTRICT HVold,
                                                        real* LPC_RESTRICT xi, const real* LPC_RESTRICT Y,
@@ -1942,8 +1906,20 @@ __global__ __launch_bounds__(NT, K1 ? LPC_K1ROWS_MINW : NT == 256 ? LPC_RFWDX_MI
     // launches only (same box, trees: C1 0.217 -> 0.212 ms, 380 x 507 0.281 -> 0.269 ms per 5 iterations; 8 frames
     // unchanged; C4's 64 frames 0.815 -> 0.855 ms per launch -- profiles/r05zb_xcd_order_trees.log)
     const unsigned gx = gridDim.x, total = gx * gridDim.y, lin = bx + gx * by;
-    const unsigned qd = total >> 3, rm = total & 7u, xcd = lin & 7u, idx = lin >> 3;
-    const unsigned l2 = (xcd < rm ? xcd * (qd + 1u) : rm * (qd + 1u) + (xcd - rm) * qd) + idx;
+    unsigned l2 = lin;
+    if (k1.xcd_order < 0) {
+      const unsigned qd = total >> 3, rm = total & 7u, xcd = lin & 7u, idx = lin >> 3;
+      l2 = (xcd < rm ? xcd * (qd + 1u) : rm * (qd + 1u) + (xcd - rm) * qd) + idx;
+    } else {
+      // large launches: runs of G consecutive row blocks per XCD inside spans of 8 G blocks -- the eight XCDs stay within
+      // 8 G rows of one another (one stream through every array, not eight), and only one block in G has its
+      // neighbours' rows on another XCD
+      const unsigned G = (unsigned)k1.xcd_order, span = 8u * G, full = total - total % span;
+      if (lin < full) {
+        const unsigned c = lin / span, w = lin - c * span;
+        l2 = c * span + (w & 7u) * G + (w >> 3);
+      }
+    }
     by = l2 / gx;
     bx = l2 - by * gx;
   }
@@ -1962,7 +1938,7 @@ __global__ __launch_bounds__(NT, K1 ? LPC_K1ROWS_MINW : NT == 256 ? LPC_RFWDX_MI
       __syncthreads();
       fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
       real2* o0 = SA + pl * g.cplane + (long)pr.r0 * g.cpitch;
-      untangle_store<NT, SK>(s, g.Wp, g.Wc, o0, o0 + g.cpitch, v1, tid);
+      untangle_store<NT, SK, SL>(s, g.Wp, g.Wc, o0, o0 + (SL ? 8 : g.cpitch), v1, tid);
       LPC_STAMP_END();
     }
     return;
@@ -1973,7 +1949,7 @@ __global__ __launch_bounds__(NT, K1 ? LPC_K1ROWS_MINW : NT == 256 ? LPC_RFWDX_MI
     auto two = [&](int i, int) { return make_real2(ra[i], v1 ? rb[i] : (real)0.); };
     fft_tile<NT, EMAX, false, SK, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, two, LdsNatural{});
     real2* o0 = SA + pl * g.cplane + (long)pr.r0 * g.cpitch;
-    untangle_store<NT, SK>(s, g.Wp, g.Wc, o0, o0 + g.cpitch, v1, tid);
+    untangle_store<NT, SK, SL>(s, g.Wp, g.Wc, o0, o0 + (SL ? 8 : g.cpitch), v1, tid);
     LPC_STAMP_END();
     return;
   }
@@ -1984,6 +1960,8 @@ __global__ __launch_bounds__(NT, K1 ? LPC_K1ROWS_MINW : NT == 256 ? LPC_RFWDX_MI
   // was the whole kernel: C1 0.272 -> 0.293 ms per 5 iterations, r04a/ab_pairing.log.)
   const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
   const int r1 = pr.r0 + 1, n4 = g.Wp >> 2;
+  const bool v0 = pr.first;     // (false: the row above a window that starts on an odd row -- read like any row outside
+                                // the window, neither stored nor transformed)
   const bool in0 = (pr.r0 >= g.sh) && (pr.r0 < g.sh + g.H), in1 = v1 && (r1 >= g.sh) && (r1 < g.sh + g.H);
   const real* y0 = Y + (long)dpl * g.uplane + (long)(pr.r0 - g.sh) * g.W;    // dereferenced only inside the window
   const real* y1 = y0 + g.W;
@@ -2001,10 +1979,10 @@ __global__ __launch_bounds__(NT, K1 ? LPC_K1ROWS_MINW : NT == 256 ? LPC_RFWDX_MI
       real x0[4], a0[4], x1[4], a1[4];
       xhalf_apply(p, c0, x0, a0);
       xhalf_apply(p, c1, x1, a1);
-      if (!c0.skip || p.xi_store) st4(xi + o_row + gc, make_real4(x0[0], x0[1], x0[2], x0[3]));
+      if (v0 && (!c0.skip || p.xi_store)) st4(xi + o_row + gc, make_real4(x0[0], x0[1], x0[2], x0[3]));
       if (v1 && (!c1.skip || p.xi_store)) st4(xi + o_row1 + gc, make_real4(x1[0], x1[1], x1[2], x1[3]));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s[lds_slot<SK>(gc + i)] = make_real2(a0[i], v1 ? a1[i] : (real)0.);
+      for (int i = 0; i < 4; ++i) s[lds_slot<SK>(gc + i)] = make_real2(v0 ? a0[i] : (real)0., v1 ? a1[i] : (real)0.);
     }
   } else {
     const int q0 = tid < n4 ? tid : 0;
@@ -2021,16 +1999,16 @@ __global__ __launch_bounds__(NT, K1 ? LPC_K1ROWS_MINW : NT == 256 ? LPC_RFWDX_MI
       real x0[4], a0[4], x1[4], a1[4];
       xhalf_apply(p, c0, x0, a0);
       xhalf_apply(p, c1, x1, a1);
-      if (!c0.skip || p.xi_store) st4(xi + o_row + gc, make_real4(x0[0], x0[1], x0[2], x0[3]));
+      if (v0 && (!c0.skip || p.xi_store)) st4(xi + o_row + gc, make_real4(x0[0], x0[1], x0[2], x0[3]));
       if (v1 && (!c1.skip || p.xi_store)) st4(xi + o_row1 + gc, make_real4(x1[0], x1[1], x1[2], x1[3]));
 #pragma unroll
-      for (int i = 0; i < 4; ++i) s[lds_slot<SK>(gc + i)] = make_real2(a0[i], v1 ? a1[i] : (real)0.);
+      for (int i = 0; i < 4; ++i) s[lds_slot<SK>(gc + i)] = make_real2(v0 ? a0[i] : (real)0., v1 ? a1[i] : (real)0.);
     }
   }
   __syncthreads();
   fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
   real2* o1 = SB + pl * g.cplane + (long)pr.r0 * g.cpitch;
-  untangle_store<NT, SK>(s, g.Wp, g.Wc, o1, o1 + g.cpitch, v1, tid);
+  untangle_store<NT, SK, SL>(s, g.Wp, g.Wc, o1, o1 + (SL ? 8 : g.cpitch), v1, tid, v0);
   LPC_STAMP_END();
 }
 
@@ -2216,6 +2194,18 @@ __global__ __launch_bounds__(NT) void k_permute_spectrum_rows(const real* LPC_RE
     const int prow = (int)(e / Wc), c = (int)(e - (long)prow * Wc);
     const int k = (prow / N2) + N1 * (prow % N2);
     out[(long)prow * cpitch + c] = nat[(long)k * Wc + c];
+  }
+}
+
+// spectrum planes [Hp][cpitch] -> the pair-line layout (spec_col): the copies of H and |G| an 8-column fused middle reads
+template <int NT, class Tp>
+__global__ __launch_bounds__(NT) void k_to_pair_lines(const Tp* LPC_RESTRICT src, Tp* LPC_RESTRICT dst, int Hp, int cpitch,
+                                                       long cplane) {
+  const long n = (long)Hp * cpitch;
+  const long pl = blockIdx.y;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const int i = (int)(e / cpitch), j = (int)(e - (long)i * cpitch);
+    dst[pl * cplane + (long)(i >> 1) * 2 * cpitch + spec_col<1>(j) + (i & 1) * 8] = src[pl * cplane + e];
   }
 }
 

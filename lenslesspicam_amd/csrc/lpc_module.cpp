@@ -14,6 +14,9 @@
 #ifndef LPC_MOD_MID_PRE
 #define LPC_MOD_MID_PRE 0
 #endif
+#ifndef LPC_MOD_SLAY
+#define LPC_MOD_SLAY 0
+#endif
 #ifndef LPC_MOD_FAMILY
 #error "lpc_module.cpp is compiled with the flags of plan_spec_defines() (lpc_plan.h)"
 #endif
@@ -163,7 +166,7 @@ static int m_admm_rows_fwd(Engine* e) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
-  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<RNT, REM, RSK, false, RowPA>, dim3(paired_rows_grid(g, false), e->P), RNT, kRowSmem, g,
+  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays<RNT, REM, RSK, false, RowPA, LPC_MOD_SLAY>, dim3(paired_rows_grid(g, false), e->P), RNT, kRowSmem, g,
                   row_arg(e), (const real*)e->Rsp, (const real*)e->Aarr, SA, SB);
 }
 static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outside) {
@@ -171,7 +174,7 @@ static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outsi
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const int irows = paired_rows_grid(g, skip_hv_outside != 0);
-  return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<RNT, REM, RSK, false, RowPA>, dim3(irows, e->P), RNT, kRowSmem,
+  return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<RNT, REM, RSK, false, RowPA, LPC_MOD_SLAY>, dim3(irows, e->P), RNT, kRowSmem,
                   geom_rev(e, e->opt.rev_rows & 2),
                   row_arg(e), (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
 }
@@ -185,13 +188,13 @@ static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc, const K1Rows* k1)
   const int xrows = paired_rows_grid(g, sc->skipa != 0);
   if (k1) {
     if constexpr (kK1Rows)
-      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA, true>, dim3(xrows, e->P), RNT, kRowSmem,
+      return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA, true, LPC_MOD_SLAY>, dim3(xrows, e->P), RNT, kRowSmem,
                       geom_rev(e, e->opt.rev_rows & 1), *sc,
                       row_arg(e), (const real*)e->Rsp, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1],
                       e->xi, (const real*)e->Y, SA, SB, *k1);
     return fail("internal: this module's rows do not hold the TV / W half");
   }
-  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA>, dim3(xrows, e->P), RNT, kRowSmem,
+  return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA, false, LPC_MOD_SLAY>, dim3(xrows, e->P), RNT, kRowSmem,
                   geom_rev(e, e->opt.rev_rows & 1), *sc,
                   row_arg(e), (const real*)e->Rsp, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1],
                   e->xi, (const real*)e->Y, SA, SB, K1Rows{});
@@ -227,20 +230,15 @@ static int m_admm_mid(Engine* e, const ColPass* cp, const AdmmScalars* sc, real 
   const real rscale = (real)1.0 / ((real)g.Hp * (real)g.Wp);
 #if LPC_MOD_MID_KIND == LPC_MID_SEQ     // single-pass columns, one spectrum at a time through T columns
   constexpr bool TWL = LPC_MOD_MID_TWG == 0;     // the plan's twiddles in LDS behind the tile
-  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, TWL, LPC_MOD_MID_PRE != 0>,
+  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, TWL, LPC_MOD_MID_PRE != 0, LPC_MOD_SLAY>,
                   dim3(cp->ntile_c * e->P), NT, (size_t)MidP::n * (T + (TWL ? 1 : 0)) * sizeof(real2), g, pa, *cp, SA, SB,
-                  (const real2*)e->Hs, (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, sc->mu1,
-                  sc->mu2, sc->mu3, rscale, sb_outside_scale,
-                  // whole long columns two at a time (option col_single): the tiles that share a cache line on one XCD
-                  (e->opt.seq_tiles_first == 0 && (size_t)MidP::n * 16 > (size_t)kMaxTilePoints) ? 2
-                  // half-line tiles of a batch: the two halves of a line eight blocks apart on one XCD (option seq_pair)
-                  : (e->opt.seq_tiles_first == 0 && e->opt.seq_pair != 0 && T * sizeof(real2) == 64 && (e->P / g.DC) % 8 == 0) ? 3
-                  : e->opt.seq_tiles_first);
+                  (const real2*)(LPC_MOD_SLAY ? e->Hs_t : e->Hs), (const real*)(LPC_MOD_SLAY ? e->Gabs_t : e->Gabs), (const real2*)e->phr, (const real2*)e->phc, sc->mu1,
+                  sc->mu2, sc->mu3, rscale, sb_outside_scale);
 #else                                   // both spectra side by side: [N][2 T]
   const FastDiv t2 = make_fastdiv((unsigned)(2 * T));
-  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<NT, EM, MidPA, 2 * T, true>, dim3(cp->G * cp->ntile_c, e->P), NT,
-                  (size_t)MidP::n * (2 * T + 1) * sizeof(real2), g, pa, *cp, SA, SB, (const real2*)e->Hs,
-                  (const real*)e->Gabs, (const real2*)e->phr, (const real2*)e->phc, t2, sc->mu1, sc->mu2, sc->mu3,
+  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm<NT, EM, MidPA, 2 * T, true, LPC_MOD_SLAY>, dim3(cp->G * cp->ntile_c, e->P), NT,
+                  (size_t)MidP::n * (2 * T + 1) * sizeof(real2), g, pa, *cp, SA, SB, (const real2*)(LPC_MOD_SLAY ? e->Hs_t : e->Hs),
+                  (const real*)(LPC_MOD_SLAY ? e->Gabs_t : e->Gabs), (const real2*)e->phr, (const real2*)e->phc, t2, sc->mu1, sc->mu2, sc->mu3,
                   rscale, sb_outside_scale);
 #endif
 }
@@ -286,5 +284,6 @@ extern "C" int lpc_module_init(LpcModule* m, size_t engine_size, const char* src
 #if LPC_MOD_MID_KIND != 0
   m->admm_mid = m_admm_mid;
 #endif
+  m->slay = LPC_MOD_SLAY;
   return 0;
 }

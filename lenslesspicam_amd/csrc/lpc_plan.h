@@ -51,6 +51,7 @@ struct PlanSpec {
   int mid_minw = 1;           // __launch_bounds__ second argument of the sequential middle
   int mid_twg = 0;            // sequential middle: twiddles read from global memory instead of a copy in LDS behind the tile
   int mid_pre = 0;            // sequential middle: both tiles' loads issued before the first transform
+  int slay = 0;               // ADMM work spectra in pair lines (lpc_kernels.h: spec_col): paired rows + 8-column sequential middle
   bool any() const { return row_kind != LPC_ROWS_RUNTIME || passA.n || mid_kind != LPC_MID_RUNTIME; }
 };
 
@@ -65,7 +66,7 @@ static inline std::string plan_spec_key(const PlanSpec& s) {
   k += s.family == LPC_FAM_ADMM ? "_admm" : "_gd";
   if (s.row_kind) k += std::string(s.row_kind == LPC_ROWS_HALF ? "_rh" : "_rp") + fft_key(s.row) + (s.row_sk == 1 ? "s" : (s.row_sk == 2 ? "z" : (s.row_sk == 3 ? "h" : ""))) + (s.row_x ? "x" : "");
   if (s.passA.n) k += "_a" + fft_key(s.passA);
-  if (s.mid_kind) k += std::string(s.mid_kind == LPC_MID_PAIR ? "_mp" : "_ms") + fft_key(s.mid) + "m" + std::to_string(s.mid_minw) + (s.mid_twg ? "g" : "") + (s.mid_pre ? "p" : "");
+  if (s.mid_kind) k += std::string(s.mid_kind == LPC_MID_PAIR ? "_mp" : "_ms") + fft_key(s.mid) + "m" + std::to_string(s.mid_minw) + (s.mid_twg ? "g" : "") + (s.mid_pre ? "p" : "") + (s.slay ? "L" : "");
   return k;
 }
 static inline std::string rad_list(const StaticFft& f) {
@@ -99,6 +100,7 @@ static inline std::vector<std::string> plan_spec_defines(const PlanSpec& s) {
     defi("LPC_MOD_MID_TWG", s.mid_twg);
     defi("LPC_MOD_MID_PRE", s.mid_pre);
   }
+  defi("LPC_MOD_SLAY", s.slay);
   return d;
 }
 
@@ -137,10 +139,12 @@ struct EngineOpts {
   int seq_pair = 0;           // sequential middle, 64-byte tile rows: the two tiles of a cache line 8 blocks apart on one XCD (measured: no gain)
   int mid_swz = -1;           // side-by-side LDS middle: pairs of column tiles on one XCD (ColPass::swz); -1: when a tile
                               // row is narrower than a 128-byte line
+  int spec_lay = -1;          // ADMM work spectra of paired rows + 8-column sequential middle in pair lines (PlanSpec::slay); 0: rows
   int hv_full = 0;            // every row of H V transformed in every iteration
   int xi_full = 0;            // xi kept on the whole padded frame
   int no_xhalf = 0;           // stand-alone image-domain kernel (no X half inside the forward rows)
   int k1_rows = 1;            // TV / W half inside the paired forward rows where a row is one quad per lane (three launches per iteration)
+  int k1_group = 16;          // ... on launches of more than 8192 row blocks: runs of this many consecutive blocks per XCD (K1Rows::xcd_order)
   int k1_half = 1;            // duals half-applied between the iterations of one call: the tiled kernel does not read V_old
                               // (9R -> 8R); 0: plain duals in every iteration (round 3)
   int k1_scalar = 0;          // ... in its scalar-lane form
@@ -220,11 +224,13 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "mid_minw") o.mid_minw = (int)iv;
       else if (k == "g_plane") o.g_plane = (int)iv;
       else if (k == "mid_swz") o.mid_swz = (int)iv;
+      else if (k == "spec_lay") o.spec_lay = (int)iv;
       else if (k == "hv_full") o.hv_full = (int)iv;
       else if (k == "xi_full") o.xi_full = (int)iv;
       else if (k == "no_xhalf") o.no_xhalf = (int)iv;
       else if (k == "k1_half") o.k1_half = (int)iv;
       else if (k == "k1_rows") o.k1_rows = (int)iv;
+      else if (k == "k1_group") o.k1_group = (int)iv;
       else if (k == "k1_scalar") o.k1_scalar = (int)iv;
       else if (k == "no_r2") o.no_r2 = (int)iv;
       else if (k == "no_skew") o.no_skew = (int)iv;

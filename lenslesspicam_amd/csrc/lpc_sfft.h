@@ -390,6 +390,9 @@ static __device__ __forceinline__ void fft_tile(real2* s, const SPlanArg<P, LANE
   constexpr bool fusel = FUSEL && !dst_lds && (P::nst - (fuse1 ? 1 : 0)) >= 1;
   const real2* tw = pa.tw;
   if constexpr (fuse1) {
+    // (a hook that writes LDS -- the twiddle copy of the fused middles -- would race with the stages below: there is no
+    // barrier between it and their first read)
+    static_assert(std::is_same<Hook, NoHook>::value, "FUSE1 and a hook do not combine");
     sfft_first_fused<P, NT, BT, INV, SKEW, SRC_LDS>(s, tid, src, fix);
     hook();
   } else if constexpr (!src_lds) {
