@@ -74,54 +74,49 @@ typedef struct lpc_config {
  * defaults that a handle's own string overrides).  None changes a result beyond float round-off; none is needed in
  * production -- they exist so that tests and A/B measurements can select a launch plan without touching the process
  * environment.  lpc_plan_info() reports the plan a handle ended up with.
- *   no_static=1        run-time FFT plans only (no plan module);  no_static_cols=1: ... for the column passes only
+ * Which kernels a handle gets
+ *   no_static=1        run-time FFT plans only (no plan module is looked for)
  *   jit=0              never compile a plan module: use what is on disk (default 1: a frame shape whose module is
  *                      missing is compiled with hipcc on first use, ~3 s, and kept in <libdir>/modules or ~/.cache)
  *   jit_min_points=N   padded frames with fewer than N points keep the run-time plans (default 65536)
  *   module_dir=PATH    first place modules are looked for / written;  compiler=PATH  the hipcc to use
+ *   module_max=N module_loaded_max=N    plan-module files kept per directory this library writes to (256, least
+ *                      recently used removed first); modules kept loaded once no handle uses them (64)
+ * Forcing a plan the chooser takes at other sizes (how the tests run every kernel family on small frames)
  *   rows_half=0|1      paired rows / one real row per half-length transform (default: by width)
  *   col_t=N tile_budget=N split_n2=N passa_t=N     column tiling: image columns per tile, LDS points per tile, forced
  *                      length of the fused middle transform, columns per pass-A tile
- *   mid_seq=0|1 mid_lds=1 prow_nt128=0|1            ADMM single-pass middle one spectrum at a time / side by side; no
- *                      register-resident middles; short paired rows on 128 threads (defaults: by batch size)
- *   seq_tiles_first=1  that sequential middle hands its workgroups out column tiles fastest instead of frames fastest
- *   seq_t=4|8|16 mid_nt=N   columns per tile of the sequential middle (default 8); lanes per LDS-middle workgroup
+ *   mid_seq=0|1        ADMM single-pass middle one spectrum at a time / side by side (default: by batch size);
+ *   mid_pre=0          ... one at a time: the second tile's loads behind the first transform (default: both up front)
+ *   prow_nt128=0|1     short paired rows on 256 / 128 threads (default: by batch size)
  *   g_plane=0|1        ADMM middles read |PsiT Psi| as a row term + a column term when it separates (0) / from its plane
  *                      (1); default: the terms when the plane exceeds 8 MB
- *   rev_order=BITS     which ADMM kernels walk their grids backwards (1 tiled kernel, 2 / 4 forward / inverse pass A,
- *                      8 LDS middle; default 9);  rev_rows=BITS (1 / 2 forward / inverse ADMM rows; default 0);
- *                      gd_rev=BITS (gradient-descent family / operator: 1 residual rows, 2 update rows, 4 register middle;
- *                      default: all three when a work spectrum exceeds the 256-MB memory-side cache)
- *   mid_swz=0|1        side-by-side middle: adjacent column tiles on one XCD (default: when a tile row is < 128 bytes)
- *   xi_full=1 hv_full=1 no_xhalf=1 k1_scalar=1      ADMM without the sensor-window structure of xi / of the H V row
- *                      transforms; with the stand-alone image-domain kernel; ... in its scalar-lane form
- *   row_rad=16.16.8 passa_rad=16.8 mid_rad=6.10.9   radices of the compile-time row / pass-A / LDS-middle plan (tuning)
- *   k1_half=0          ADMM duals stored plain between the iterations of one call (default 1: half-applied, the tiled
- *                      kernel then does not read V_old: 9R -> 8R)
- *   k1_rows=0          ADMM: keep the tiled TV / W kernel (default 1: paired rows of one quad per lane -- padded widths up to
+ *   mid_swz=0|1        side-by-side middle: adjacent half-line column tiles on one XCD (default: when a tile row is < 128
+ *                      bytes and the spectra are not in pair lines)
+ *   spec_lay=0         ADMM work spectra as plain rows (default: paired rows + a single-pass middle of 8-column tiles keep
+ *                      them in PAIR LINES -- rows 2p, 2p + 1 x 8 columns share one 128-byte line, lpc_kernels.h: spec_col)
+ *   row_rad=16.16.8    radices of the compile-time row plan instead of the chooser's (one module)
+ * The structure of an ADMM iteration (each setting is an older, complete form of the same arithmetic)
+ *   xi_full=1 hv_full=1   without the sensor-window structure of xi / of the H V row transforms
+ *   k1_half=0          duals stored plain between the iterations of one call (default 1: half-applied, the tiled kernel
+ *                      then does not read V_old: 9R -> 8R)
+ *   k1_rows=0          keep the tiled TV / W kernel (default 1: paired rows of one quad per lane -- padded widths up to
  *                      1024 -- take that half of the image-domain work as well: three launches per iteration, r_sp never
  *                      stored; such rows then run on 256 lanes at every batch size)
- *   mid_pre=0|1 mid_twg=1 seq_pair=1               sequential middle: both tiles' loads before the first transform (default:
- *                      launches of >= 4096 workgroups); twiddles from global memory; the two 64-byte tiles of a cache line
- *                      eight blocks apart on one XCD (measured: no gain)
- *   col_single=0|1     ADMM, float32: the whole column transform in ONE launch over whole columns (measured at 12 MP:
- *                      2.25 ms against 1.455 ms for pass A + middle + inverse pass A; default: off)
- *   row_lay=0|1|2|3    LDS layout of the compile-time row tiles: natural / i + i/8 (default where affine) / the conflict-free
- *                      xor layout / i + i/16 (plans of radices 8 and 16; both measured: no faster);  row_nt=N  lanes per row
- *                      workgroup
- *   gd_v2=0            gradient-descent family: the first form of the two fused row kernels (default 1: the second form,
- *                      lpc_gd_v2_kernels.h, wherever the row plan has one radix and the window offset / width are even)
- *   stagger=N lds_pad=N     tuning of those kernels: sleep units between the start times of the workgroups of a launch's
- *                      first generation that share a CU (measured: no gain; default 0); bytes of LDS claimed beyond the
- *                      tile (fewer workgroups per CU; measured: no effect)
- *   module_max=N module_loaded_max=N               plan-module files kept per directory this library writes to (256, least
- *                      recently used removed first); modules kept loaded once no handle uses them (64)
- *   row_pf=N           ADMM inverse rows and the gradient-descent family's residual rows (half-length, float32, radices
- *                      8 / 16) as N persistent workgroups per CU with the next row in flight by LDS-DMA (N >= 16:
- *                      workgroups in all); measured: no faster (default 0)
- *   rpitch_pad=N       floats added to the row pitch of the padded real planes (measured: no faster; default 0)
- *   no_r2=1 no_skew=1 gd_no_fuse_fwd=1              run-time row plans without the folded radix-2 stage / the LDS skew;
- *                      gradient-descent update without the next iteration's forward rows
+ *   k1_group=N         ... on launches of more than 8192 row blocks: runs of N consecutive blocks per XCD (default 16;
+ *                      0: launch order)
+ * Block orders (permutations)
+ *   rev_order=BITS     which ADMM kernels walk their grids backwards (1 tiled kernel, 2 / 4 forward / inverse pass A,
+ *                      8 LDS middle; default 9);  gd_rev=BITS (gradient-descent family / operator: 1 residual rows, 2
+ *                      update rows, 4 register middle; default: all three when a work spectrum exceeds the 256-MB
+ *                      memory-side cache)
+ * Gradient-descent family
+ *   gd_v2=0            the first form of the two fused row kernels (default 1: the second form, lpc_gd_v2_kernels.h,
+ *                      wherever the row plan has one radix and the window offset / width are even)
+ *   gd_no_fuse_fwd=1   update without the next iteration's forward rows
+ * (Variants that were built, measured and not adopted -- persistent row workgroups with LDS-DMA prefetch, whole-column
+ * single-launch transforms, the xor / i + i/16 LDS layouts, staggered first generations, padded row pitches, the half-line
+ * tile pairing of the sequential middle -- left the sources in round 6; their measurements are in profiles/HISTORY.md.)
  * Path-valued options (module_dir, compiler) are unescaped before use: %XX (two hex digits) stands for the byte XX, so the
  * separators of this string can appear in a path -- "%2C" is ',', "%3B" ';', "%20" ' ' -- and a literal '%' that is
  * followed by two hex digits must itself be written "%25".

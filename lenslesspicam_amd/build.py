@@ -109,8 +109,11 @@ def build_hip(force=False, verbose=True):
     return OUT
 
 
-# frame shapes whose plan modules are pre-built: BASELINE.json's configurations C1-C5 and the
-# profile/*.py frame.  (algo: 1 ADMM, 4 FISTA -- the gradient-descent family and the bare operator share one module)
+# frame shapes whose plan modules are pre-built: BASELINE.json's configurations C1-C5, the
+# profile/*.py frame, and the reference's standard frames beyond them -- RPi-HQ (3040 x 4056, lensless/hardware/sensor.py:76)
+# at `downsample` 2 / 4 / 8 (configs/recon/defaults.yaml:20 ships 4) and DiffuserCam-Mirflickr frames (270 x 480) gray and
+# RGB at batch 1 / 8 / 16 / 64 -- so that a deployment without a compiler runs them on compile-time plans too.
+# (algo: 1 ADMM, 4 FISTA -- the gradient-descent family and the bare operator share one module)
 PREBUILT = [
     dict(algo=1, height=3040, width=4056, channels=3), dict(algo=4, height=3040, width=4056, channels=3),   # C2, C3
     dict(algo=1, height=270, width=480, channels=3), dict(algo=4, height=270, width=480, channels=3),       # C1
@@ -119,6 +122,13 @@ PREBUILT = [
     dict(algo=1, height=1080, width=1920, channels=3, depth=16), dict(algo=4, height=1080, width=1920, channels=3),  # C5
     dict(algo=1, height=760, width=1014, channels=1), dict(algo=4, height=760, width=1014, channels=1),     # profile/*.py
     dict(algo=1, height=1080, width=1920, channels=3),                                                       # one plane of C5
+    dict(algo=1, height=1520, width=2028, channels=3), dict(algo=4, height=1520, width=2028, channels=3),   # RPi-HQ / 2
+    dict(algo=1, height=760, width=1014, channels=3), dict(algo=4, height=760, width=1014, channels=3),     # RPi-HQ / 4
+    dict(algo=1, height=380, width=507, channels=3), dict(algo=4, height=380, width=507, channels=3),       # RPi-HQ / 8
+    dict(algo=1, height=270, width=480, channels=3, batch=16),                                               # DiffuserCam RGB
+    dict(algo=1, height=270, width=480, channels=1), dict(algo=4, height=270, width=480, channels=1),       # ... gray
+    dict(algo=1, height=270, width=480, channels=1, batch=8), dict(algo=1, height=270, width=480, channels=1, batch=16),
+    dict(algo=1, height=270, width=480, channels=1, batch=64),
 ]
 PREBUILT_F64 = [dict(algo=1, height=3040, width=4056, channels=3), dict(algo=4, height=3040, width=4056, channels=3)]
 

@@ -118,7 +118,6 @@ static int plan_from_radices(Engine* e, Fft1dPlan& p, int n, const std::vector<i
     if (nb % 8 != 0) p.skew_ok = 0;
     if (!(p.ns[st] % 8 == 0 || (p.ns[st] == 1 && p.radix[st] % 8 == 0))) p.skew_ok = 0;
   }
-  if (e->opt.no_skew) p.skew_ok = 0;
   // diagnostic only (results are garbage): no butterflies at all, every pass degenerates to "tile in, tile out"
   // through LDS -- times the memory access pattern of the passes alone (profiles/r01b_notes.md)
 #ifdef LPC_DEBUG_KNOBS   // never in the product build: the results are garbage by construction
@@ -176,32 +175,14 @@ static bool radices_skew_ok(int n, const std::vector<int>& rad) {
   return true;
 }
 
-// LDS layout of a compile-time row plan (lpc_fft.h: lds_slot)
-static int row_layout(const EngineOpts& o, int n, const std::vector<int>& rad) {
-  // Default: i + i/8 where the plan keeps it affine.  The xor layout (row_lay=2) removes the bank conflicts that layout
-  // causes on every contiguous access -- tools/lds_model.py: 3844 -> 2116 LDS array cycles per 4096-point row against
-  // 1924 conflict-free -- and buys nothing: same-box A/B (profiles/r04f_ab_rowlay.log) C2 130.68 -> 130.29 ms per 40
-  // iterations, C4 35.11 -> 35.05, C1 0.270 -> 0.274, C3 (FISTA) 74.01 -> 74.60, C5 182.6 -> 189.7.  The row kernels run
-  // at 4.85-5.05 TB/s against 5.25 TB/s for a plain device copy on the same box: they wait for HBM, not for LDS
-  // (round 1 found the same when it first removed the conflicts of the natural layout: -2 %).
-  const int skew = radices_skew_ok(n, rad) ? 1 : 0;
-  if (o.no_skew || o.row_lay == 0) return 0;
-  if (o.row_lay == 2) return n % 16 == 0 ? 2 : skew;
-  if (o.row_lay == 3) {      // i + i/16: plans whose radices are all 8 or 16 (lpc_fft.h)
-    bool ok = n % 16 == 0;
-    for (int r : rad) ok = ok && (r == 8 || r == 16);
-    return ok ? 3 : skew;
-  }
-  return skew;
-}
+// LDS layout of a compile-time row plan (lpc_fft.h: lds_slot): i + i/8 where the plan keeps it affine.  (The conflict-free
+// xor layout and i + i/16 were built and measured in rounds 4 / 5: LDS busy 47 % -> 20 %, kernel time unchanged -- the row
+// kernels wait for the vector-memory path, not for LDS; profiles/HISTORY.md)
+static int row_layout(int n, const std::vector<int>& rad) { return radices_skew_ok(n, rad) ? 1 : 0; }
 
 // choose the column split Hp = N1*N2 and the tile width
 static void choose_split(const EngineOpts& opt, int Hp, int Wc, int* N1, int* N2, int* T, bool prefer24 = false,
-                         bool admm_f32 = false, bool single_launch = false) {
-  if (single_launch) {   // whole columns, kSingleT of them per tile (choose_plan: the sequential ADMM middle)
-    *N1 = 1; *N2 = Hp; *T = (opt.seq_t == 1 || opt.seq_t == 2 || opt.seq_t == 4) && (long)Hp * opt.seq_t <= kMaxTilePoints ? opt.seq_t : 2;
-    return;
-  }
+                         bool admm_f32 = false) {
   int t = 16;
   if (opt.col_t > 0) t = opt.col_t;  // option col_t
   while (t > 1 && t / 2 >= Wc) t /= 2;  // tiny images: do not waste lanes on empty columns
@@ -248,8 +229,8 @@ static void set_static_fft(StaticFft& f, int n, const std::vector<int>& rad, int
   f.T = T; f.nt = nt; f.em = em;
 }
 static inline int round_up64(int v) { return (v + 63) / 64 * 64; }
-// options row_rad / passa_rad / mid_rad: "16.16.8" replaces `rad` when it is a factorisation of n into radices that have
-// a butterfly (lpc_fft.h: Dft<R>)
+// option row_rad: "16.16.8" replaces `rad` when it is a factorisation of n into radices that have a butterfly
+// (lpc_fft.h: Dft<R>)
 static void override_radices(const std::string& opt, int n, std::vector<int>& rad) {
   if (opt.empty()) return;
   std::vector<int> r;
@@ -289,44 +270,24 @@ static void choose_plan(Engine* e, bool allow_static) {
   e->spec = PlanSpec{};
   e->spec.family = admm ? LPC_FAM_ADMM : LPC_FAM_GD;
   e->spec.f64 = f32 ? 0 : 1;
-  e->mid_reg = !o.mid_lds;
+  e->mid_reg = true;
   // (a 24-point register middle for ADMM in float32 only: 2 x 24 complex128 values do not fit a lane's registers)
   // (the gradient-descent family keeps 128 x 48 at 6144 rows: its 48-point middle lives in registers)
-  // Single-launch column transform (option col_single): a frame whose columns would be split four-step (pass A + fused
-  // middle + inverse pass A = 12 S + Sc of HBM traffic per iteration) but still fit LDS two columns at a time takes the
-  // sequential middle over WHOLE columns instead: 4 S + Sc in one launch.  Needs the module's compile-time plans, 24-bit
-  // row offsets and a padded height that has a three- or four-stage plan on 1024 lanes.
-  bool single = false;
-  if (admm && f32 && allow_static && !o.no_static_cols && o.col_single != 0 && (long)g.Hp * 2 <= kMaxTilePoints &&
-      (long)g.Hp * 2 * 16 > kMaxTilePoints && g.Wc > 8) {
-    single = o.col_single == 1;      // (-1: not yet a default anywhere -- see profiles/r04_notes.md)
-  }
-  choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, (!admm || f32) && e->mid_reg, admm && f32, single);
+  choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, !admm || f32, admm && f32);
   // the column kernels of a plan module address their tiles with 24-bit row-index x row-step products (k_cols): the step
   // between two rows of one column transform must stay below 2^24 bytes (12 MP: 48 rows x 32.8 KB = 1.6 MB)
   const long col_step = (long)(e->N1 > 1 ? e->N2 : 1) * g.cpitch * (long)sizeof(real2);
-  const bool st_cols = allow_static && !o.no_static_cols && col_step < (1L << 24) && g.Hp < (1 << 24) &&
+  const bool st_cols = allow_static && col_step < (1L << 24) && g.Hp < (1 << 24) &&
                        (unsigned long long)g.Hp * g.cpitch * sizeof(real2) < (1ULL << 32);   // ... and offsets are 32-bit
   // Single-pass ADMM columns whose two-spectra tile allows only 8 image columns (DiffuserCam-sized frames, 540 padded
   // rows): the fused middle takes the two spectra one after the other through the tile (k_cols_mid_admm_seq), one
   // parked in registers while the other is transformed ... when the batch is large enough to fill the chip with
-  // workgroups that each hold one spectrum (measured, profiles/r02_notes.md: 64 frames 1.20 -> 0.96 ms per launch with
-  // 16-column tiles; ONE frame 0.032 -> 0.042 ms: 93 workgroups for 256 CUs)
-  bool seq = false;
-  if (single && st_cols) {
-    seq = true;                    // (e->T already is the tile width: 2 columns, option seq_t = 1 | 2 | 4)
-  } else if (admm && f32 && st_cols && e->N1 == 1 && e->T == 8 && g.Wc > 8 && (long)g.Hp * 16 <= kMaxTilePoints &&
-      o.col_t == 0 && o.mid_seq != 0 && ((long)e->P * ((g.Wc + 15) / 16) >= 512 || o.mid_seq == 1)) {
-    seq = true;
-    // 8 columns per tile on 256 lanes x 17 points: four 39-KB workgroups per CU instead of two 73-KB ones of 512 lanes --
-    // same waves per CU, but barriers over 4 waves and four independent phases to overlap (C4, same box: middle
-    // 0.608 -> 0.550 ms, 20-iteration call 38.38 -> 35.73 ms; profiles/r03_notes.md section 15)
-    e->T = o.seq_t == 16 ? 16 : (o.seq_t == 4 ? 4 : 8);
-  }
-  if (single && !seq) {            // no compile-time column plans after all: back to the four-step split
-    single = false;
-    choose_split(o, g.Hp, g.Wc, &e->N1, &e->N2, &e->T, (!admm || f32) && e->mid_reg, admm && f32, false);
-  }
+  // workgroups that each hold one spectrum (64 frames 1.20 -> 0.96 ms per launch; ONE frame 0.032 -> 0.042 ms: 93
+  // workgroups for 256 CUs): four 39-KB workgroups of 512 lanes x 9 points per CU inside 64 VGPRs.  (Whole 6144-point
+  // columns two at a time through the same kernel -- one launch instead of three per column step -- were built and measured
+  // in round 4: 2.25 ms against 1.455 ms; 16-column tiles: 30 % slower.  profiles/HISTORY.md)
+  const bool seq = admm && f32 && st_cols && e->N1 == 1 && e->T == 8 && g.Wc > 8 && (long)g.Hp * 16 <= kMaxTilePoints &&
+                   o.col_t == 0 && o.mid_seq != 0 && ((long)e->P * ((g.Wc + 15) / 16) >= 512 || o.mid_seq == 1);
   // Row passes: one real row per half-length complex transform (k_r*_half kernels) once the
   // paired tile is so large that fewer than 5 workgroups fit a CU's 160 KiB of LDS.  Measured (r01b_notes.md):
   // 8192 columns +3 % it/s, 3840 columns (C5) +1.8 %; 960 columns (C4) -5 %: the short transforms leave most
@@ -348,7 +309,7 @@ static void choose_plan(Engine* e, bool allow_static) {
   std::vector<int> rad;
   // the X half of the image-domain work moves into the forward rows when the stencil half can run as the tiled
   // four-pixel-lane kernel (k_admm_spatial_v4<.., XHALF = false>): padded width a multiple of 4
-  const bool xhalf = admm && g.Wp % 4 == 0 && !o.no_xhalf && !o.k1_scalar;
+  const bool xhalf = admm && g.Wp % 4 == 0;
   // ---- rows
   if (e->rows_half) {
     const int n = g.Wp / 2;
@@ -370,11 +331,10 @@ static void choose_plan(Engine* e, bool allow_static) {
     // (1536 x 2048 frames: 4.43 -> 4.30 ms per 60 iterations); 2048-point rows are faster on 256 in both families
     if (n == 4096 && rad[0] == 16) nt = 512;
     if (n == 1024 && !admm) nt = 256;
-    if (o.row_nt >= 64 && o.row_nt <= 1024 && o.row_nt % 64 == 0) nt = o.row_nt;
     set_static_fft(sp.row, n, rad, 1, nt, (n + nt - 1) / nt);
     if (sp.row.n && sp.row.em <= 16) {
       sp.row_kind = LPC_ROWS_HALF;
-      sp.row_sk = row_layout(o, n, rad);
+      sp.row_sk = row_layout(n, rad);
       sp.row_x = xhalf;
     }
   } else if (admm) {    // paired rows: ADMM's own kernels only (set-up transforms keep the run-time plan)
@@ -395,14 +355,13 @@ static void choose_plan(Engine* e, bool allow_static) {
     // size (64 frames 33.1 -> 31.0 ms per 20 iterations, 8 frames 4.27 -> 4.00 ms; profiles/r05_notes.md section 5)
     if (nt < 256 && n >= 512) {
       const bool batch = (long)e->P * g.Hp >= 8192;
-      const bool k1r = xhalf && o.k1_rows != 0 && n % 4 == 0 && n / 4 <= 256 && !o.k1_scalar;   // (lpc_module.cpp: kK1Rows)
+      const bool k1r = xhalf && o.k1_rows != 0 && n % 4 == 0 && n / 4 <= 256;   // (lpc_module.cpp: kK1Rows)
       if (o.prow_nt128 == 0 || (o.prow_nt128 < 0 && (!batch || k1r))) nt = 256;
     }
-    if (o.row_nt >= 64 && o.row_nt <= 1024 && o.row_nt % 64 == 0) nt = o.row_nt;
     set_static_fft(sp.row, n, rad, 1, nt, (n + nt - 1) / nt);
     if (sp.row.n && sp.row.em <= 16) {
       sp.row_kind = LPC_ROWS_PAIRED;
-      sp.row_sk = row_layout(o, n, rad);
+      sp.row_sk = row_layout(n, rad);
       sp.row_x = xhalf;
     }
   }
@@ -417,7 +376,6 @@ static void choose_plan(Engine* e, bool allow_static) {
     plan_radices(e->N1, rad);
     if (e->N1 == 90) rad = {10, 9};      // two stages instead of 6.5.3: 16 x 1080p planes 48.1 -> 46.9 ms per 20 iterations
                                           // (r03k_ab.log; 9.10, 18.5, 30.3 are slower, and 128 = 16.8 is slower than 8.8.2 at 12 MP)
-    override_radices(o.passa_rad, e->N1, rad);
     const int pts = e->N1 * T;
     int nt = T >= 32 ? 512 : 256;
     while (nt < 1024 && (pts + nt - 1) / nt > 16) nt *= 2;
@@ -441,16 +399,8 @@ static void choose_plan(Engine* e, bool allow_static) {
     // 5-iteration call 0.243 -> 0.234 ms (profiles/r04t_ab_c1.log; 30.18 on 1024 lanes 19.8 us, 768 lanes 19.6 us).
     // Only while every workgroup has a CU of its own (256 on an MI355X): two frames = 366 tiles are 6 % SLOWER that way
     // (0.370 -> 0.392 ms, r04t_ab_c1c.log).
-    const bool one_wave_of_tiles = !seq && !single && e->N1 == 1 && (long)e->P * ((g.Wc + T - 1) / T) <= plan_cu_count() && n * 2 * T > 8192;
+    const bool one_wave_of_tiles = !seq && e->N1 == 1 && (long)e->P * ((g.Wc + T - 1) / T) <= plan_cu_count() && n * 2 * T > 8192;
     if (one_wave_of_tiles && n == 540) rad = {6, 10, 9};
-    if (single) {                  // long columns: fat stages (plan_radices stops at radix 8)
-      rad.clear();
-      int r = n;
-      while (r % 16 == 0 && r / 16 >= 16) { rad.push_back(16); r /= 16; }
-      std::vector<int> tail;
-      if (plan_radices(r, tail)) rad.insert(rad.end(), tail.begin(), tail.end());
-    }
-    override_radices(o.mid_rad, n, rad);
     const int pts = n * (seq ? T : 2 * T);
     int nt = pts <= 4096 ? 256 : (pts <= 9216 ? 512 : 1024);
     // one spectrum at a time: 8 columns x 540 points on 512 lanes x 9 points (round 3: 256 x 17) -- the middle of a batch
@@ -460,33 +410,26 @@ static void choose_plan(Engine* e, bool allow_static) {
     // 512 lanes inside 64 VGPRs 0.464 / 70.6
     if (seq) nt = pts <= 9 * 256 ? 256 : (pts <= 18 * 512 ? 512 : 1024);
     if (one_wave_of_tiles) nt = 1024;
-    if (o.mid_nt >= 64 && o.mid_nt <= 1024 && o.mid_nt % 64 == 0) nt = o.mid_nt;
     set_static_fft(sp.mid, n, rad, T, nt, (pts + nt - 1) / nt);
     if (sp.mid.n && sp.mid.em <= 18) {
       sp.mid_kind = seq ? LPC_MID_SEQ : LPC_MID_PAIR;
       if (seq) {   // waves per SIMD the register allocation must allow: as many workgroups as the LDS holds
-        sp.mid_twg = o.mid_twg ? 1 : 0;
-        // both tiles' loads up front when the launch is many waves of workgroups deep (C4, 64 frames: 11 712 workgroups
-        // for 1 024 resident, middle 0.494 -> 0.473 ms; an 8-frame shard -- 1 464 workgroups -- is 1.5 % slower with it:
-        // profiles/r04h_ab.log)
-        sp.mid_pre = o.mid_pre >= 0 ? (o.mid_pre ? 1 : 0) : 1;     // (round 6: the 8-frame shard too, 3.86 -> 3.83 ms per 20 iterations)
-        const size_t lds = (size_t)n * (T + (sp.mid_twg ? 0 : 1)) * sizeof(real2);
+        // both tiles' loads up front (round 4: large batches only; round 6: the 8-frame shard too, 3.86 -> 3.83 ms per call)
+        sp.mid_pre = o.mid_pre >= 0 ? (o.mid_pre ? 1 : 0) : 1;
+        const size_t lds = (size_t)n * (T + 1) * sizeof(real2);        // tile + the plan's twiddles behind it
         const int wgs = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds));
         // (512 lanes: 8 = a 64-VGPR allocation, four workgroups per CU as the LDS allows -- 68 registers without the
-        // bound, i.e. three; the middle of 64 / 8 frames 0.493 -> 0.464 ms / 74.2 -> 70.6 us, three instances each,
-        // profiles/r04u_ab_shard4.log; 8-12 bytes of scratch)
+        // bound, i.e. three; the middle of 64 / 8 frames 0.493 -> 0.464 ms / 74.2 -> 70.6 us)
         sp.mid_minw = std::min(8, std::max(1, (wgs * nt + 255) / 256));
-        if (o.mid_minw > 0) sp.mid_minw = std::min(8, o.mid_minw);
       }
     } else {
       sp.mid = StaticFft{};
     }
   }
-  if (seq && sp.mid_kind != LPC_MID_SEQ) e->T = 8;   // (no module kernel for it after all: back to the two-spectra tile)
-  // pair-line work spectra (lpc_kernels.h: spec_col): paired rows + the 8-column sequential middle, float32 (a tile row
+  // pair-line work spectra (lpc_kernels.h: spec_col): paired rows + a single-pass middle of 8-column tiles, float32 (a tile row
   // of 8 complex128 columns is a whole line already)
   sp.slay = (admm && f32 && sp.row_kind == LPC_ROWS_PAIRED && sp.mid_kind != LPC_MID_RUNTIME && e->N1 == 1 && sp.mid.T == 8 &&
-             !single && o.spec_lay != 0) ? 1 : 0;
+             o.spec_lay != 0) ? 1 : 0;
 }
 
 // frame geometry (rfft_convolve.py:110-117) and the launch plan -- no device work (also serves lpc_plan_module)
@@ -499,7 +442,7 @@ static int setup_shape(Engine* e, bool* want_static_out) {
   g.Wc = g.Wp / 2 + 1;
   g.sh = (g.Hp - g.H) / 2;
   g.sw = (g.Wp - g.W) / 2;
-  g.rpitch = (g.Wp + 3) / 4 * 4 + (e->opt.rpitch_pad > 0 ? e->opt.rpitch_pad / 4 * 4 : 0);
+  g.rpitch = (g.Wp + 3) / 4 * 4;
   g.cpitch = (g.Wc + 15) / 16 * 16;
   g.rplane = (long)g.Hp * g.rpitch;
   g.cplane = (long)((g.Hp + 1) & ~1) * g.cpitch;      // whole row pairs (PlaneGeom::slay)
@@ -529,13 +472,17 @@ static int setup_geometry(Engine* e) {
   if (!want_static) e->mod_note = e->opt.no_static ? "no_static" : "small frame";
   else if (e->spec.any()) {
     e->mod = get_plan_module(e->spec, e->opt, e->opt.jit != 0, &e->mod_note);
-    if (!e->mod) choose_plan(e, false);
+    if (!e->mod) {      // lpc_plan_info() names the module a deployment without a compiler would have to ship
+      const std::string key = plan_spec_key(e->spec);
+      if (e->mod_note.find(key) == std::string::npos) e->mod_note = "module " + key + ": " + e->mod_note;
+      choose_plan(e, false);
+    }
   }
   if (!e->mod) e->spec = PlanSpec{};
   e->g.slay = (e->mod && e->mod->slay) ? 1 : 0;
   const bool admm = c.algo == LPC_ALGO_ADMM;
   LPC_OK(build_plan(e, e->planW, g.Wp));
-  e->rows_r2 = e->planW.nst >= 2 && e->planW.radix[e->planW.nst - 1] == 2 && !e->opt.no_r2;
+  e->rows_r2 = e->planW.nst >= 2 && e->planW.radix[e->planW.nst - 1] == 2;
   if (e->rows_r2) {
     std::vector<int> rad{2};
     for (int st = 0; st + 1 < e->planW.nst; ++st) rad.push_back(e->planW.radix[st]);
@@ -549,13 +496,13 @@ static int setup_geometry(Engine* e) {
   if (e->N1 > 1) LPC_OK(build_plan(e, e->planA, e->N1));
   // The half of the image-domain work that needs no neighbours rides in the module's forward row kernel: the blocks of
   // `a` compute xi' and a = mu1 X - xi' from xi, HV, HV_old, y themselves (-2R per iteration), the tiled kernel keeps
-  // the stencil half at its own occupancy (option no_xhalf: the full stand-alone kernel) ...
+  // the stencil half at its own occupancy (without a module: the full stand-alone kernel) ...
   e->xhalf_rows = admm && e->mod && e->mod->admm_rows_fwd_x;
   // ... narrow frames (paired rows of one quad per lane: padded widths up to 1024) hand it the TV / W half too: three
   // launches per iteration, r_sp never stored.  One small frame is a chain of launch boundaries and memory latencies
   // (C1 -7.6 %), a batch saves the trip of r_sp through memory and the tiled kernel's launch (C4 -6.3 %);
   // profiles/r05_notes.md section 5 (option k1_rows=0: off)
-  e->k1_rows = e->xhalf_rows && e->mod->k1_rows && g.Wp % 4 == 0 && !e->opt.k1_scalar && e->opt.k1_rows != 0;
+  e->k1_rows = e->xhalf_rows && e->mod->k1_rows && g.Wp % 4 == 0 && e->opt.k1_rows != 0;
   // ... outside the sensor window that half works from HV alone (AdmmScalars::xiw; option xi_full: every pixel alike) ...
   e->xi_window = e->xhalf_rows && !e->opt.xi_full;
   // ... and rows wholly outside it skip the H V row transforms in both directions: the kept rows of SB are rescaled by
@@ -563,7 +510,7 @@ static int setup_geometry(Engine* e) {
   e->hv_skip = e->xi_window && !e->opt.hv_full && e->mod->admm_rows_inv && (e->N1 > 1 || e->mod->admm_mid);
   e->gd_fuse_fwd = c.algo >= LPC_ALGO_GD && e->mod && e->mod->gd_rows_update_fwd && !e->opt.gd_no_fuse_fwd;
   // the second form of the fused row kernels: 8-byte accesses to y / x need an even window offset and frame width
-  e->gd_v2 = c.algo >= LPC_ALGO_GD && e->mod && e->mod->gd_v2 && e->tws_row && e->opt.gd_v2 != 0 && e->opt.row_pf <= 0 &&
+  e->gd_v2 = c.algo >= LPC_ALGO_GD && e->mod && e->mod->gd_v2 && e->tws_row && e->opt.gd_v2 != 0 &&
              ((g.sw | g.W) & 1) == 0 && g.W >= 2;
   if (e->opt.gd_rev < 0)     // EngineOpts::gd_rev
     // all three (the row kernels and the register middle alternate with the forward-walking pass A, so every kernel
@@ -807,7 +754,7 @@ static int admm_iterate(Engine* e, int n_iter) {
   const unsigned tiles_x = (g.Wp + TW - 1) / TW, tiles_y = (g.Hp + TH - 1) / TH;
   const dim3 k1_grid(tiles_x * tiles_y, e->P, 1);
   // 16-byte-lane kernel whenever the padded width allows aligned four-pixel lanes (every BASELINE size does)
-  const bool vec4 = (g.Wp % 4 == 0) && !e->opt.k1_scalar;
+  const bool vec4 = g.Wp % 4 == 0;
   constexpr int TH4 = 8, TW4 = 256;
   const unsigned tiles_x4 = (g.Wp + TW4 - 1) / TW4, tiles_y4 = (g.Hp + TH4 - 1) / TH4;
   const dim3 k1_grid4(tiles_x4 * tiles_y4, e->P, 1);
@@ -1582,7 +1529,7 @@ int lpc_kernel_bytes(lpc_handle e, int kid, double* bytes) {
       // ... and without V_old once the duals travel half-applied between the iterations of a call (k1_half): 8R
       // ... k1_rows (small frames): not launched; the forward rows read V, eta0, eta1, rho (+ V_old without k1_half)
       // instead of r_sp and write eta0, eta1, rho: + 6R (7R)
-      case LPC_K_SPATIAL: b = e->k1_rows ? 0.0 : e->xhalf_rows ? ((e->opt.k1_half != 0 && g.Wp % 4 == 0 && !e->opt.k1_scalar) ? 8.0 : 9.0) * R
+      case LPC_K_SPATIAL: b = e->k1_rows ? 0.0 : e->xhalf_rows ? ((e->opt.k1_half != 0 && g.Wp % 4 == 0) ? 8.0 : 9.0) * R
                                             : 15.0 * R + R0; break;
       // ... with xi confined to the sensor window (AdmmScalars::xiw) the row kernel reads r_sp, HV everywhere (2R) and
       // xi, HV_old / writes xi only over the window (3 window-sized arrays per plane) and y: 2R + 3 Rw + R0 + 2S

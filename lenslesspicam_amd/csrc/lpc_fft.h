@@ -296,37 +296,25 @@ static __device__ __forceinline__ void twiddle_mul_lane(real2* v, const real2* L
 //      CONTIGUOUS access then spans 36 slots per 32 lanes and wraps onto its own banks -- ds_read_b64 2 -> 4 array cycles,
 //      ds_write_b64 4 -> 8: half of all LDS cycles of the row kernels were conflicts (SQ_LDS_BANK_CONFLICT /
 //      SQ_LDS_IDX_ACTIVE = 0.44-0.50 in profiles/r03fin_c2_counters.md; tools/lds_model.py reproduces the factor)
-//   2  i ^ ((i >> 4) & 15): a permutation inside every aligned block of 16 elements (128 bytes), so contiguous accesses
-//      stay conflict-free, and the 16 lanes of a store group that write elements 16 apart (stride-R stores of the first
-//      stage, stride-NS stores of the next) land in 16 different 8-byte bank pairs.  No padding.  Needs n % 16 == 0.
-//      Model, array cycles per 4096-point workgroup: natural 5764, i + i/8 3844, this 2116, conflict-free 1924.
-//   3  i + i/16 (round 5; plans whose radices are all 8 or 16): one slot of padding per 16 elements.  The stride-16
-//      stores of a radix-16 first stage (lane j writes elements 16 j + m) land 17 slots = 34 banks apart -- 32 lanes on 32
-//      different bank pairs -- a contiguous 32-lane access spans 34 slots (2 of 32 lanes wrap; i + i/8: 4), and every
-//      stride that is a multiple of 16 stays affine: immediate LDS offsets, no address arithmetic per element.
 #define LPC_LAY_NONE 0
 #define LPC_LAY_SKEW8 1
-#define LPC_LAY_XOR16 2
-#define LPC_LAY_SKEW16 3
 template <int SKEW>
 static __device__ __forceinline__ int lds_slot(int i) {
-  return SKEW == LPC_LAY_SKEW8 ? i + (i >> 3)
-                               : (SKEW == LPC_LAY_XOR16 ? (i ^ ((i >> 4) & 15)) : (SKEW == LPC_LAY_SKEW16 ? i + (i >> 4) : i));
+  return SKEW == LPC_LAY_SKEW8 ? i + (i >> 3) : i;
 }
 // slot(i + m * stride) == slot(i) + m * lds_stride(stride) for every i, m?  (then a stage addresses its R elements with
 // immediates from one base)
 template <int SKEW>
 static __host__ __device__ constexpr bool lds_affine(int stride) {
-  return SKEW == LPC_LAY_SKEW8 ? stride % 8 == 0
-                               : (SKEW == LPC_LAY_XOR16 ? stride % 256 == 0 : (SKEW == LPC_LAY_SKEW16 ? stride % 16 == 0 : true));
+  return SKEW == LPC_LAY_SKEW8 ? stride % 8 == 0 : true;
 }
 template <int SKEW>
 static __host__ __device__ constexpr int lds_stride(int stride) {
-  return SKEW == LPC_LAY_SKEW8 ? stride + (stride >> 3) : (SKEW == LPC_LAY_SKEW16 ? stride + (stride >> 4) : stride);
+  return SKEW == LPC_LAY_SKEW8 ? stride + (stride >> 3) : stride;
 }
 static __host__ __device__ __forceinline__ int lds_slots_skewed(int n) { return n + (n >> 3) + 1; }
 static __host__ __device__ __forceinline__ int lds_slots_of(int n, int layout) {
-  return layout == LPC_LAY_SKEW8 ? lds_slots_skewed(n) : (layout == LPC_LAY_SKEW16 ? n + (n >> 4) + 1 : n);
+  return layout == LPC_LAY_SKEW8 ? lds_slots_skewed(n) : n;
 }
 
 // One Stockham stage over a tile of BT transforms held in LDS (in place).  Ends with a barrier.

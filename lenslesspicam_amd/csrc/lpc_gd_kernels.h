@@ -208,151 +208,6 @@ __global__ __launch_bounds__(NT) void k_rinv_gd_mid_half(PlaneGeom g, PL plan, c
   untangle_half_store<NT, SK>(s, M, twW, Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch, tid);
 }
 
-// ---- k_rinv_gd_mid_half as a PERSISTENT workgroup with the next row in flight (option row_pf; compile-time plans) ------
-// The residual rows carry two 4096-point transforms for every 80 KB they move: unlike ADMM's inverse rows (which wait
-// for HBM, profiles/r04_notes.md section 6) they are bound by what a CU overlaps -- four workgroups per CU, each paying
-// its load latency, its launch and twelve barriers per row.  Here a workgroup walks rows blockIdx.x, + gridDim.x, ...:
-//   * the half-spectrum of the NEXT row travels into a second LDS buffer by LDS-DMA while this row is transformed;
-//   * no table is read from global memory inside the loop (vmcnt retires in order: waiting for an entry would wait
-//     for the copy): stage twiddles from LDS (LdsTw), the (un)tangling twiddles of a lane in registers;
-//   * the lane's samples of the measurement row are loaded where the first forward stage forms the residual: that wait
-//     also collects the copy, which has had the three inverse stages to land (keeping the samples in registers from
-//     before the copy -- 32 VGPRs across the inverse stages -- made the kernel spill, and a spill reload is a vector
-//     memory operation that drains the copy).
-// Same arithmetic in the same order as k_rinv_gd_mid_half: bit-identical.  Needs the `pair` geometry (window offset,
-// frame width and Wp / 2 even: 8-byte accesses to y) -- the launcher checks -- and radices 8 / 16, one butterfly per lane.
-template <int NT, int EMAX, int SK, class PL>
-__global__ __launch_bounds__(NT, 2 * NT / 256) void k_rinv_gd_mid_half_pf(PlaneGeom g, PL plan,
-                                                                          const real2* LPC_RESTRICT twW,
-                                                                          const real2* LPC_RESTRICT Sin,
-                                                                          real2* LPC_RESTRICT Sout,
-                                                                          const real* LPC_RESTRICT Y, int nwork) {
-  using P = typename PL::plan;
-  constexpr int M = P::n, R0 = P::radix(0), NB0 = M / R0;
-  static_assert(LdsTw<P>::ok(NT) && R0 <= 16 && M % 2 == 0, "row_pf: radices 8 / 16, one butterfly per lane");
-  LPC_DYN_SMEM(smem);
-  real2* s = (real2*)smem;
-  real2* st = s + ((LPC_ROW_SMEM_BYTES(M, SK) + 15) / 16) * 2;       // staging: points 0 .. M (+1), natural order
-  const int tid = LPC_TID(NT);
-  const long pl = blockIdx.y;
-  const int hh = g.Hp / 2, hw = g.Wp / 2;
-  constexpr int EH = EMAX / 2 + 1;
-  constexpr int NR = (M + 2 + 2 * NT - 1) / (2 * NT);
-  LdsTw<P> h;
-  h.template fill<NT>(st + M + 8, plan.tw, tid);
-  const int dpl = (int)(pl / g.DC) * g.C + (int)(pl % g.C);
-  auto rowu = [&](int i) { return g.rev ? nwork - 1 - i : i; };
-  auto issue = [&](int i, int tid) {
-    const int lane = tid & 63;
-    const int sr = wrap_add(g.sh + rowu(i), hh, g.Hp);
-    const real2* in = Sin + pl * g.cplane + (long)sr * g.cpitch;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int e = 2 * (tid + r * NT);
-      if (e <= M) lpc_glds16(in + e, st + 2 * (r * NT + (tid - lane)), lane);
-    }
-  };
-  int i = (int)blockIdx.x;
-  if (i < nwork) issue(i, tid);
-  const int tid0 = tid;
-  for (; i < nwork; i += (int)gridDim.x) {
-    const int u = rowu(i);
-    // (tid behind a compiler barrier, once per row: every tile / staging / sample address is the same for every row, and
-    // hoisted out of the row loop they are spilled -- a spill reload is a vector memory operation that drains the copy)
-    int tid = tid0;
-#if !defined(LPC_SIMT_EMU)
-    asm volatile("" : "+v"(tid));
-    __builtin_assume((unsigned)tid < (unsigned)NT);
-#endif
-    // the (un)tangling twiddles of this lane: loaded behind the copy that is waited for next, and once more before the
-    // untangling (by then the next copy has had both transforms to land) -- kept across the row they are spilled
-    real2 twk[EH];
-#pragma unroll
-    for (int q = 0; q < EH; ++q) {
-      const int k = tid + q * NT;
-      twk[q] = twW[k <= M / 2 ? k : 0];
-    }
-    lpc_glds_wait();
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < EH; ++q) {        // tangle_half_load, from the staging buffer
-      const int k = tid + q * NT;
-      if (k <= M / 2) {
-        real2 a = st[k], b = st[M - k];
-        if (k == 0) { a.y = (real)0.; b.y = (real)0.; }
-        const real2 e = make_real2(a.x + b.x, a.y - b.y);
-        const real2 d = make_real2(a.x - b.x, a.y + b.y);
-        const real2 od = cmul_conj(d, twk[q]);
-        s[lds_slot<SK>(k)] = make_real2(e.x - od.y, e.y + od.x);
-        if (k != 0 && k != M - k) s[lds_slot<SK>(M - k)] = make_real2(e.x + od.y, od.x - e.y);
-      }
-    }
-    __syncthreads();
-    const real* y = Y + (long)dpl * g.uplane + (long)u * g.W;
-    if (i + (int)gridDim.x < nwork) issue(i + (int)gridDim.x, tid);
-    // inverse transform, result in the tile (natural order)
-    sfft_stages_h<P, NT, true, SK>(s, h, tid, std::make_integer_sequence<int, P::nst>{});
-    // forward transform; its first stage forms the residual: sample 2i, 2i+1 of the re-padded row =
-    // (inside the window) ? conv[(2i + Wp/2) mod Wp] - y : 0
-    {
-      real2 v[R0];
-      const int t = tid;
-      if (t < NB0) {
-        real2 yy[R0];
-#pragma unroll
-        for (int m = 0; m < R0; ++m) {          // unconditional loads (a sample outside the window reads y[0], unused)
-          const int c = 2 * (t + m * NB0) - g.sw;
-          yy[m] = *(const real2*)(y + ((c >= 0 && c < g.W) ? c : 0));
-        }
-#pragma unroll
-        for (int m = 0; m < R0; ++m) {
-          const int ii = t + m * NB0, c = 2 * ii - g.sw;
-          const real2 z = s[lds_slot<SK>(wrap_add(2 * ii, hw, g.Wp) >> 1)];
-          v[m] = (c >= 0 && c < g.W) ? make_real2(z.x - yy[m].x, z.y - yy[m].y) : make_real2((real)0., (real)0.);
-        }
-      }
-      __syncthreads();
-      if (tid < NB0) {
-        Dft<R0, false>::run(v);
-        const int ob = lds_slot<SK>(tid * R0);
-        if (SK == LPC_LAY_SKEW8) {
-#pragma unroll
-          for (int m = 0; m < R0; ++m) s[ob + m + (m >> 3)] = v[m];
-        } else if (SK == LPC_LAY_XOR16 || SK == LPC_LAY_SKEW16) {
-#pragma unroll
-          for (int m = 0; m < R0; ++m) s[lds_slot<SK>(tid * R0 + m)] = v[m];
-        } else {
-#pragma unroll
-          for (int m = 0; m < R0; ++m) s[ob + m] = v[m];
-        }
-      }
-      __syncthreads();
-    }
-    sfft_stages_h1<P, NT, false, SK>(s, h, tid, std::make_integer_sequence<int, P::nst - 1>{});
-    // untangle_half_store with the twiddles of this lane from registers
-    real2* o = Sout + pl * g.cplane + (long)(g.sh + u) * g.cpitch;
-#pragma unroll
-    for (int q = 0; q < EH; ++q) {
-      const int k = tid + q * NT;
-      twk[q] = twW[k <= M / 2 ? k : 0];
-    }
-#pragma unroll
-    for (int q = 0; q < EH; ++q) {
-      const int k = tid + q * NT;
-      if (k <= M / 2) {
-        const int km = M - k;
-        const real2 zk = s[lds_slot<SK>(k)];
-        const real2 zm = s[lds_slot<SK>(k == 0 ? 0 : km)];
-        const real ex = (real)0.5 * (zk.x + zm.x), ey = (real)0.5 * (zk.y - zm.y);
-        const real2 od = make_real2((real)0.5 * (zk.y + zm.y), (real)-0.5 * (zk.x - zm.x));
-        const real2 wo = cmul(twk[q], od);
-        o[k] = make_real2(ex + wo.x, ey + wo.y);
-        if (k != km) o[km] = make_real2(ex - wo.x, wo.y - ey);
-      }
-    }
-  }
-}
-
 template <int NT, int EMAX, int SK, class PL = Fft1dPlan>
 __global__ __launch_bounds__(NT) void k_rinv_gd_update_half(PlaneGeom g, PL plan,
                                                              const real2* LPC_RESTRICT twW,

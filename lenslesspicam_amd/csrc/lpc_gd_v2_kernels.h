@@ -266,13 +266,12 @@ template <int NT, int SK, class PL>
 __global__ __launch_bounds__(NT, LPC_V2_RESID_MINW) void k_gd_resid_v2(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                                const real2* LPC_RESTRICT Sin,
                                                                real2* LPC_RESTRICT Sout, const real* LPC_RESTRICT Y,
-                                                               FastDiv fdc, FastDiv fc, int stagger) {
+                                                               FastDiv fdc, FastDiv fc) {
   using P = typename PL::plan;
   constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB, L = GdV2<P>::L;
   static_assert(GdV2<P>::ok && NT == NB, "k_gd_resid_v2: one butterfly per lane and stage");
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  lpc_stagger(blockIdx.x + gridDim.x * blockIdx.y, stagger >> 16, stagger & 0xffff);
   const int j = LPC_TID(NT), u = (int)LPC_BX(g);
   const unsigned pl = LPC_BY(g);
   const int sr = wrap_add(g.sh + u, g.Hp / 2, g.Hp);
@@ -315,8 +314,7 @@ template <int NT, int SK, class PL, int KIND, int FIRST>
 __global__ __launch_bounds__(NT, 4) void k_gd_update_fwd_v2(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
                                                             const real2* LPC_RESTRICT Sin, real2* LPC_RESTRICT Sout,
                                                             real* LPC_RESTRICT X, real* LPC_RESTRICT AUX,
-                                                            const real* LPC_RESTRICT alpha, GdScalars pin, FastDiv fc,
-                                                            int stagger) {
+                                                            const real* LPC_RESTRICT alpha, GdScalars pin, FastDiv fc) {
   using P = typename PL::plan;
   constexpr int M = GdV2<P>::M, R = GdV2<P>::R, NB = GdV2<P>::NB, L = GdV2<P>::L, H = R / 2;
   static_assert(GdV2<P>::ok && NT == NB, "k_gd_update_fwd_v2: one butterfly per lane and stage");
@@ -325,7 +323,6 @@ __global__ __launch_bounds__(NT, 4) void k_gd_update_fwd_v2(PlaneGeom g, PL plan
   p.kind = KIND; p.first = FIRST; p.split = 0;
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
-  lpc_stagger(blockIdx.x + gridDim.x * blockIdx.y, stagger >> 16, stagger & 0xffff);
   const int j = LPC_TID(NT), u = (int)LPC_BX(g);
   const unsigned pl = LPC_BY(g);
   const int sr = wrap_add(g.sh + u, g.Hp / 2, g.Hp);

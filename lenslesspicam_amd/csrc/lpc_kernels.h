@@ -51,20 +51,6 @@ static __host__ __device__ __forceinline__ int spec_col(int k) { return SL ? k +
 #define LPC_BY(g) ((g).rev ? gridDim.y - 1u - blockIdx.y : blockIdx.y)
 #define LPC_BZ(g) ((g).rev ? gridDim.z - 1u - blockIdx.z : blockIdx.z)
 
-// ---- phase stagger of the first generation of workgroups ---------------------------------------------------------------
-// A row kernel's workgroup is load -> transform(s) -> store, and every workgroup of a launch does the same amount of
-// work: the ~1300 workgroups that start together at the top of a launch stay in step, generation after generation (a slot
-// is refilled when its workgroup ends, i.e. in step too) -- the whole chip loads, then the whole chip computes with HBM
-// idle, then the whole chip stores.  The kernel then takes memory time PLUS compute time instead of the larger of the two
-// (knock-out timings, profiles/r05_notes.md: removing the butterflies changes nothing, removing 50 % of the bytes removes
-// exactly their HBM time).  Fix: the workgroups of the first generation that share a CU start `layer * units` sleep units
-// apart (layer = which of the CU's slots the block fills: linear block id / (8 XCDs x 32 CUs)), one fifth of a workgroup's
-// lifetime each; later generations inherit the offsets.  Costs the first generation's sleep once per launch.
-//   lpc_stagger(linear block id, slots per CU, units): call at the top of the kernel (all lanes).
-static __device__ __forceinline__ void lpc_stagger(unsigned bid, int slots, int units) {
-  if (units > 0 && bid < 256u * (unsigned)slots) lpc_sleep_units((int)(bid >> 8) * units);
-}
-
 static __device__ __forceinline__ int wrap_add(int i, int d, int n) {  // (i + d) mod n for |d| <= n
   int r = i + d;
   if (r >= n) r -= n;
@@ -353,91 +339,6 @@ __global__ __launch_bounds__(NT) void k_rinv_half(PlaneGeom g, PL plan, const re
   fft_tile<NT, EMAX, true, SK, true, false, true>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, out);
 }
 
-// ---- k_rinv_half as a PERSISTENT workgroup with the next row in flight (option row_pf; compile-time plans) ----------
-// k_rinv_half runs load -> tangle -> three LDS stages -> store once per workgroup: every row pays its HBM latency in
-// full and only the other workgroups of the CU (four at 64 VGPRs) hide it.  Here a workgroup walks rows
-// blockIdx.x, + gridDim.x, ...: while row u is transformed, the half-spectrum of row u + gridDim.x travels straight into
-// a second LDS buffer by LDS-DMA (lpc_glds16: no VGPRs, in flight across the barriers of the stages); the stage twiddles
-// come from a copy in LDS (LdsTw: a table load inside the loop would wait for the copy as well -- vmcnt retires in
-// order), the tangling twiddles of a lane are the same for every row and stay in registers.  LDS: tile + M + 8 staging
-// points + the stage twiddles (4096-point rows: 37 + 33 + 8.5 KB, two workgroups per CU).  Same arithmetic in the same order as
-// k_rinv_half: bit-identical output.
-template <int NT, int EMAX, int SK, class PL>
-__global__ __launch_bounds__(NT, 2 * NT / 256) void k_rinv_half_pf(PlaneGeom g, PL plan, const real2* LPC_RESTRICT twW,
-                                                      const real2* LPC_RESTRICT SA, const real2* LPC_RESTRICT SB,
-                                                      real* LPC_RESTRICT A, real* LPC_RESTRICT B, int skip_b_outside,
-                                                      int nwork) {
-  using P = typename PL::plan;
-  constexpr int M = P::n;
-  static_assert(LdsTw<P>::ok(NT), "row_pf: radices 8 / 16, one butterfly per lane");
-  static_assert(M % 2 == 0, "row_pf: 16-byte copies");
-  LPC_DYN_SMEM(smem);
-  real2* s = (real2*)smem;
-  real2* st = s + ((LPC_ROW_SMEM_BYTES(M, SK) + 15) / 16) * 2;       // staging: points 0 .. M (+1) in natural order
-  const int tid = LPC_TID(NT);
-  const int lane = tid & 63;
-  const long pl = blockIdx.y;
-  constexpr int EH = EMAX / 2 + 1;
-  constexpr int NR = (M + 2 + 2 * NT - 1) / (2 * NT);     // copy rounds: 2 points per lane and round
-  LdsTw<P> h;
-  h.template fill<NT>(st + M + 8, plan.tw, tid);     // (visible behind the first barrier of the row loop)
-  real2 twk[EH];
-#pragma unroll
-  for (int q = 0; q < EH; ++q) {
-    const int k = tid + q * NT;
-    twk[q] = k <= M / 2 ? twW[k] : make_real2((real)0., (real)0.);
-  }
-  auto rowof = [&](int i, int& row, int& arr) {
-    const unsigned bx = (unsigned)(g.rev ? nwork - 1 - i : i);
-    row = (int)(bx >> 1); arr = (int)((bx ^ (bx >> 3)) & 1u);
-    if (skip_b_outside) {
-      if ((int)bx < 2 * g.H) row += g.sh;
-      else {
-        const int q = (int)bx - 2 * g.H;
-        row = q < g.sh ? q : q + g.H;
-        arr = 0;
-      }
-    }
-  };
-  auto issue = [&](int i) {
-    int row, arr;
-    rowof(i, row, arr);
-    const real2* in = (arr ? SB : SA) + pl * g.cplane + (long)row * g.cpitch;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-      const int e = 2 * (tid + r * NT);
-      if (e <= M) lpc_glds16(in + e, st + 2 * (r * NT + (tid - lane)), lane);
-    }
-  };
-  int i = (int)blockIdx.x;
-  if (i < nwork) issue(i);
-  for (; i < nwork; i += (int)gridDim.x) {
-    int row, arr;
-    rowof(i, row, arr);
-    lpc_glds_wait();
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < EH; ++q) {        // tangle_half_load, from the staging buffer
-      const int k = tid + q * NT;
-      if (k <= M / 2) {
-        real2 a = st[k], b = st[M - k];
-        if (k == 0) { a.y = (real)0.; b.y = (real)0.; }
-        const real2 e = make_real2(a.x + b.x, a.y - b.y);
-        const real2 d = make_real2(a.x - b.x, a.y + b.y);
-        const real2 od = cmul_conj(d, twk[q]);
-        s[lds_slot<SK>(k)] = make_real2(e.x - od.y, e.y + od.x);
-        if (k != 0 && k != M - k) s[lds_slot<SK>(M - k)] = make_real2(e.x + od.y, od.x - e.y);
-      }
-    }
-    __syncthreads();
-    if (i + (int)gridDim.x < nwork) issue(i + (int)gridDim.x);
-    real2* o2 = (real2*)((arr ? B : A) + pl * g.rplane + (long)row * g.rpitch);
-    auto out = [&](int ix, int, real2 v) { o2[ix] = v; };
-    sfft_stages_h<P, NT, true, SK>(s, h, tid, std::make_integer_sequence<int, P::nst - 1>{});
-    sfft_last_fused_h<P, NT, true, SK>(s, h, tid, out);
-  }
-}
-
 // ---- forward, generic: rows (2b, 2b+1) of ONE real source -> spectrum rows ------------
 struct RealSrc {
   const real* base;
@@ -597,12 +498,6 @@ __global__ __launch_bounds__(NT) void k_rinv_rows_half(PlaneGeom g, PL plan, con
 
 #ifndef LPC_MID_FUSE1
 #define LPC_MID_FUSE1 false  // measured: no gain on the fused middle (profiles/r01b_notes.md)
-#endif
-#ifndef LPC_SEQ_FUSE1
-#define LPC_SEQ_FUSE1 false  // sequential ADMM middle: first stage of the forward transforms fused into the tile loads
-#endif
-#ifndef LPC_SEQ_STEP3_BATCH
-#define LPC_SEQ_STEP3_BATCH 0
 #endif
 #ifndef LPC_MID_CONSTS_LATE
 #define LPC_MID_CONSTS_LATE 1
@@ -1114,7 +1009,7 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
 // only (SBT == cp.T).
 // SL = 1: the work spectra AND the copies of H / |G| passed in are in the pair-line layout (spec_col; T == 8): a tile's
 // rows (2p, 2p + 1) are one 128-byte line.
-template <int NT, int EMAX, class PL, int SBT, int MINW = 1, bool TWLDS = false, bool PRE = false, int SL = 0>
+template <int NT, int EMAX, class PL, int SBT, int MINW = 1, bool PRE = false, int SL = 0>
 __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL plan, ColPass cp, real2* LPC_RESTRICT SA,
                                                            real2* LPC_RESTRICT SB, const real2* LPC_RESTRICT Hs,
                                                            const real* LPC_RESTRICT Gabs, const real2* LPC_RESTRICT phr,
@@ -1185,7 +1080,7 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
     return cscale(x, (unsigned)(i - sh) >= (unsigned)hwin ? sb_k : (real)1.);   // one compare, one select, one product
   };
   // the twiddle table moves into LDS behind the tile (lpc_sfft.h twiddles_to_lds)
-  if (TWLDS) plan = twiddles_to_lds<NT>(plan, s + NELEM, tid);
+  plan = twiddles_to_lds<NT>(plan, s + NELEM, tid);
   real2 a[EM];
   {
     // PRE: both tiles' loads are issued up front, `a` first, r_sp right behind it: the transform of `a` then runs while

@@ -8,9 +8,6 @@
 #include "lpc_gd_kernels.h"
 #include "lpc_gd_v2_kernels.h"
 
-#ifndef LPC_MOD_MID_TWG
-#define LPC_MOD_MID_TWG 0
-#endif
 #ifndef LPC_MOD_MID_PRE
 #define LPC_MOD_MID_PRE 0
 #endif
@@ -35,10 +32,8 @@ typedef SPlan<LPC_MOD_ROW_RAD> RowP;
 #endif
 typedef SPlanArg<RowP, LPC_MOD_TW_LANE != 0> RowPA;
 static constexpr int RNT = LPC_MOD_ROW_NT, REM = LPC_MOD_ROW_EM;
-static constexpr int RSK = LPC_MOD_ROW_SK;       // LDS layout of the row tile: LPC_LAY_NONE / _SKEW8 / _XOR16 (lpc_fft.h)
+static constexpr int RSK = LPC_MOD_ROW_SK;       // LDS layout of the row tile: LPC_LAY_NONE / LPC_LAY_SKEW8 (lpc_fft.h)
 static_assert(RSK != LPC_LAY_SKEW8 || RowP::skew_ok(), "this row plan does not keep the LDS skew affine");
-static_assert(RSK != LPC_LAY_XOR16 || RowP::n % 16 == 0, "the xor layout permutes aligned blocks of 16 elements");
-static_assert(RSK != LPC_LAY_SKEW16 || RowP::n % 16 == 0, "the i + i/16 layout pads aligned blocks of 16 elements");
 static const size_t kRowSmem = LPC_ROW_SMEM_BYTES(RowP::n, RSK);
 #endif
 
@@ -66,20 +61,8 @@ static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outsi
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const int hrows = skip_hv_outside ? g.Hp + g.H : 2 * g.Hp;
-#ifndef LPC_DOUBLE
-  if constexpr (LdsTw<RowP>::ok(RNT)) {
-    if (e->opt.row_pf > 0) {      // persistent workgroups, the next row in flight (k_rinv_half_pf)
-      const size_t smem = ((kRowSmem + 15) / 16) * 16 + (size_t)(RowP::n + 8 + LdsTw<RowP>::size) * sizeof(real2);
-      const int total = e->opt.row_pf >= 16 ? e->opt.row_pf : e->opt.row_pf * rt::cu_count();   // (>= 16: workgroups, tuning)
-      const int gx = std::max(1, std::min(hrows, total / std::max(1, e->P)));
-      return launch_k(e, LPC_K_ROW_INV, k_rinv_half_pf<RNT, REM, RSK, RowPA>, dim3(gx, e->P), RNT, smem,
-                      geom_rev(e, e->opt.rev_rows & 2), row_arg(e), e->planW.tw, (const real2*)SA, (const real2*)SB, Vout,
-                      HVout, skip_hv_outside ? 1 : 0, hrows);
-    }
-  }
-#endif
   return launch_k(e, LPC_K_ROW_INV, k_rinv_half<RNT, REM, RSK, RowPA>, dim3(hrows, e->P), RNT, kRowSmem,
-                  geom_rev(e, e->opt.rev_rows & 2), row_arg(e),
+                  e->g, row_arg(e),
                   e->planW.tw, (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
 }
 #if LPC_MOD_ROW_X
@@ -89,7 +72,7 @@ static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc, const K1Rows* k1)
   real2* SA = e->S;
   real2* SB = e->S + (size_t)e->P * g.cplane;
   return launch_k(e, LPC_K_ROW_FWD, k_rfwd_half_x<RNT, REM, RSK, RowPA>, dim3(2 * g.Hp, e->P), RNT, kRowSmem,
-                  geom_rev(e, e->opt.rev_rows & 1), *sc,
+                  e->g, *sc,
                   row_arg(e), (const real2*)e->planW.tw, (const real*)e->Rsp, (const real*)e->HVb[e->hcur],
                   (const real*)e->HVb[e->hcur ^ 1], e->xi, (const real*)e->Y, SA, SB);
 }
@@ -108,21 +91,9 @@ static int m_gd_rows_mid(Engine* e) {
 #ifndef LPC_DOUBLE
   if constexpr (GdV2<RowP>::ok) {
     if (e->gd_v2)     // second form (lpc_gd_v2_kernels.h): one-radix plan, M / R lanes per row
-      return launch_k(e, LPC_K_ROW_INV, k_gd_resid_v2<GdV2<RowP>::NB, V2SK, RowPA>, dim3(g.H, e->P), GdV2<RowP>::NB, kV2Smem + (size_t)std::max(0, e->opt.lds_pad),
+      return launch_k(e, LPC_K_ROW_INV, k_gd_resid_v2<GdV2<RowP>::NB, V2SK, RowPA>, dim3(g.H, e->P), GdV2<RowP>::NB, kV2Smem,
                       geom_rev(e, e->opt.gd_rev & 1), row_arg(e), e->planW.tw, (const real2*)e->S, e->S2,
-                      (const real*)e->Y, make_fastdiv((unsigned)g.DC), make_fastdiv((unsigned)g.C),
-                      (5 << 16) | (e->opt.stagger < 0 ? 0 : e->opt.stagger));
-  }
-  if constexpr (LdsTw<RowP>::ok(RNT)) {
-    // persistent workgroups, the next row in flight (k_rinv_gd_mid_half_pf); 8-byte accesses to y need the pair geometry
-    if (e->opt.row_pf > 0 && ((g.sw | g.W | (g.Wp / 2)) & 1) == 0) {
-      const size_t smem = ((kRowSmem + 15) / 16) * 16 + (size_t)(RowP::n + 8 + LdsTw<RowP>::size) * sizeof(real2);
-      const int total = e->opt.row_pf >= 16 ? e->opt.row_pf : e->opt.row_pf * rt::cu_count();
-      const int gx = std::max(1, std::min(g.H, total / std::max(1, e->P)));
-      return launch_k(e, LPC_K_ROW_INV, k_rinv_gd_mid_half_pf<RNT, REM, RSK, RowPA>, dim3(gx, e->P), RNT, smem,
-                      geom_rev(e, e->opt.gd_rev & 1), row_arg(e), e->planW.tw, (const real2*)e->S, e->S2,
-                      (const real*)e->Y, g.H);
-    }
+                      (const real*)e->Y, make_fastdiv((unsigned)g.DC), make_fastdiv((unsigned)g.C));
   }
 #endif
   return launch_k(e, LPC_K_ROW_INV, k_rinv_gd_mid_half<RNT, REM, RSK, RowPA>, dim3(g.H, e->P), RNT, kRowSmem,
@@ -141,9 +112,9 @@ static int m_gd_rows_update_fwd(Engine* e, const GdScalars* sc, const real* alph
   if constexpr (GdV2<RowP>::ok) {
     if (e->gd_v2) {
       auto go = [&](auto kernel) {
-        return launch_k(e, LPC_K_SPATIAL, kernel, dim3(g.H, e->P), GdV2<RowP>::NB, kV2Smem + (size_t)std::max(0, e->opt.lds_pad), geom_rev(e, e->opt.gd_rev & 2),
+        return launch_k(e, LPC_K_SPATIAL, kernel, dim3(g.H, e->P), GdV2<RowP>::NB, kV2Smem, geom_rev(e, e->opt.gd_rev & 2),
                         row_arg(e), e->planW.tw, (const real2*)e->S2, e->S, e->gx, e->gaux, alpha, *sc,
-                        make_fastdiv((unsigned)g.C), (4 << 16) | (e->opt.stagger < 0 ? 0 : e->opt.stagger));
+                        make_fastdiv((unsigned)g.C));
       };
       constexpr int NB = GdV2<RowP>::NB;
       if (sc->kind == 2) return sc->first ? go(k_gd_update_fwd_v2<NB, V2SK, RowPA, 2, 1>) : go(k_gd_update_fwd_v2<NB, V2SK, RowPA, 2, 0>);
@@ -175,7 +146,7 @@ static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outsi
   real2* SB = e->S + (size_t)e->P * g.cplane;
   const int irows = paired_rows_grid(g, skip_hv_outside != 0);
   return launch_k(e, LPC_K_ROW_INV, k_rinv_arrays<RNT, REM, RSK, false, RowPA, LPC_MOD_SLAY>, dim3(irows, e->P), RNT, kRowSmem,
-                  geom_rev(e, e->opt.rev_rows & 2),
+                  e->g,
                   row_arg(e), (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
 }
 #if LPC_MOD_ROW_X
@@ -189,13 +160,13 @@ static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc, const K1Rows* k1)
   if (k1) {
     if constexpr (kK1Rows)
       return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA, true, LPC_MOD_SLAY>, dim3(xrows, e->P), RNT, kRowSmem,
-                      geom_rev(e, e->opt.rev_rows & 1), *sc,
+                      e->g, *sc,
                       row_arg(e), (const real*)e->Rsp, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1],
                       e->xi, (const real*)e->Y, SA, SB, *k1);
     return fail("internal: this module's rows do not hold the TV / W half");
   }
   return launch_k(e, LPC_K_ROW_FWD, k_rfwd_arrays_x<RNT, REM, RSK, RowPA, false, LPC_MOD_SLAY>, dim3(xrows, e->P), RNT, kRowSmem,
-                  geom_rev(e, e->opt.rev_rows & 1), *sc,
+                  e->g, *sc,
                   row_arg(e), (const real*)e->Rsp, (const real*)e->HVb[e->hcur], (const real*)e->HVb[e->hcur ^ 1],
                   e->xi, (const real*)e->Y, SA, SB, K1Rows{});
 }
@@ -229,9 +200,9 @@ static int m_admm_mid(Engine* e, const ColPass* cp, const AdmmScalars* sc, real 
   const MidPA pa = splan_arg<MidP>(e->planB);
   const real rscale = (real)1.0 / ((real)g.Hp * (real)g.Wp);
 #if LPC_MOD_MID_KIND == LPC_MID_SEQ     // single-pass columns, one spectrum at a time through T columns
-  constexpr bool TWL = LPC_MOD_MID_TWG == 0;     // the plan's twiddles in LDS behind the tile
-  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, TWL, LPC_MOD_MID_PRE != 0, LPC_MOD_SLAY>,
-                  dim3(cp->ntile_c * e->P), NT, (size_t)MidP::n * (T + (TWL ? 1 : 0)) * sizeof(real2), g, pa, *cp, SA, SB,
+  // (LDS: the tile + the plan's twiddle table behind it)
+  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, LPC_MOD_MID_PRE != 0, LPC_MOD_SLAY>,
+                  dim3(cp->ntile_c * e->P), NT, (size_t)MidP::n * (T + 1) * sizeof(real2), g, pa, *cp, SA, SB,
                   (const real2*)(LPC_MOD_SLAY ? e->Hs_t : e->Hs), (const real*)(LPC_MOD_SLAY ? e->Gabs_t : e->Gabs), (const real2*)e->phr, (const real2*)e->phc, sc->mu1,
                   sc->mu2, sc->mu3, rscale, sb_outside_scale);
 #else                                   // both spectra side by side: [N][2 T]

@@ -43,13 +43,12 @@ struct PlanSpec {
   int f64 = 0;
   int row_kind = LPC_ROWS_RUNTIME;
   StaticFft row;              // length Wp / 2 (half) or Wp (paired)
-  int row_sk = 0;             // LDS layout of the row tile: 0 natural, 1 i + i/8, 2 i ^ ((i >> 4) & 15)  (lpc_fft.h)
+  int row_sk = 0;             // LDS layout of the row tile: 0 natural, 1 i + i/8 (lpc_fft.h)
   int row_x = 0;              // ADMM: forward rows with the X half of the image-domain work
   StaticFft passA;            // pass A of a split column transform (T = 32 | 16 | narrower)
   int mid_kind = LPC_MID_RUNTIME;
   StaticFft mid;              // ADMM fused middle in LDS
   int mid_minw = 1;           // __launch_bounds__ second argument of the sequential middle
-  int mid_twg = 0;            // sequential middle: twiddles read from global memory instead of a copy in LDS behind the tile
   int mid_pre = 0;            // sequential middle: both tiles' loads issued before the first transform
   int slay = 0;               // ADMM work spectra in pair lines (lpc_kernels.h: spec_col): paired rows + 8-column sequential middle
   bool any() const { return row_kind != LPC_ROWS_RUNTIME || passA.n || mid_kind != LPC_MID_RUNTIME; }
@@ -64,9 +63,9 @@ static inline std::string fft_key(const StaticFft& f) {
 static inline std::string plan_spec_key(const PlanSpec& s) {
   std::string k = s.f64 ? "f64" : "f32";
   k += s.family == LPC_FAM_ADMM ? "_admm" : "_gd";
-  if (s.row_kind) k += std::string(s.row_kind == LPC_ROWS_HALF ? "_rh" : "_rp") + fft_key(s.row) + (s.row_sk == 1 ? "s" : (s.row_sk == 2 ? "z" : (s.row_sk == 3 ? "h" : ""))) + (s.row_x ? "x" : "");
+  if (s.row_kind) k += std::string(s.row_kind == LPC_ROWS_HALF ? "_rh" : "_rp") + fft_key(s.row) + (s.row_sk == 1 ? "s" : "") + (s.row_x ? "x" : "");
   if (s.passA.n) k += "_a" + fft_key(s.passA);
-  if (s.mid_kind) k += std::string(s.mid_kind == LPC_MID_PAIR ? "_mp" : "_ms") + fft_key(s.mid) + "m" + std::to_string(s.mid_minw) + (s.mid_twg ? "g" : "") + (s.mid_pre ? "p" : "") + (s.slay ? "L" : "");
+  if (s.mid_kind) k += std::string(s.mid_kind == LPC_MID_PAIR ? "_mp" : "_ms") + fft_key(s.mid) + "m" + std::to_string(s.mid_minw) + (s.mid_pre ? "p" : "") + (s.slay ? "L" : "");
   return k;
 }
 static inline std::string rad_list(const StaticFft& f) {
@@ -97,7 +96,6 @@ static inline std::vector<std::string> plan_spec_defines(const PlanSpec& s) {
     def("LPC_MOD_MID_RAD", rad_list(s.mid));
     defi("LPC_MOD_MID_NT", s.mid.nt); defi("LPC_MOD_MID_EM", s.mid.em); defi("LPC_MOD_MID_T", s.mid.T);
     defi("LPC_MOD_MID_MINW", s.mid_minw);
-    defi("LPC_MOD_MID_TWG", s.mid_twg);
     defi("LPC_MOD_MID_PRE", s.mid_pre);
   }
   defi("LPC_MOD_SLAY", s.slay);
@@ -106,70 +104,47 @@ static inline std::vector<std::string> plan_spec_defines(const PlanSpec& s) {
 
 // ---- options (lpc_config::options, "key=value,key=value"; include/lpc.h lists them) ---------------------------------
 struct EngineOpts {
+  // -- which kernels exist for a handle
   int no_static = 0;          // run-time plans everywhere: no plan module is looked for
-  int no_static_cols = 0;     // ... for the column passes only
   int jit = 1;                // compile a missing plan module at lpc_create (0: only modules already on disk)
   long jit_min_points = 1L << 16;   // padded frames smaller than this keep the run-time plans (launch-latency regime)
-  int rows_half = -1;         // -1: by size; 0: paired rows; 1: one real row per half-length transform (even widths)
-  int tile_budget = 0;        // LDS points per column tile (tests force the four-step split onto small frames)
-  int split_n2 = 0;           // force the length of the fused middle transform
-  int col_t = 0;              // image columns per column tile
-  int passa_t = 0;            // ... of pass A on a compile-time plan (32 | 16)
-  int mid_seq = -1;           // single-pass ADMM middle: -1 by batch size; 1 one spectrum at a time; 0 side by side
-  int mid_lds = 0;            // no register-resident middles
-  int prow_nt128 = -1;        // short paired rows on 128 threads: -1 by batch size
-  int rev_order = 9;          // bit 0 / 1 / 2 / 3: the tiled ADMM kernel / forward pass A / inverse pass A / the LDS middle walk
-                              // their grids BACKWARDS: a kernel that starts where its predecessor finished finds the last
-                              // ~256 MB that one wrote in the memory-side cache.  Default 9 (K1 and the middle; measured
-                              // same-box, profiles/r03_notes.md: C4 -3.3 %, C5 -2.5 %, C2 -1.5 %; all four: +1 %)
-  int rev_rows = 0;           // bit 0 / 1: ADMM forward / inverse rows (plan-module kernels) backwards (measured: no gain)
-  int gd_rev = -1;            // gradient-descent family / operator, backwards: bit 0 residual rows, 1 update rows, 2 the
-                              // register middle.  -1: the middle, when a work spectrum is larger than the memory-side
-                              // cache (12 MP FISTA 80.3 -> 75.5 ms per 40 iterations; 152-MB spectra: +1 %, off)
-  int seq_t = 0, mid_nt = 0;  // tuning: columns per tile of the sequential middle (4 | 8 | 16), lanes per middle workgroup
-  int g_plane = -1;           // ADMM middles read |PsiT Psi| from its plane (1) / as row + column terms when it separates (0);
-                              // -1: the terms when the plane is larger than 8 MB (it then misses the L2 once per colour plane)
-  int col_single = -1;        // ADMM (float32): the whole column transform in ONE launch -- whole columns in LDS, two image
-                              // columns per workgroup, one spectrum at a time (k_cols_mid_admm_seq) -- instead of pass A +
-                              // middle + inverse pass A, whenever a two-column tile of whole columns fits LDS.  -1: by size
-  int mid_twg = 0;            // sequential middle: twiddles from global memory (no LDS copy: more workgroups per CU)
-  int mid_minw = 0;           // sequential middle: waves per SIMD its register allocation must allow (tuning; 0: 4 at most)
-  int mid_pre = -1;           // sequential middle: load both tiles before the first transform (-1: default of the plan)
-  int seq_tiles_first = 0;    // sequential middle: workgroups handed out column tiles fastest instead of frames fastest
-  int seq_pair = 0;           // sequential middle, 64-byte tile rows: the two tiles of a cache line 8 blocks apart on one XCD (measured: no gain)
-  int mid_swz = -1;           // side-by-side LDS middle: pairs of column tiles on one XCD (ColPass::swz); -1: when a tile
-                              // row is narrower than a 128-byte line
-  int spec_lay = -1;          // ADMM work spectra of paired rows + 8-column sequential middle in pair lines (PlanSpec::slay); 0: rows
-  int hv_full = 0;            // every row of H V transformed in every iteration
-  int xi_full = 0;            // xi kept on the whole padded frame
-  int no_xhalf = 0;           // stand-alone image-domain kernel (no X half inside the forward rows)
-  int k1_rows = 1;            // TV / W half inside the paired forward rows where a row is one quad per lane (three launches per iteration)
-  int k1_group = 16;          // ... on launches of more than 8192 row blocks: runs of this many consecutive blocks per XCD (K1Rows::xcd_order)
-  int k1_half = 1;            // duals half-applied between the iterations of one call: the tiled kernel does not read V_old
-                              // (9R -> 8R); 0: plain duals in every iteration (round 3)
-  int k1_scalar = 0;          // ... in its scalar-lane form
-  int no_r2 = 0, no_skew = 0; // run-time row plans: no folded radix-2 stage / no LDS skew
-  int row_lay = -1;           // LDS layout of the compile-time row plans: -1 / 1 i + i/8 where that stays affine; 0 natural;
-                              // 2 the conflict-free xor layout (lengths that are multiples of 16; measured: no faster)
-  int gd_no_fuse_fwd = 0;     // gradient-descent update without the next iteration's forward rows
-  int gd_v2 = 1;              // gradient-descent family, half-length rows on a one-radix plan (4096 = 16.16.16, 512 = 8.8.8) and
-                              // even window offset / width: the fused row kernels of lpc_gd_v2_kernels.h (0: the first form)
-  int stagger = -1;           // sleep units (2048 cycles) between the start times of the workgroups of a launch's first
-                              // generation that share a CU (lpc_kernels.h: lpc_stagger); -1: the kernel's default, 0: off
-  int lds_pad = 0;            // tuning: bytes of LDS a fused gradient-descent row workgroup claims beyond its tile (fewer workgroups
-                              // per CU: the last, partly filled generation of a launch is shorter)
-  int rpitch_pad = 0;         // floats added to the pitch of the padded real planes (tuning: a pitch of 2^k bytes puts the same
-                              // column of every row on the same HBM channel)
-  int row_pf = 0;             // ADMM inverse rows (half-length, float32, radices 8 / 16): persistent workgroups, N per CU, with
-                              // the next row in flight by LDS-DMA (k_rinv_half_pf); 0: one workgroup per row
-  int row_nt = 0;             // threads per row workgroup of the compile-time row plan (tuning; multiple of 64)
-  std::string row_rad, passa_rad, mid_rad;   // "16.16.8": radices of the compile-time row / pass-A / LDS-middle plan
-                              // instead of the chooser's (an experiment costs one module: ~3 s); ignored unless the
-                              // product is the transform length and every radix has a butterfly
   std::string module_dir;     // where plan modules are looked for and written first (default: <libdir>/modules)
   std::string compiler;       // hipcc to compile a missing module with (default: $ROCM_PATH/bin/hipcc, /opt/rocm/bin/hipcc)
   int module_max = 256;       // module files kept in a directory this library writes to (least recently used go first)
   int module_loaded_max = 64; // modules kept dlopen()ed by a process once no handle uses them
+  // -- forcing a plan the chooser takes for other sizes (tests run every kernel family on small frames with these;
+  //    every setting gives valid results)
+  int rows_half = -1;         // -1: by size; 0: paired rows; 1: one real row per half-length transform (even widths)
+  int tile_budget = 0;        // LDS points per column tile (forces the four-step split / 8-column tiles onto small frames)
+  int split_n2 = 0;           // length of the fused middle transform of a split column pass
+  int col_t = 0;              // image columns per column tile
+  int passa_t = 0;            // ... of pass A on a compile-time plan (32 | 16)
+  int mid_seq = -1;           // single-pass ADMM middle: -1 by batch size; 1 one spectrum at a time; 0 side by side
+  int mid_pre = -1;           // ... one spectrum at a time: 0 the second tile's loads behind the first transform (-1 / 1: up front)
+  int prow_nt128 = -1;        // short paired rows on 128 threads: -1 by batch size
+  int g_plane = -1;           // ADMM middles read |PsiT Psi| from its plane (1) / as row + column terms when it separates (0);
+                              // -1: the terms when the plane is larger than 8 MB (it then misses the L2 once per colour plane)
+  int mid_swz = -1;           // side-by-side LDS middle: pairs of half-line column tiles on one XCD (ColPass::swz); -1: when a
+                              // tile row is narrower than a 128-byte line and the spectra are not in pair lines
+  int spec_lay = -1;          // ADMM work spectra of paired rows + 8-column middles in pair lines (PlanSpec::slay); 0: rows
+  std::string row_rad;        // "16.16.8": radices of the compile-time row plan instead of the chooser's (one module, ~3 s);
+                              // ignored unless the product is the row length and every radix has a butterfly
+  // -- the structure of an ADMM iteration (each 0 / 1 is an older, complete form of the same arithmetic)
+  int hv_full = 0;            // every row of H V transformed in every iteration
+  int xi_full = 0;            // xi kept on the whole padded frame
+  int k1_rows = 1;            // TV / W half inside the paired forward rows where a row is one quad per lane (three launches)
+  int k1_group = 16;          // ... on launches of more than 8192 row blocks: runs of this many consecutive blocks per XCD
+                              // (K1Rows::xcd_order; 0: launch order)
+  int k1_half = 1;            // duals half-applied between the iterations of one call: the tiled kernel does not read V_old
+  // -- block orders (permutations: results unchanged)
+  int rev_order = 9;          // bit 0 / 1 / 2 / 3: the tiled ADMM kernel / forward pass A / inverse pass A / the LDS middle walk
+                              // their grids BACKWARDS: a kernel that starts where its predecessor finished finds the last
+                              // ~256 MB that one wrote in the memory-side cache (C4 -3.3 %, C5 -2.5 %, C2 -1.5 %)
+  int gd_rev = -1;            // gradient-descent family / operator, backwards: bit 0 residual rows, 1 update rows, 2 the
+                              // register middle.  -1: all three when a work spectrum is larger than the memory-side cache
+  // -- gradient-descent family
+  int gd_no_fuse_fwd = 0;     // update without the next iteration's forward rows
+  int gd_v2 = 1;              // half-length rows on a one-radix plan: the fused row kernels of lpc_gd_v2_kernels.h (0: first form)
 };
 
 // path-valued options (module_dir, compiler) may contain the separators below as %XX escapes ("%2C" = ','; "%25" = '%')
@@ -200,55 +175,33 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       const std::string k = tok.substr(0, eq), v = eq == std::string::npos ? "1" : tok.substr(eq + 1);
       const long iv = std::atol(v.c_str());
       if (k == "no_static") o.no_static = (int)iv;
-      else if (k == "no_static_cols") o.no_static_cols = (int)iv;
       else if (k == "jit") o.jit = (int)iv;
       else if (k == "jit_min_points") o.jit_min_points = iv;
+      else if (k == "module_dir") o.module_dir = unescape_opt_path(v);
+      else if (k == "compiler") o.compiler = unescape_opt_path(v);
+      else if (k == "module_max") o.module_max = (int)iv;
+      else if (k == "module_loaded_max") o.module_loaded_max = (int)iv;
       else if (k == "rows_half") o.rows_half = (int)iv;
       else if (k == "tile_budget") o.tile_budget = (int)iv;
       else if (k == "split_n2") o.split_n2 = (int)iv;
       else if (k == "col_t") o.col_t = (int)iv;
       else if (k == "passa_t") o.passa_t = (int)iv;
       else if (k == "mid_seq") o.mid_seq = (int)iv;
-      else if (k == "mid_lds") o.mid_lds = (int)iv;
-      else if (k == "prow_nt128") o.prow_nt128 = (int)iv;
-      else if (k == "rev_order") o.rev_order = (int)iv;
-      else if (k == "rev_rows") o.rev_rows = (int)iv;
-      else if (k == "gd_rev") o.gd_rev = (int)iv;
-      else if (k == "seq_t") o.seq_t = (int)iv;
-      else if (k == "mid_nt") o.mid_nt = (int)iv;
-      else if (k == "seq_tiles_first") o.seq_tiles_first = (int)iv;
-      else if (k == "seq_pair") o.seq_pair = (int)iv;
-      else if (k == "col_single") o.col_single = (int)iv;
-      else if (k == "mid_twg") o.mid_twg = (int)iv;
       else if (k == "mid_pre") o.mid_pre = (int)iv;
-      else if (k == "mid_minw") o.mid_minw = (int)iv;
+      else if (k == "prow_nt128") o.prow_nt128 = (int)iv;
       else if (k == "g_plane") o.g_plane = (int)iv;
       else if (k == "mid_swz") o.mid_swz = (int)iv;
       else if (k == "spec_lay") o.spec_lay = (int)iv;
+      else if (k == "row_rad") o.row_rad = v;
       else if (k == "hv_full") o.hv_full = (int)iv;
       else if (k == "xi_full") o.xi_full = (int)iv;
-      else if (k == "no_xhalf") o.no_xhalf = (int)iv;
-      else if (k == "k1_half") o.k1_half = (int)iv;
       else if (k == "k1_rows") o.k1_rows = (int)iv;
       else if (k == "k1_group") o.k1_group = (int)iv;
-      else if (k == "k1_scalar") o.k1_scalar = (int)iv;
-      else if (k == "no_r2") o.no_r2 = (int)iv;
-      else if (k == "no_skew") o.no_skew = (int)iv;
-      else if (k == "row_lay") o.row_lay = (int)iv;
+      else if (k == "k1_half") o.k1_half = (int)iv;
+      else if (k == "rev_order") o.rev_order = (int)iv;
+      else if (k == "gd_rev") o.gd_rev = (int)iv;
       else if (k == "gd_no_fuse_fwd") o.gd_no_fuse_fwd = (int)iv;
       else if (k == "gd_v2") o.gd_v2 = (int)iv;
-      else if (k == "stagger") o.stagger = (int)iv;
-      else if (k == "lds_pad") o.lds_pad = (int)iv;
-      else if (k == "row_nt") o.row_nt = (int)iv;
-      else if (k == "row_pf") o.row_pf = (int)iv;
-      else if (k == "rpitch_pad") o.rpitch_pad = (int)iv;
-      else if (k == "row_rad") o.row_rad = v;
-      else if (k == "passa_rad") o.passa_rad = v;
-      else if (k == "mid_rad") o.mid_rad = v;
-      else if (k == "module_dir") o.module_dir = unescape_opt_path(v);
-      else if (k == "compiler") o.compiler = unescape_opt_path(v);
-      else if (k == "module_max") o.module_max = (int)iv;
-      else if (k == "module_loaded_max") o.module_loaded_max = (int)iv;
       else return "unknown engine option '" + k + "'";
     }
     i = j + 1;

@@ -54,18 +54,12 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
 #define __syncthreads() lpc_emu::barrier()
 #define LPC_DYN_SMEM(name) char* name = lpc_emu::ctx().smem
 #define LPC_TID(nt) ((int)threadIdx.x)
-// LDS-DMA (see the HIP branch): the emulator copies the lane's 16 bytes itself
-static inline void lpc_glds16(const void* gsrc, void* lds_wave_base, int lane) {
-  std::memcpy((char*)lds_wave_base + 16 * lane, gsrc, 16);
-}
-static inline void lpc_glds_wait() {}
 static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a * (uint64_t)b) >> 32); }
 // range-checked row accesses (see the HIP branch): the emulator checks the range itself
 struct lpc_rsrc { char* base; unsigned bytes; };
 static inline lpc_rsrc lpc_make_rsrc(const void* base, unsigned bytes) { lpc_rsrc r; r.base = (char*)base; r.bytes = bytes; return r; }
 static inline int lpc_opaque(int x) { return x; }
 #define LPC_SCHED_FENCE() ((void)0)
-static inline void lpc_sleep_units(int) {}
 
 typedef void* lpcStream_t;
 typedef int lpcError_t;
@@ -148,22 +142,6 @@ static __device__ __forceinline__ void lpc_sync_stamped() { __syncthreads(); lpc
 #define LPC_STAMP_END() lpc_stamp_end()
 #endif
 
-// LDS-DMA: every active lane of the wave copies 16 bytes from ITS global address `gsrc` to LDS at the WAVE-UNIFORM byte
-// address of `lds_wave_base` + 16 * lane (global_load_lds_dwordx4: no VGPR destination, counted by vmcnt).  Written as
-// inline assembly so that the compiler does not know about the pending LDS write: a `__syncthreads()` then stays a bare
-// s_barrier and the copy stays in flight across the barriers of the transform that runs meanwhile (with the builtin the
-// fence of every barrier would drain it).  The price: the data is ordered for a reader only by lpc_glds_wait() in the
-// ISSUING wave followed by a barrier the reader has passed.  M0 (the LDS base) is saved and restored in the statement.
-// No "memory" clobber: loop-invariant table loads may move across it; the barriers around it order the LDS accesses.
-static __device__ __forceinline__ void lpc_glds16(const void* gsrc, void* lds_wave_base, int /*lane*/) {
-  const unsigned dst = __builtin_amdgcn_readfirstlane(
-      (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds_wave_base);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(gsrc), "s"(dst));
-}
-static __device__ __forceinline__ void lpc_glds_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // Range-checked accesses to one row of an un-padded plane ("pad on load, crop on store" done by the address unit): a raw
 // buffer resource over the row's bytes; a load whose byte offset (unsigned: a negative column is a huge offset) lies
 // outside it returns zero, a store outside it is dropped -- no clamped addresses, no selects, no branches, and one 32-bit
@@ -177,10 +155,6 @@ static __device__ __forceinline__ lpc_rsrc lpc_make_rsrc(const void* base, unsig
 static __device__ __forceinline__ int lpc_opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 // nothing is scheduled across this point (keeps a batch of loads behind the arithmetic whose registers it needs)
 #define LPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
-// the wave sleeps n x 2048 cycles (s_sleep 32, n times; about 0.9 us each at 2.3 GHz) -- see lpc_stagger()
-static __device__ __forceinline__ void lpc_sleep_units(int n) {
-  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(32);
-}
 typedef hipStream_t lpcStream_t;
 typedef hipError_t lpcError_t;
 #define lpcSuccess hipSuccess

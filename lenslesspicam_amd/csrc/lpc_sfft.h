@@ -201,9 +201,6 @@ static __device__ __forceinline__ void sfft_first_fused(real2* s, int tid, Src& 
       if (SKEW == LPC_LAY_SKEW8) {
 #pragma unroll
         for (int m = 0; m < R; ++m) s[ob + m + (m >> 3)] = v[b][m];
-      } else if (SKEW == LPC_LAY_XOR16 || SKEW == LPC_LAY_SKEW16) {
-#pragma unroll
-        for (int m = 0; m < R; ++m) s[lds_slot<SKEW>(j * R * BT + c + m * BT)] = v[b][m];
       } else {
 #pragma unroll
         for (int m = 0; m < R; ++m) s[ob + m * BT] = v[b][m];
@@ -247,124 +244,6 @@ static __device__ __forceinline__ void sfft_last_fused(real2* s, const real2* LP
 #pragma unroll
       for (int m = 0; m < R; ++m) dst(oi + m * NS, c, v[b][m]);
     }
-  }
-}
-
-// ---- stages whose twiddles come from a table in LDS (persistent row kernels) ------------------------------------------
-// A workgroup that walks many rows while an LDS-DMA copy is in flight must not touch the twiddle table in global memory
-// inside the row loop: vmcnt retires in order, so the wait for a table entry would also wait for the (older) copy.
-// twiddle_mul<R> of a radix-8 / -16 stage loads w, w^2, w^4 (, w^8) and forms the other powers by products; LdsTw holds
-// exactly those base entries of every stage -- 4 x ns(st) values, [power][k] -- copied once per workgroup; apply() is
-// the arithmetic of twiddle_mul on them, so such a stage gives bit-identical results.  One butterfly per lane and stage
-// (N / R <= NT), radices 8 and 16 only.
-template <class P>
-struct LdsTw {
-  const real2* t;     // LDS
-  static constexpr int off(int st) {
-    int o = 0;
-    for (int i = 1; i < st; ++i) o += 4 * P::ns(i);
-    return o;
-  }
-  static constexpr int size = off(P::nst);      // real2 entries
-  template <int NT>
-  __device__ __forceinline__ void fill(real2* dst, const real2* LPC_RESTRICT tw, int tid) {
-#pragma unroll
-    for (int st = 1; st < P::nst; ++st) {
-      const int NS = P::ns(st), STEP = P::n / (NS * P::radix(st));
-      for (int e = tid; e < 4 * NS; e += NT) {
-        const int i = e / NS, k = e % NS;
-        dst[off(st) + e] = (i < 3 || P::radix(st) == 16) ? tw[(k * STEP) << i] : make_real2((real)1., (real)0.);
-      }
-    }
-    t = dst;
-  }
-  template <int R, bool INV, int ST>
-  __device__ __forceinline__ void apply(real2* v, int k) const {
-    constexpr int NS = P::ns(ST);
-    const real2* b = t + off(ST) + k;
-    real2 x[16];
-    x[1] = b[0]; x[2] = b[NS]; x[4] = b[2 * NS];
-    if (R == 16) x[8] = b[3 * NS];
-    x[3] = cmul(x[1], x[2]); x[5] = cmul(x[1], x[4]); x[6] = cmul(x[2], x[4]); x[7] = cmul(x[3], x[4]);
-    if (R == 16) {
-#pragma unroll
-      for (int m = 9; m < 16; ++m) x[m] = cmul(x[m - 8], x[8]);
-    }
-#pragma unroll
-    for (int m = 1; m < R; ++m) v[m] = INV ? cmul_conj(v[m], x[m]) : cmul(v[m], x[m]);
-  }
-  static constexpr bool ok(int nt) {
-    for (int st = 0; st < P::nst; ++st)
-      if ((P::radix(st) != 8 && P::radix(st) != 16) || P::n / P::radix(st) > nt) return false;
-    return true;
-  }
-};
-
-template <class P, int ST, int NT, bool INV, int SKEW>
-static __device__ __forceinline__ void sfft_stage_h(real2* s, const LdsTw<P>& h, int tid) {
-  constexpr int R = P::radix(ST), N = P::n, NS = P::ns(ST);
-  constexpr int NB = N / R;
-  constexpr bool GUARD = NB < NT;
-  constexpr int IST = NB, OST = NS;
-  constexpr int RS = lds_stride<SKEW>(IST), WS = lds_stride<SKEW>(OST);
-  constexpr bool RAFF = lds_affine<SKEW>(IST), WAFF = lds_affine<SKEW>(OST);
-  static_assert(NB <= NT, "LDS-twiddle stages: one butterfly per lane");
-  real2 v[R];
-  int obase = -1;
-  if (!GUARD || tid < NB) {
-    const int jq = tid / NS, k = tid % NS;
-    const int rb = lds_slot<SKEW>(tid);
-#pragma unroll
-    for (int m = 0; m < R; ++m) v[m] = RAFF ? s[rb + m * RS] : s[lds_slot<SKEW>(tid + m * IST)];
-    if (NS > 1) h.template apply<R, INV, ST>(v, k);
-    Dft<R, INV>::run(v);
-    const int oi = jq * NS * R + k;
-    obase = (WAFF || SKEW == LPC_LAY_SKEW8) ? lds_slot<SKEW>(oi) : oi;
-  }
-  __syncthreads();
-  if (!GUARD || obase >= 0) {
-    if (SKEW == LPC_LAY_SKEW8 && NS == 1) {
-#pragma unroll
-      for (int m = 0; m < R; ++m) s[obase + m + (m >> 3)] = v[m];
-    } else if (WAFF || SKEW == LPC_LAY_SKEW8) {
-#pragma unroll
-      for (int m = 0; m < R; ++m) s[obase + m * WS] = v[m];
-    } else {
-#pragma unroll
-      for (int m = 0; m < R; ++m) s[lds_slot<SKEW>(obase + m * OST)] = v[m];
-    }
-  }
-  __syncthreads();
-}
-template <class P, int NT, bool INV, int SKEW, int... I>
-static __device__ __forceinline__ void sfft_stages_h(real2* s, const LdsTw<P>& h, int tid, std::integer_sequence<int, I...>) {
-  (sfft_stage_h<P, I, NT, INV, SKEW>(s, h, tid), ...);
-}
-// stages 1 .. (behind a first stage the caller ran itself)
-template <class P, int NT, bool INV, int SKEW, int... I>
-static __device__ __forceinline__ void sfft_stages_h1(real2* s, const LdsTw<P>& h, int tid, std::integer_sequence<int, I...>) {
-  (sfft_stage_h<P, 1 + I, NT, INV, SKEW>(s, h, tid), ...);
-}
-// last stage into the drain, twiddles from LDS
-template <class P, int NT, bool INV, int SKEW, class Dst>
-static __device__ __forceinline__ void sfft_last_fused_h(real2* s, const LdsTw<P>& h, int tid, Dst& dst) {
-  constexpr int ST = P::nst - 1;
-  constexpr int R = P::radix(ST), N = P::n, NS = P::ns(ST);
-  constexpr int NB = N / R;
-  constexpr bool GUARD = NB < NT;
-  constexpr int IST = NB, RS = lds_stride<SKEW>(IST);
-  constexpr bool RAFF = lds_affine<SKEW>(IST);
-  if (!GUARD || tid < NB) {
-    real2 v[R];
-    const int rb = lds_slot<SKEW>(tid);
-#pragma unroll
-    for (int m = 0; m < R; ++m) v[m] = RAFF ? s[rb + m * RS] : s[lds_slot<SKEW>(tid + m * IST)];
-    const int jq = tid / NS, k = tid % NS;
-    if (NS > 1) h.template apply<R, INV, ST>(v, k);
-    Dft<R, INV>::run(v);
-    const int oi = jq * NS * R + k;
-#pragma unroll
-    for (int m = 0; m < R; ++m) dst(oi + m * NS, 0, v[m]);
   }
 }
 

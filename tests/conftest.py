@@ -20,8 +20,7 @@ EMU_LIB_F64 = os.path.join(EMU_BUILD, "liblpc_emu_f64.so")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
-    config.addinivalue_line("markers", "gpu_long: opt-in anchors that need a MI355X AND > 60 s of CPU oracle each (-m gpu_long; the "
-                                       "driver's -m gpu step does not select them; last run recorded under profiles/)")
+
 
 
 def _emu_sources():

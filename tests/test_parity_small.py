@@ -601,19 +601,21 @@ def test_window_structure_with_a_per_iteration_schedule(backend, monkeypatch):
 
 
 def test_c4_sequential_middle_on_one_frame(backend, monkeypatch):
-    """C4's fused ADMM middle takes the two spectra one after the other through one column tile
-    (k_cols_mid_admm_seq: 8 columns on 256 lanes by default, 16 on 512 with seq_t=16); the engine selects it for large
-    batches only, the option mid_seq=1 forces it onto one DiffuserCam-sized frame so that the CPU suite executes it.
-    Batches must equal single-frame runs either way."""
+    """C4's fused ADMM middle takes the two spectra one after the other through one tile of 8 image columns
+    (k_cols_mid_admm_seq, 512 lanes); the engine selects it for large batches only, the option mid_seq=1 forces it onto one
+    DiffuserCam-sized frame so that the CPU suite executes it -- with the work spectra in pair lines (the default) and in
+    plain rows (spec_lay=0), and with the second tile's loads behind the first transform (mid_pre=0)."""
     psf = orc.synthetic_psf(1, 270, 480, 1, seed=1)
     engine_opts(monkeypatch, mid_seq=1)
     _admm_fista_vs_oracle(270, 480, 1, (540, 960), n_admm=2, n_fista=1)
     info = lpa.ADMM(torch.from_numpy(psf))._handle.plan_info()
-    assert "one spectrum at a time" in info and "T = 8" in info, info
-    engine_opts(monkeypatch, seq_t=16)
-    _admm_fista_vs_oracle(270, 480, 1, (540, 960), n_admm=2, n_fista=0)
+    assert "one spectrum at a time, pair-line spectra" in info and "T = 8" in info, info
+    for extra in ({"spec_lay": 0}, {"mid_pre": 0}):
+        engine_opts(monkeypatch, mid_seq=1, **extra)
+        _admm_fista_vs_oracle(270, 480, 1, (540, 960), n_admm=2, n_fista=0)
+    engine_opts(monkeypatch, mid_seq=1, spec_lay=0)
     info = lpa.ADMM(torch.from_numpy(psf))._handle.plan_info()
-    assert "one spectrum at a time" in info and "T = 16" in info, info
+    assert "one spectrum at a time]" in info, info
 
 
 def test_c4_sequential_middle_frames_fastest_block_order(backend):
@@ -634,26 +636,52 @@ def test_c4_sequential_middle_frames_fastest_block_order(backend):
         assert torch.equal(single.apply(n_iter=2, disp_iter=None), got[b]), b
 
 
-def test_c4_sequential_middle_half_line_pairs_block_order(backend):
-    """Batches whose frame count is a multiple of 8: the two 64-byte-row tiles that share every cache line of a frame are
-    handed out 8 blocks apart on one XCD (k_cols_mid_admm_seq, tiles_first == 3; option seq_pair=0 restores the
-    frames-fastest order), with both tiles' loads issued up front (mid_pre=1, the default of large batches).  8 gray
-    frames x 2 depth planes x 61 column tiles (odd: the last tile of every plane is handed out on its own) -- bit for bit
-    the frames-fastest order's result, and a single-frame run's."""
-    rng = np.random.default_rng(32)
-    psf = torch.from_numpy(orc.synthetic_psf(2, 270, 480, 1, seed=2))
-    ys = torch.from_numpy(rng.random((8, 1, 270, 480, 1), dtype=np.float32))
+def test_pair_line_spectra_odd_window_and_odd_height(backend):
+    """Pair-line work spectra (lpc_kernels.h: spec_col -- rows (2p, 2p + 1) x 8 columns of a half spectrum share one
+    128-byte line; paired rows + a single-pass middle of 8-column tiles): the window's row pairs are aligned to even rows,
+    so a window that starts on an ODD row (270 x 480: sh = 135; 23 x 40: sh = 11) gets a first and a last pair with one
+    row that is neither formed nor stored, and an odd padded height (45) a last pair of one row.  Long enough calls to run
+    the steady state (a on the window's rows only, H V rows skipped outside it); against the float64 oracle, against the
+    plain layout, and -- a batch -- against its single frames bit for bit.  Both middles: one spectrum at a time and side
+    by side."""
+    rng = np.random.default_rng(61)
+    for (H, W, C, B), opts in (((23, 40, 1, 1), {"mid_seq": 1, "tile_budget": 720}), ((23, 40, 3, 2), {"mid_seq": 0, "tile_budget": 720}),
+                               ((24, 40, 3, 2), {"mid_seq": 1, "tile_budget": 768}), ((270, 480, 1, 1), {})):
+        psf = orc.synthetic_psf(1, H, W, C, seed=3)
+        ys = rng.random((B, 1, H, W, C), dtype=np.float32)
+        outs = {}
+        for lay in (1, 0):
+            rec = lpa.ADMM(torch.from_numpy(psf).to(backend.device), tau=2e-6, mu2=1e-4,
+                           engine_options={"jit_min_points": 0, "spec_lay": lay, **opts})
+            info = rec._handle.plan_info()
+            assert ("pair-line spectra" in info) == bool(lay) and "row transforms skipped" in info, info
+            rec.set_data(torch.from_numpy(ys).to(backend.device))
+            outs[lay] = rec.apply_batch(n_iter=9)
+            if lay and B > 1:
+                for b in range(B):
+                    rec.set_data(torch.from_numpy(ys[b, 0]).to(backend.device))
+                    assert torch.equal(rec.apply(n_iter=9, disp_iter=None), outs[1][b]), (H, W, b)
+        o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
+        o.set_data(ys[0, 0])
+        assert rel(outs[1][0], o.apply(9)) <= 5e-6 and rel(outs[1], outs[0]) <= 2e-6, (H, W)
+
+
+def test_xcd_runs_of_the_fused_forward_rows_change_nothing(backend, monkeypatch):
+    """K1Rows::xcd_order: launches of more than 8192 row blocks hand the blocks of the fused forward rows out in runs of
+    k1_group consecutive blocks per XCD (the stencil's neighbour rows then come from that XCD's L2), smaller ones an eighth
+    of the launch per XCD -- permutations of the block order: every setting must give the launch order's result bit for
+    bit.  16 gray frames of 270 x 480: 8640 row blocks by the host's count (6496 launched once the rows outside the sensor
+    window are skipped: not a multiple of either run length, the tail keeps launch order)."""
+    rng = np.random.default_rng(62)
+    psf = torch.from_numpy(orc.synthetic_psf(1, 270, 480, 1, seed=2)).to(backend.device)
+    ys = torch.from_numpy(rng.random((16, 1, 270, 480, 1), dtype=np.float32)).to(backend.device)
     outs = []
-    for extra in ({"mid_pre": 1}, {"seq_pair": 0, "mid_pre": 0}):
-        rec = lpa.ADMM(psf, engine_options={"mid_seq": 1, "prow_nt128": 1, "jit_min_points": 0, **extra})
+    for grp in (0, 16, 5):
+        rec = lpa.ADMM(psf, tau=2e-6, mu2=1e-4, engine_options={"k1_group": grp})
+        assert "three launches per iteration" in rec._handle.plan_info()
         rec.set_data(ys)
-        assert "one spectrum at a time" in rec._handle.plan_info()
-        outs.append(rec.apply_batch(n_iter=2))
-    assert torch.equal(outs[0], outs[1])
-    single = lpa.ADMM(psf, engine_options={"mid_seq": 1, "prow_nt128": 1, "jit_min_points": 0})
-    for b in (0, 5, 7):
-        single.set_data(ys[b, 0])
-        assert torch.equal(single.apply(n_iter=2, disp_iter=None), outs[0][b]), b
+        outs.append(rec.apply_batch(n_iter=3))
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
 
 
 def test_middle_tile_pairs_on_one_xcd(backend):
@@ -870,123 +898,6 @@ def test_gram_as_row_and_column_terms(backend, monkeypatch):
     assert "gram as row + column terms" not in rec._handle.plan_info()
 
 
-@pytest.mark.parametrize("lay", [0, 2], ids=["natural", "xor16"])
-@pytest.mark.parametrize("half", [0, 1], ids=["paired", "half_rows"])
-def test_row_tile_lds_layouts(backend, monkeypatch, lay, half):
-    """option row_lay: the LDS layout of the compile-time row plans (lpc_fft.h: lds_slot) -- natural, and the
-    conflict-free xor layout i ^ ((i >> 4) & 15) (the default is i + i/8).  Same golden trajectories on each: ADMM with
-    the X half in the forward rows (64- and 32-point row transforms), FISTA's residual / update rows, the operator."""
-    engine_opts(monkeypatch, row_lay=lay, rows_half=half, jit_min_points=0)
-    test_admm_matches_reference_golden(backend, "admm_24x32x3_tv")
-    test_gd_family_matches_reference_golden(backend, "fista_24x32x3")
-    test_convolver_golden(backend, "a")
-    psf = np.load(os.path.join(GOLDEN, "admm_24x32x3_tv.npz"))["psf"]
-    info = lpa.ADMM(torch.from_numpy(psf).to(backend.device))._handle.plan_info()
-    key = info.split("plan module ")[1]
-    assert ("z" if lay == 2 else "") + "x" in key.split("_")[2] and "s" not in key.split("_")[2].split("w")[1], key
-
-
-@pytest.mark.parametrize("shape,rad", [((20, 64, 3), "8.8"), ((9, 256, 1), "16.16")])
-def test_row_tile_layout_one_pad_per_16(backend, monkeypatch, shape, rad):
-    """option row_lay=3: i + i/16 (plans whose radices are all 8 or 16; lpc_fft.h) on ADMM's half-length row kernels --
-    forward rows with the X half, inverse rows, sensor-window structure -- against the float64 oracle."""
-    H, W, C = shape
-    rng = np.random.default_rng(W)
-    psf = orc.synthetic_psf(1, H, W, C, seed=3)
-    y = rng.random((H, W, C), dtype=np.float32)
-    engine_opts(monkeypatch, rows_half=1, row_rad=rad, row_lay=3, jit_min_points=0)
-    rec = lpa.ADMM(torch.from_numpy(psf).to(backend.device), tau=2e-6, mu2=1e-4)
-    info = rec._handle.plan_info()
-    assert "half-length %d [static %s" % (rec._padded_shape[2] // 2, rad) in info, info
-    assert info.split("plan module ")[1].split("_")[2].split("x")[1].startswith(("8h", "16h")) or "hx" in info, info
-    rec.set_data(torch.from_numpy(y).to(backend.device))
-    o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
-    o.set_data(y)
-    assert rel(rec.apply(n_iter=7, disp_iter=None), o.apply(7)) <= 5e-6, info
-
-
-@pytest.mark.parametrize("shape,seq_t", [((270, 20, 1), 2), ((270, 20, 3), 1), ((300, 36, 1), 4)])
-def test_single_launch_columns(backend, monkeypatch, shape, seq_t):
-    """option col_single=1: the whole column transform of the ADMM step in one launch -- the sequential middle
-    (k_cols_mid_admm_seq) over WHOLE columns, seq_t image columns per workgroup, instead of pass A + middle + inverse pass
-    A (what 12 MP would run: 6144-row columns two at a time; here 540- / 600-row columns, the smallest heights that take
-    the mode).  Sensor-window structure included (rows of SB outside the window rescaled by the middle)."""
-    engine_opts(monkeypatch, col_single=1, jit_min_points=0, seq_t=seq_t)
-    H, W, C = shape
-    rng = np.random.default_rng(H + W)
-    psf = orc.synthetic_psf(1, H, W, C, seed=4)
-    y = rng.random((H, W, C), dtype=np.float32)
-    rec = lpa.ADMM(torch.from_numpy(psf).to(backend.device), tau=2e-6, mu2=1e-4)
-    info = rec._handle.plan_info()
-    assert f"single pass {rec._padded_shape[1]}, T = {seq_t}" in info and "one spectrum at a time" in info, info
-    assert "row transforms skipped" in info, info
-    rec.set_data(torch.from_numpy(y).to(backend.device))
-    o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
-    o.set_data(y)
-    assert rel(rec.apply(n_iter=8, disp_iter=None), o.apply(8)) <= 5e-6, info
-
-
-@pytest.mark.parametrize("shape,rad", [((20, 64, 3), "8.8"), ((12, 128, 1), "16.8"), ((9, 256, 3), "16.16")])
-def test_prefetching_inverse_rows(backend, monkeypatch, shape, rad):
-    """option row_pf: ADMM's inverse rows as persistent workgroups with the next half-spectrum row in flight by LDS-DMA
-    and the stage twiddles in LDS (k_rinv_half_pf).  Same arithmetic in the same order as k_rinv_half: the result is
-    BIT-identical to the one-workgroup-per-row kernel, and both agree with the float64 oracle.  More rows than
-    workgroups (every workgroup walks several rows), sensor-window structure (H V rows skipped outside it) included."""
-    H, W, C = shape
-    rng = np.random.default_rng(W)
-    psf = orc.synthetic_psf(1, H, W, C, seed=3)
-    y = rng.random((H, W, C), dtype=np.float32)
-    outs = []
-    for pf in (0, 1):
-        engine_opts(monkeypatch, rows_half=1, row_rad=rad, row_pf=pf, jit_min_points=0)
-        rec = lpa.ADMM(torch.from_numpy(psf).to(backend.device), tau=2e-6, mu2=1e-4)
-        info = rec._handle.plan_info()
-        assert "half-length %d [static %s" % (rec._padded_shape[2] // 2, rad) in info, info
-        rec.set_data(torch.from_numpy(y).to(backend.device))
-        outs.append(rec.apply(n_iter=7, disp_iter=None).detach().cpu().numpy().copy())
-    assert np.array_equal(outs[0], outs[1])
-    o = orc.ADMMOracle(psf, dtype=torch.float64, tau=2e-6, mu2=1e-4)
-    o.set_data(y)
-    assert rel(outs[1], o.apply(7)) <= 5e-6
-
-
-@pytest.mark.parametrize("pad", [8, 36])
-def test_padded_real_row_pitch(backend, monkeypatch, pad):
-    """option rpitch_pad: the padded real planes (V, H V, the duals, r_sp) with a row pitch wider than the padded frame
-    (a tuning experiment: rows of 2^k bytes -- no HBM channel effect was found, profiles/r04_notes.md).  Every kernel
-    addresses those planes through PlaneGeom::rpitch: same goldens on both row schemes and on the run-time plans."""
-    for half in (0, 1):
-        engine_opts(monkeypatch, rpitch_pad=pad, rows_half=half, jit_min_points=0)
-        test_admm_matches_reference_golden(backend, "admm_24x32x3_tv")
-        test_convolver_golden(backend, "a")
-    engine_opts(monkeypatch, rpitch_pad=pad)
-    test_admm_matches_reference_golden(backend, "admm_24x32x3_tv")
-
-
-@pytest.mark.parametrize("shape,rad", [((20, 64, 3), "8.8"), ((11, 128, 1), "16.8"), ((9, 256, 3), "16.16")])
-def test_prefetching_residual_rows(backend, monkeypatch, shape, rad):
-    """option row_pf on the gradient-descent family: the residual rows (irfft row -> crop, - y, re-pad -> rfft row) as
-    persistent workgroups with the next half-spectrum row in flight by LDS-DMA and the stage twiddles in LDS
-    (k_rinv_gd_mid_half_pf).  Same arithmetic in the same order as k_rinv_gd_mid_half: BIT-identical iterates; both agree
-    with the float64 oracle.  More rows than workgroups on the emulator (one workgroup walks all rows of a plane)."""
-    H, W, C = shape
-    rng = np.random.default_rng(W + 1)
-    psf = orc.synthetic_psf(1, H, W, C, seed=5)
-    y = rng.random((H, W, C), dtype=np.float32)
-    outs = []
-    for pf in (0, 1):
-        engine_opts(monkeypatch, row_rad=rad, row_pf=pf, jit_min_points=0)
-        rec = lpa.FISTA(torch.from_numpy(psf).to(backend.device))
-        info = rec._handle.plan_info()
-        assert "half-length %d [static %s" % (rec._padded_shape[2] // 2, rad) in info, info
-        rec.set_data(torch.from_numpy(y).to(backend.device))
-        outs.append(rec.apply(n_iter=9, disp_iter=None).detach().cpu().numpy().copy())
-    assert np.array_equal(outs[0], outs[1])
-    o = orc.GDOracle(psf, kind="fista", dtype=torch.float64)
-    o.set_data(y)
-    assert rel(outs[1], o.apply(9)) <= 5e-6
-
-
 @pytest.mark.parametrize("shape,algo,rad,extra", [
     ((1, 5, 512, 1), "fista", "8.8.8", {}),
     ((2, 4, 512, 3), "fista", "8.8.8", {"gd_rev": 7}),
@@ -994,10 +905,8 @@ def test_prefetching_residual_rows(backend, monkeypatch, shape, rad):
     ((1, 3, 512, 1), "gd", "8.8.8", {}),
     ((1, 3, 4092, 1), "fista", "16.16.16", {}),
     ((1, 3, 4092, 3), "nesterov", "8.8.8.8", {"row_rad": "8.8.8.8"}),
-    ((1, 4, 512, 3), "fista", "8.8.8", {"row_lay": 3}),
-    ((1, 3, 4092, 1), "fista", "16.16.16", {"row_lay": 3}),
-    ((1, 3, 4092, 1), "nesterov", "16.16.16", {"row_lay": 0}),
-    ((1, 3, 4092, 1), "gd", "16.16.16", {"row_lay": 2}),
+    ((1, 3, 4092, 1), "nesterov", "16.16.16", {}),
+    ((1, 3, 4092, 1), "gd", "16.16.16", {}),
 ])
 def test_gd_fused_rows_second_form(backend, monkeypatch, shape, algo, rad, extra):
     """option gd_v2 (default on): the gradient-descent family's two fused row kernels in their second form

@@ -80,8 +80,8 @@ def _worker(rank, world, port, emu_path, out_dir):
     psf16 = rng.random((16, 12, 16, 3), dtype=np.float32) ** 4
     y = rng.random((12, 16, 3), dtype=np.float32)
     ps = PlaneShardedReconstructor(lpa.ADMM, psf16, **kw)
-    assert len(ps.units) == 48 and list(ps._solvers) == [((2 * rank, 2 * rank + 1), (0, 1, 2))], list(ps._solvers)
     got = ps(y, n_iter=3)
+    assert len(ps.units) == 48 and list(ps._solvers) == [((2 * rank, 2 * rank + 1), (0, 1, 2))], list(ps._solvers)
     stack = lpa.ADMM(psf16, **kw)
     stack.set_data(y)
     assert got.shape == (16, 12, 16, 3) and np.array_equal(got, stack.apply(n_iter=3, disp_iter=None, plot=False)), rank
