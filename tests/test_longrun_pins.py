@@ -12,8 +12,8 @@ torch-CPU float64 AND float32 on closed-form inputs, reduced to crops + a lattic
 What is asserted, per snapshot:
   * the float64 build (liblpc_f64.so, sensor-window structure ON -- the kernels the float32 engine runs) equals the
     reference's float64 samples to <= 1e-9 of max|x|, its frame sums to 1e-9, its PSNR vs the scene to 1e-6 dB;
-  * the float32 engine is within the tolerance table of DESIGN.md section 2 of the reference's float64 samples and within
-    0.01 dB of its PSNR (north_star);
+  * the float32 engine is within SURVEY.md section 8(c)'s tolerances of the reference's float64 samples (TOL32 below) and
+    within 0.01 dB of its PSNR (north_star);
   * the ATTRIBUTION behind the float32 tolerance: the engine is no further from the reference's float64 samples than the
     reference's own float32 run is (x ATTR_SLACK, with a floor of a few ulp where both are at round-off).
 
@@ -38,9 +38,11 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 F64_TOL = 1e-9
 ATTR_SLACK = 1.0          # engine distance <= ATTR_SLACK x the reference's own float32 distance ...
 ATTR_FLOOR = 5e-6         # ... or this, where both sit at float32 round-off (short runs, small frames)
-# float32 tolerance vs float64 truth, relative to max|x| (SURVEY.md section 8(c) as amended there)
-TOL32 = {("admm", 5): 1e-5, ("admm", 12): 2e-5, ("admm", 20): 2e-5, ("admm", 30): 1.5e-4, ("admm", 50): 2e-4,
-         ("admm", 100): 3e-4, ("fista", 6): 1e-5, ("fista", 30): 5e-5, ("fista", 300): 5e-4}
+# float32 tolerance vs float64 truth on the samples, relative to max|x| -- SURVEY.md section 8(c)'s own figures (ADMM 1e-5 /
+# 5e-5 after <= 20 / 100 iterations, FISTA 5e-4 after 300); measured: 1.1e-5 at ADMM-100 where the reference's own float32
+# run is at 9.8e-5 (the full-frame bound of tests/test_parity_fullsize.py stays 3e-4: other inputs have shown 1.7e-4)
+TOL32 = {("admm", 5): 1e-5, ("admm", 12): 1e-5, ("admm", 20): 1e-5, ("admm", 30): 2e-5, ("admm", 50): 2e-5,
+         ("admm", 100): 5e-5, ("fista", 6): 1e-5, ("fista", 30): 5e-5, ("fista", 300): 5e-4}
 
 
 def fixture_file(tag):
