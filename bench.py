@@ -316,12 +316,12 @@ def load_traffic(plan_info):
     from lenslesspicam_amd import build as _build
 
     fp = _build.fingerprint()
+    key = plan_info.split("plan module ", 1)[1].strip() if "plan module " in plan_info else None
     for entry in tj.get("plans", []):
-        if entry.get("plan_module") and ("plan module " + entry["plan_module"]) in plan_info:
-            # counters are only as good as the kernels they were taken on: an entry carries the fingerprint of the sources
-            # it was measured with (tools/summarize_prof.py stamps it); another fingerprint = stale = not reported
-            if entry.get("source_fingerprint") != fp:
-                return None
+        # the WHOLE module key (one key may be a prefix of another), and counters are only as good as the kernels they were
+        # taken on: an entry carries the fingerprint of the sources it was measured with (tools/summarize_prof.py stamps
+        # it); another fingerprint = stale = not reported
+        if key and entry.get("plan_module") == key and entry.get("source_fingerprint") == fp:
             return entry
     return None
 

@@ -26,13 +26,14 @@ SAN_LIB = os.path.join(EMU_DIR, "_build_san", "liblpc_emu.so")
 
 # one case of every kernel family, run-time plans and plan modules: paired and half-length ADMM rows with the X half and
 # the sensor-window structure, the tiled image-domain kernel and its form inside the forward rows, the LDS / sequential
-# middles, the gradient-descent family's fused rows (both forms), a random odd shape (LPC_SAN_FULL=1 adds everything
+# middles (plain and pair-line spectra, odd window offsets, an odd padded height), the gradient-descent family's fused rows (both forms), a random odd shape (LPC_SAN_FULL=1 adds everything
 # else: pass A, the register middles, the operator, tiny frames, the world-size-2 gloo tests)
 SUBSET = " or ".join([
     "test_admm_matches_reference_golden and admm_24x32x3_tv",
     "test_gd_family_matches_reference_golden and fista_24x32x3",
     "test_admm_half_length_row_kernels and admm_24x32x3_tv and static_plan",
     "test_c4_sequential_middle_on_one_frame",
+    "test_pair_line_spectra_odd_window_and_odd_height",
     "test_gd_fused_rows_second_form and shape0",
     "test_tv_half_inside_forward_rows and shape0",
     "test_random_small_shapes_through_plan_modules and emu-0",

@@ -113,6 +113,7 @@ if plan and "plan module " in plan:
             entry["kernels"][kid] = {"kernel": k, "hbm_bytes_per_launch": v}
     tf = os.path.join(out, "traffic.json")
     tj = json.load(open(tf)) if os.path.exists(tf) else {"plans": []}
-    tj["plans"] = [e for e in tj["plans"] if e.get("plan_module") != key] + [entry]
+    # entries of other source trees are stale (bench.py ignores them): they leave the file
+    tj["plans"] = [e for e in tj["plans"] if e.get("plan_module") != key and e.get("source_fingerprint") == entry["source_fingerprint"]] + [entry]
     json.dump(tj, open(tf, "w"), indent=1)
 print("\n".join(lines))
