@@ -98,6 +98,8 @@ typedef struct lpc_config {
  *   row_rad=16.16.8    radices of the compile-time row plan instead of the chooser's (one module)
  * The structure of an ADMM iteration (each setting is an older, complete form of the same arithmetic)
  *   xi_full=1 hv_full=1   without the sensor-window structure of xi / of the H V row transforms
+ *   mid_pc=0           sequential middle on pair-line spectra: H, |G| and the phase factors loaded and combined per element
+ *                      (default 1: precombined once per PSF and step sizes into one 16-byte + one 4-byte load per element)
  *   k1_half=0          duals stored plain between the iterations of one call (default 1: half-applied, the tiled kernel
  *                      then does not read V_old: 9R -> 8R)
  *   k1_rows=0          keep the tiled TV / W kernel (default 1: paired rows of one quad per lane -- padded widths up to

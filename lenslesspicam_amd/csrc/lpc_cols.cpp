@@ -110,6 +110,19 @@ int admm_cols(Engine* e, const AdmmScalars& sc) {
     // need a 256- / 192-point pass A that costs more than it saves; 48 points is 1.62 ms (AGPR traffic).
     if (regN == 24) { LPC_OK(reg_mid(k_cols_mid_admm_reg<8, 3>)); }
     else if (e->mod && e->mod->admm_mid) {   // compile-time plan in LDS: both spectra side by side, or one at a time
+      if (e->midc && !(e->midc_valid && e->midc_par[0] == (double)sc.mu1 && e->midc_par[1] == (double)sc.mu2 &&
+                       e->midc_par[2] == (double)sc.mu3)) {      // k_mid_consts: once per (PSF, step sizes)
+        const long n = (long)((g.Hp + 1) & ~1) * g.cpitch;
+        auto consts = [&](auto kernel) {
+          return launch_k(e, -1, kernel, grid1d(n, 256, e->Ppsf), 256, 0, (const real2*)e->Hs_t, (const real*)e->Gabs_t,
+                          cp.ga, cp.gb, (const real2*)e->phr, (const real2*)e->phc, g.Hp, g.Wc, g.cpitch, g.cplane, sc.mu1,
+                          sc.mu2, sc.mu3, (real)1.0 / ((real)g.Hp * (real)g.Wp), e->midc, e->midrd);
+        };
+        if (e->mod->mid_pc == 2) LPC_OK(consts(k_mid_consts<256, true>));
+        else LPC_OK(consts(k_mid_consts<256, false>));
+        e->midc_par[0] = (double)sc.mu1; e->midc_par[1] = (double)sc.mu2; e->midc_par[2] = (double)sc.mu3;
+        e->midc_valid = true;
+      }
       LPC_OK(e->mod->admm_mid(e, &cp, &sc, (sc.skipa && !split) ? sc.mu1 * (real)g.Wp : (real)0.));
     }
     else if (cp.N * cp.T * 2 > 8192 && cp.N * cp.T * 2 <= 9216) {

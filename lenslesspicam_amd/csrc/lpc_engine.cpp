@@ -430,6 +430,9 @@ static void choose_plan(Engine* e, bool allow_static) {
   // of 8 complex128 columns is a whole line already)
   sp.slay = (admm && f32 && sp.row_kind == LPC_ROWS_PAIRED && sp.mid_kind != LPC_MID_RUNTIME && e->N1 == 1 && sp.mid.T == 8 &&
              o.spec_lay != 0) ? 1 : 0;
+  // ... the sequential middle's point-wise constants precombined (k_mid_consts); even padded sizes: the ifftshift phases are
+  // +-1, one complex constant per element instead of two (mid_pc = 2)
+  sp.mid_pc = (sp.slay && sp.mid_kind == LPC_MID_SEQ && o.mid_pc != 0) ? ((g.Hp % 2 == 0 && g.Wp % 2 == 0) ? 2 : 1) : 0;
 }
 
 // frame geometry (rfft_convolve.py:110-117) and the launch plan -- no device work (also serves lpc_plan_module)
@@ -658,6 +661,12 @@ static int admm_alloc(Engine* e) {
   if (g.slay) {
     LPC_OK(dev_alloc(e, &e->Gabs_t, (size_t)g.cplane));
     LPC_OK(dev_alloc(e, &e->Hs_t, (size_t)g.cplane * e->Ppsf));
+    if (e->mod && e->mod->mid_pc) {
+      real2* c = nullptr;
+      LPC_OK(dev_alloc(e, &c, (size_t)g.cplane * e->Ppsf * (e->mod->mid_pc == 1 ? 2 : 1)));
+      e->midc = c;
+      LPC_OK(dev_alloc(e, &e->midrd, (size_t)g.cplane * e->Ppsf));
+    }
   }
   LPC_OK(dev_alloc(e, &e->Ga, (size_t)g.Hp));
   LPC_OK(dev_alloc(e, &e->Gb, (size_t)g.cpitch));
@@ -670,6 +679,7 @@ static int admm_alloc(Engine* e) {
 static int admm_split_gram(Engine* e) {
   const PlaneGeom& g = e->g;
   e->g_sep = 0;
+  e->midc_valid = false;      // (a new PSF or gram: the middle's precombined constants are remade at the next step)
   if (g.slay)       // the 8-column middle reads the plane in pair lines
     LPC_OK(launch_k(e, -1, k_to_pair_lines<256, real>, grid1d((long)g.Hp * g.cpitch, 256), 256, 0, (const real*)e->Gabs,
                     e->Gabs_t, g.Hp, g.cpitch, g.cplane));

@@ -107,6 +107,11 @@ struct lpc_engine {
   real2* Hs = nullptr;     // [Ppsf] PSF spectrum, permuted row order, norm applied
   real2* Hs_t = nullptr;   // ... and |G| below: copies in the pair-line layout for the module's 8-column middle (PlaneGeom::slay)
   real* Gabs_t = nullptr;
+  // ... and the sequential middle's point-wise constants, precombined per (PSF, step sizes) (lpc_kernels.h: k_mid_consts)
+  void* midc = nullptr;       // MidConst (mid_pc 1) or real2 (mid_pc 2: real phases) per element
+  real* midrd = nullptr;
+  double midc_par[3] = {0, 0, 0};   // the step sizes the tables were made for
+  bool midc_valid = false;
   real* Gabs = nullptr;    // ADMM: |PsiT Psi| spectrum, ONE plane (identical for every channel)
   // ... and, when that plane is a sum of a row term and a column term (the reference's finite-difference gram is:
   // (2 - 2 cos th_r) + (2 - 2 cos th_c)), the two vectors the middles read instead of it: Ga[row] + Gb[col]
@@ -255,6 +260,7 @@ struct LpcModule {
   int (*cols_passA)(Engine*, const ColPass*, real2* S, int nplanes, int inverse, int kid);
   int (*admm_mid)(Engine*, const ColPass*, const AdmmScalars*, real sb_outside_scale);
   int k1_rows;    // admm_rows_fwd_x takes the TV / W half of the image-domain work as well (k_rfwd_arrays_x<.., K1>)
+  int mid_pc;     // its sequential middle reads the precombined constants (Engine::midc / midrd)
   int slay;       // its ADMM row kernels and fused middle keep the work spectra in pair lines (PlanSpec::slay)
   int gd_v2;      // the module holds k_gd_resid_v2 / k_gd_update_fwd_v2 for its row plan (lpc_gd_v2_kernels.h)
 };

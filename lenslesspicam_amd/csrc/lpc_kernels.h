@@ -997,6 +997,15 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
   LPC_STAMP_END();
 }
 
+// ---- the point-wise step's constants of the pair-line sequential middle, precombined ------------------------------------
+// Step 3 of k_cols_mid_admm_seq needs, per tile element, H, |G|, the row and the column phase: four loads and a
+// reciprocal per element, nine elements per lane, each waiting for its own loads -- a third of a workgroup's lifetime at C4
+// (profiles/r05_notes.md section 5).  They depend on the PSF plane and the step sizes only, not on the frame: one small
+// kernel forms  c1 = conj(H) ph,  c2 = H ph  (ph = phr[row] phc[column])  and  rd = rscale / (mu1 |H|^2 + mu2 |G| + mu3)
+// once per (PSF, step sizes) -- every iteration of an unrolled schedule, never again otherwise -- in the pair-line
+// layout; the step then is one 16-byte and one 4-byte load and three products per element.
+struct alignas(16) MidConst { real2 c1, c2; };     // (k_mid_consts: behind the kernel that reads them)
+
 // ---- the same fused middle, ONE ARRAY AT A TIME through a tile of T image columns (single-pass columns only) ------
 // k_cols_mid_admm keeps both spectra in one [N][2T] tile; when a whole column is long (540 rows for the
 // DiffuserCam-sized frames of C1 / C4) that tile allows only T = 8 columns per array -- 64-byte row segments, half a
@@ -1009,12 +1018,15 @@ __global__ __launch_bounds__(NT) void k_cols_mid_admm(PlaneGeom g, PL plan, ColP
 // only (SBT == cp.T).
 // SL = 1: the work spectra AND the copies of H / |G| passed in are in the pair-line layout (spec_col; T == 8): a tile's
 // rows (2p, 2p + 1) are one 128-byte line.
-template <int NT, int EMAX, class PL, int SBT, int MINW = 1, bool PRE = false, int SL = 0>
+// PC (with SL): Hs / Gabs are the precombined constants of k_mid_consts (1: MidConst planes, 2: c1 planes -- real phases --
+// and the rd planes), phr / phc are not read.
+template <int NT, int EMAX, class PL, int SBT, int MINW = 1, bool PRE = false, int SL = 0, int PC = 0>
 __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL plan, ColPass cp, real2* LPC_RESTRICT SA,
                                                            real2* LPC_RESTRICT SB, const real2* LPC_RESTRICT Hs,
                                                            const real* LPC_RESTRICT Gabs, const real2* LPC_RESTRICT phr,
                                                            const real2* LPC_RESTRICT phc, real mu1, real mu2, real mu3,
                                                            real rscale, real sb_outside_scale) {
+  static_assert(!PC || SL, "precombined constants live in the pair-line layout");
   LPC_DYN_SMEM(smem);
   real2* s = (real2*)smem;
   // (plain threadIdx.x, not LPC_TID: knowing tid < NT the optimiser keeps all 17 row indices of a lane -- as 64-bit
@@ -1038,8 +1050,8 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   const int cb = SL ? 2 * c0 : c0;                  // first element of the tile's column chunk within a row (pair)
   real2* ba = SA + pl * g.cplane + cb;
   real2* bb = SB + pl * g.cplane + cb;
-  const real2* hb = Hs + (long)pp * g.cplane + cb;
-  const real* rb = Gabs + cb;
+  const real2* hb = Hs + (PC == 1 ? 2 : 1) * ((long)pp * g.cplane + cb);       // (PC == 1: 16-byte elements)
+  const real* rb = Gabs + (PC ? (long)pp * g.cplane : 0) + cb;
   // 32-bit byte offsets from workgroup-uniform bases (a plane is < 4 GB): one v_mad_u32 per access instead of a
   // 64-bit multiply-add (quarter rate) + 64-bit shift-add
   const unsigned r8 = (unsigned)g.cpitch * (unsigned)sizeof(real2), r4 = (unsigned)g.cpitch * (unsigned)sizeof(real);
@@ -1123,14 +1135,28 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
     if (k < KFULL || tid + k * NT < NELEM) {
       if (j0 < wc) {
         const int e = tid + k * NT, i = i0 + k * RSTEP;
-        const real2 hh = ld_off(hb + k * rstep, l8);
-        const real gk = cp.ga ? cp.ga[i] + cp.gb[c0 + j0] : ld_off(rb + k * rstep, l4);
-        const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * gk + mu3);
-        const real2 ph = cmul(phr[i], phc[c0 + j0]);
-        const real2 t = cmul(cmul_conj(a[k], hh), ph);
-        const real2 vh = cscale(cadd(s[e], t), rdiv);
-        s[e] = vh;
-        a[k] = cmul(cmul(vh, hh), ph);
+        if constexpr (PC == 1) {
+          const MidConst mc = ld_off((const MidConst*)hb + k * rstep, 2u * l8);
+          const real rdiv = ld_off(rb + k * rstep, l4);
+          const real2 vh = cscale(cadd(s[e], cmul(a[k], mc.c1)), rdiv);
+          s[e] = vh;
+          a[k] = cmul(vh, mc.c2);
+        } else if constexpr (PC == 2) {
+          const real2 c1 = ld_off(hb + k * rstep, l8);
+          const real rdiv = ld_off(rb + k * rstep, l4);
+          const real2 vh = cscale(cadd(s[e], cmul(a[k], c1)), rdiv);
+          s[e] = vh;
+          a[k] = cmul_conj(vh, c1);
+        } else {
+          const real2 hh = ld_off(hb + k * rstep, l8);
+          const real gk = cp.ga ? cp.ga[i] + cp.gb[c0 + j0] : ld_off(rb + k * rstep, l4);
+          const real rdiv = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * gk + mu3);
+          const real2 ph = cmul(phr[i], phc[c0 + j0]);
+          const real2 t = cmul(cmul_conj(a[k], hh), ph);
+          const real2 vh = cscale(cadd(s[e], t), rdiv);
+          s[e] = vh;
+          a[k] = cmul(cmul(vh, hh), ph);
+        }
       }
     }
   }
@@ -1149,6 +1175,36 @@ __global__ __launch_bounds__(NT, MINW) void k_cols_mid_admm_seq(PlaneGeom g, PL 
   auto outB = [=](int i, int j, real2 x) { if (j < wc) st_off(bb, off8(i, j), x); };
   fft_tile<NT, EMAX, true, false, true, false, LPC_COLS_FUSEL, SBT>(s, plan, T, cp.tdiv, tid, LdsNatural{}, outB);
   LPC_STAMP_END();
+}
+
+// REALPH: the phases are +-1 (even padded sizes: ifftshift = (-1)^k per axis), c2 = conj(c1): only c1 is stored (8 bytes)
+template <int NT, bool REALPH>
+__global__ __launch_bounds__(NT) void k_mid_consts(const real2* LPC_RESTRICT Hs_t, const real* LPC_RESTRICT Gabs_t,
+                                                    const real* LPC_RESTRICT ga, const real* LPC_RESTRICT gb,
+                                                    const real2* LPC_RESTRICT phr, const real2* LPC_RESTRICT phc, int Hp,
+                                                    int Wc, int cpitch, long cplane, real mu1, real mu2, real mu3,
+                                                    real rscale, void* LPC_RESTRICT Cv, real* LPC_RESTRICT RD) {
+  const long n = (long)((Hp + 1) & ~1) * cpitch;          // pair-line positions of one plane
+  const long pl = blockIdx.y;
+  for (long e = (long)blockIdx.x * NT + threadIdx.x; e < n; e += (long)gridDim.x * NT) {
+    const long pair = e / (2 * cpitch);
+    const int w = (int)(e - pair * 2 * cpitch);
+    const int i = 2 * (int)pair + ((w >> 3) & 1), j = ((w >> 4) << 3) + (w & 7);
+    MidConst mc;
+    mc.c1 = mc.c2 = make_real2((real)0., (real)0.);
+    real rd = (real)0.;
+    if (i < Hp && j < Wc) {
+      const real2 hh = Hs_t[pl * cplane + e];
+      const real gk = ga ? ga[i] + gb[j] : Gabs_t[e];
+      const real2 ph = cmul(phr[i], phc[j]);
+      mc.c1 = cmul(make_real2(hh.x, -hh.y), ph);
+      mc.c2 = cmul(hh, ph);
+      rd = rscale * recip_pos(mu1 * rabs(hh.x * hh.x + hh.y * hh.y) + mu2 * gk + mu3);
+    }
+    if (REALPH) ((real2*)Cv)[pl * cplane + e] = mc.c1;
+    else ((MidConst*)Cv)[pl * cplane + e] = mc;
+    RD[pl * cplane + e] = rd;
+  }
 }
 
 // ============================================================ ADMM spatial kernel ==

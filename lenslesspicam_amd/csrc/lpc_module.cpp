@@ -14,6 +14,9 @@
 #ifndef LPC_MOD_SLAY
 #define LPC_MOD_SLAY 0
 #endif
+#ifndef LPC_MOD_MID_PC
+#define LPC_MOD_MID_PC 0
+#endif
 #ifndef LPC_MOD_FAMILY
 #error "lpc_module.cpp is compiled with the flags of plan_spec_defines() (lpc_plan.h)"
 #endif
@@ -201,9 +204,11 @@ static int m_admm_mid(Engine* e, const ColPass* cp, const AdmmScalars* sc, real 
   const real rscale = (real)1.0 / ((real)g.Hp * (real)g.Wp);
 #if LPC_MOD_MID_KIND == LPC_MID_SEQ     // single-pass columns, one spectrum at a time through T columns
   // (LDS: the tile + the plan's twiddle table behind it)
-  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, LPC_MOD_MID_PRE != 0, LPC_MOD_SLAY>,
+  constexpr int PC = LPC_MOD_SLAY != 0 ? LPC_MOD_MID_PC : 0;      // precombined point-wise constants (k_mid_consts)
+  return launch_k(e, LPC_K_COL_MID, k_cols_mid_admm_seq<NT, EM, MidPA, T, LPC_MOD_MID_MINW, LPC_MOD_MID_PRE != 0, LPC_MOD_SLAY, PC>,
                   dim3(cp->ntile_c * e->P), NT, (size_t)MidP::n * (T + 1) * sizeof(real2), g, pa, *cp, SA, SB,
-                  (const real2*)(LPC_MOD_SLAY ? e->Hs_t : e->Hs), (const real*)(LPC_MOD_SLAY ? e->Gabs_t : e->Gabs), (const real2*)e->phr, (const real2*)e->phc, sc->mu1,
+                  PC ? (const real2*)e->midc : (const real2*)(LPC_MOD_SLAY ? e->Hs_t : e->Hs),
+                  PC ? (const real*)e->midrd : (const real*)(LPC_MOD_SLAY ? e->Gabs_t : e->Gabs), (const real2*)e->phr, (const real2*)e->phc, sc->mu1,
                   sc->mu2, sc->mu3, rscale, sb_outside_scale);
 #else                                   // both spectra side by side: [N][2 T]
   const FastDiv t2 = make_fastdiv((unsigned)(2 * T));
@@ -256,5 +261,8 @@ extern "C" int lpc_module_init(LpcModule* m, size_t engine_size, const char* src
   m->admm_mid = m_admm_mid;
 #endif
   m->slay = LPC_MOD_SLAY;
+#if LPC_MOD_MID_KIND == LPC_MID_SEQ
+  m->mid_pc = LPC_MOD_SLAY != 0 ? LPC_MOD_MID_PC : 0;
+#endif
   return 0;
 }

@@ -50,6 +50,8 @@ struct PlanSpec {
   StaticFft mid;              // ADMM fused middle in LDS
   int mid_minw = 1;           // __launch_bounds__ second argument of the sequential middle
   int mid_pre = 0;            // sequential middle: both tiles' loads issued before the first transform
+  int mid_pc = 0;             // sequential middle on pair-line spectra: point-wise constants precombined (k_mid_consts): 1 two
+                              // complex constants per element, 2 one (even padded sizes: the ifftshift phases are +-1)
   int slay = 0;               // ADMM work spectra in pair lines (lpc_kernels.h: spec_col): paired rows + 8-column sequential middle
   bool any() const { return row_kind != LPC_ROWS_RUNTIME || passA.n || mid_kind != LPC_MID_RUNTIME; }
 };
@@ -65,7 +67,7 @@ static inline std::string plan_spec_key(const PlanSpec& s) {
   k += s.family == LPC_FAM_ADMM ? "_admm" : "_gd";
   if (s.row_kind) k += std::string(s.row_kind == LPC_ROWS_HALF ? "_rh" : "_rp") + fft_key(s.row) + (s.row_sk == 1 ? "s" : "") + (s.row_x ? "x" : "");
   if (s.passA.n) k += "_a" + fft_key(s.passA);
-  if (s.mid_kind) k += std::string(s.mid_kind == LPC_MID_PAIR ? "_mp" : "_ms") + fft_key(s.mid) + "m" + std::to_string(s.mid_minw) + (s.mid_pre ? "p" : "") + (s.slay ? "L" : "");
+  if (s.mid_kind) k += std::string(s.mid_kind == LPC_MID_PAIR ? "_mp" : "_ms") + fft_key(s.mid) + "m" + std::to_string(s.mid_minw) + (s.mid_pre ? "p" : "") + (s.slay ? "L" : "") + (s.mid_pc == 1 ? "c" : (s.mid_pc == 2 ? "r" : ""));
   return k;
 }
 static inline std::string rad_list(const StaticFft& f) {
@@ -99,6 +101,7 @@ static inline std::vector<std::string> plan_spec_defines(const PlanSpec& s) {
     defi("LPC_MOD_MID_PRE", s.mid_pre);
   }
   defi("LPC_MOD_SLAY", s.slay);
+  defi("LPC_MOD_MID_PC", s.mid_pc);
   return d;
 }
 
@@ -135,6 +138,8 @@ struct EngineOpts {
   int k1_rows = 1;            // TV / W half inside the paired forward rows where a row is one quad per lane (three launches)
   int k1_group = 16;          // ... on launches of more than 8192 row blocks: runs of this many consecutive blocks per XCD
                               // (K1Rows::xcd_order; 0: launch order)
+  int mid_pc = 1;             // sequential middle on pair-line spectra: H, |G| and the phases precombined per (PSF, step sizes)
+                              // into one 16-byte + one 4-byte load per element (PlanSpec::mid_pc); 0: loaded and combined per element
   int k1_half = 1;            // duals half-applied between the iterations of one call: the tiled kernel does not read V_old
   // -- block orders (permutations: results unchanged)
   int rev_order = 9;          // bit 0 / 1 / 2 / 3: the tiled ADMM kernel / forward pass A / inverse pass A / the LDS middle walk
@@ -198,6 +203,7 @@ static inline std::string parse_engine_opts(const char* str, EngineOpts& o) {
       else if (k == "k1_rows") o.k1_rows = (int)iv;
       else if (k == "k1_group") o.k1_group = (int)iv;
       else if (k == "k1_half") o.k1_half = (int)iv;
+      else if (k == "mid_pc") o.mid_pc = (int)iv;
       else if (k == "rev_order") o.rev_order = (int)iv;
       else if (k == "gd_rev") o.gd_rev = (int)iv;
       else if (k == "gd_no_fuse_fwd") o.gd_no_fuse_fwd = (int)iv;

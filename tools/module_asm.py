@@ -37,10 +37,10 @@ def defines(key):
     else:
         d.append("-DLPC_MOD_PASSA=0")
     if mid:
-        m = re.fullmatch(r"m([ps])" + fft + r"m(\d+)(g?)(p?)(L?)", mid)
+        m = re.fullmatch(r"m([ps])" + fft + r"m(\d+)(g?)(p?)(L?)([cr]?)", mid)
         d += ["-DLPC_MOD_MID_KIND=%d" % (1 if m[1] == "p" else 2), "-DLPC_MOD_MID_RAD=" + m[3].replace(".", ","),
               "-DLPC_MOD_MID_T=" + m[4], "-DLPC_MOD_MID_NT=" + m[5], "-DLPC_MOD_MID_EM=" + m[6], "-DLPC_MOD_MID_MINW=" + m[7],
-              "-DLPC_MOD_MID_TWG=%d" % bool(m[8]), "-DLPC_MOD_MID_PRE=%d" % bool(m[9]), "-DLPC_MOD_SLAY=%d" % bool(m[10])]
+              "-DLPC_MOD_MID_TWG=%d" % bool(m[8]), "-DLPC_MOD_MID_PRE=%d" % bool(m[9]), "-DLPC_MOD_SLAY=%d" % bool(m[10]), "-DLPC_MOD_MID_PC=%d" % {"": 0, "c": 1, "r": 2}[m[11]]]
     else:
         d.append("-DLPC_MOD_MID_KIND=0")
     return d
