@@ -47,7 +47,10 @@ def test_every_fixture_is_self_consistent():
                 assert c64.dtype == np.float64 and c32.dtype == np.float32 and c64.shape == c32.shape
                 assert c64.shape[0] == 8 and c64.shape[1:3] == (32, 32)
                 top = fx[f"{name}_f64_it{it}_stats"][2]
-                d = np.abs(c32.astype(np.float64) - c64).max() / top
+                l64, l32 = fx[f"{name}_f64_it{it}_lattice"], fx[f"{name}_f32_it{it}_lattice"]
+                assert l64.dtype == np.float64 and l32.dtype == np.float32 and l64.shape == l32.shape and l64.max() > 0
+                # (a crop may be all zero -- FISTA's projection clamps most of the frame's border -- the lattice never is)
+                d = max(np.abs(c32.astype(np.float64) - c64).max(), np.abs(l32.astype(np.float64) - l64).max()) / top
                 full = float(fx[f"{name}_f32_it{it}_dist64_full"])
                 assert 0 < d <= full * (1 + 1e-12), (path, name, it, d, full)     # the samples are part of the frame
                 assert (c64 >= 0).all() and (c32 >= 0).all()                       # apply() clamps (admm.py:337, gd.py:27-30)
