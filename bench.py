@@ -340,7 +340,9 @@ def kernel_table(handle, prof, traffic=None):
                              "GBps": round(b / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                              "frac_of_peak": round(b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
             t = (traffic or {}).get("kernels", {}).get(name)
-            if t and b > 0:
+            # (one plan module serves every batch size of a frame shape: counters taken on another batch size are not
+            # this workload's -- a ratio outside [0.5, 2] can only be that)
+            if t and b > 0 and 0.5 <= t["hbm_bytes_per_launch"] / b <= 2.0:
                 kernels[name].update(traffic_GB=round(t["hbm_bytes_per_launch"] / 1e9, 3),
                                      traffic_over_alg=round(t["hbm_bytes_per_launch"] / b, 3), pmc_kernel=t["kernel"])
     return kernels
