@@ -102,9 +102,9 @@ typedef struct lpc_config {
  *                      (default 1: precombined once per PSF and step sizes into one 16-byte + one 4-byte load per element)
  *   k1_half=0          duals stored plain between the iterations of one call (default 1: half-applied, the tiled kernel
  *                      then does not read V_old: 9R -> 8R)
- *   k1_rows=0          keep the tiled TV / W kernel (default 1: paired rows of one quad per lane -- padded widths up to
- *                      1024 -- take that half of the image-domain work as well: three launches per iteration, r_sp never
- *                      stored; such rows then run on 256 lanes at every batch size)
+ *   k1_rows=0          keep the tiled TV / W kernel (default 1: paired rows of one or two quads per lane -- padded widths up
+ *                      to 2048 -- take that half of the image-domain work as well: three launches per iteration, r_sp never
+ *                      stored; rows of up to 1024 points then run on 256 lanes at every batch size)
  *   k1_group=N         ... on launches of more than 8192 row blocks: runs of N consecutive blocks per XCD (default 16;
  *                      0: launch order)
  * Block orders (permutations)

@@ -505,7 +505,10 @@ static int setup_geometry(Engine* e) {
   // launches per iteration, r_sp never stored.  One small frame is a chain of launch boundaries and memory latencies
   // (C1 -7.6 %), a batch saves the trip of r_sp through memory and the tiled kernel's launch (C4 -6.3 %);
   // profiles/r05_notes.md section 5 (option k1_rows=0: off)
-  e->k1_rows = e->xhalf_rows && e->mod->k1_rows && g.Wp % 4 == 0 && e->opt.k1_rows != 0;
+  // (round 6: rows of TWO quads per lane as well -- padded widths up to 2048: the reference's own profile frame 760 x 1014
+  // gray 0.458 -> 0.442 ms per 5 iterations, 8 frames of 600 x 800 x 3 22.1 -> 20.8 ms per 20; profiles/r06_notes.md.  FOUR
+  // quads per lane -- 12-MP half-length rows -- are slower than the tiled kernel: not built)
+  e->k1_rows = e->xhalf_rows && g.Wp % 4 == 0 && e->mod->k1_rows != 0 && e->opt.k1_rows != 0;
   // ... outside the sensor window that half works from HV alone (AdmmScalars::xiw; option xi_full: every pixel alike) ...
   e->xi_window = e->xhalf_rows && !e->opt.xi_full;
   // ... and rows wholly outside it skip the H V row transforms in both directions: the kept rows of SB are rescaled by

@@ -1915,12 +1915,12 @@ __global__ __launch_bounds__(NT, K1 ? LPC_K1ROWS_MINW : NT == 256 ? LPC_RFWDX_MI
   const long o_row = pl * g.rplane + (long)pr.r0 * g.rpitch;
   if (K1 && pr.arr == 0) {
     if constexpr (K1) {
-      static_assert((PL::n >> 2) <= NT, "one quad per lane and row");
-      if (tid < (PL::n >> 2)) {
-        const long po = pl * g.rplane;
+      static_assert((PL::n >> 2) <= 2 * NT, "one or two quads per lane and row");
+      const long po = pl * g.rplane;
+#pragma unroll
+      for (int q = tid; q < (PL::n >> 2); q += NT)
         k1_two_rows<SK>(g, p, k1.V + po, k1.Vold + po, k1.eta0 + po, k1.eta1 + po, k1.eta0_out + po, k1.eta1_out + po,
-                        k1.rho + po, pr.r0, v1, tid, s);
-      }
+                        k1.rho + po, pr.r0, v1, q, s);
       __syncthreads();
       fft_tile<NT, EMAX, false, SK, false>(s, plan, 1, make_fastdiv_dev1(), tid, LdsNatural{}, LdsNatural{});
       real2* o0 = SA + pl * g.cplane + (long)pr.r0 * g.cpitch;

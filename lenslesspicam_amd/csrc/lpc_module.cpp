@@ -153,7 +153,9 @@ static int m_admm_rows_inv(Engine* e, real* Vout, real* HVout, int skip_hv_outsi
                   row_arg(e), (const real2*)SA, (const real2*)SB, Vout, HVout, skip_hv_outside ? 1 : 0);
 }
 #if LPC_MOD_ROW_X
-constexpr bool kK1Rows = (RowP::n >> 2) <= RNT;     // one quad per lane and row: the TV / W half can ride along
+// quads per lane and row with which the TV / W half can ride along: 1 or 2 (padded widths up to 8 x the lanes), else 0
+constexpr int kK1Quads = (RowP::n >> 2) <= RNT ? 1 : ((RowP::n >> 2) <= 2 * RNT ? 2 : 0);
+constexpr bool kK1Rows = kK1Quads != 0;
 static int m_admm_rows_fwd_x(Engine* e, const AdmmScalars* sc, const K1Rows* k1) {
   const PlaneGeom& g = e->g;
   real2* SA = e->S;
@@ -242,7 +244,7 @@ extern "C" int lpc_module_init(LpcModule* m, size_t engine_size, const char* src
 #if LPC_MOD_ROW_X
   m->admm_rows_fwd_x = m_admm_rows_fwd_x;
 #if LPC_MOD_ROW_KIND == LPC_ROWS_PAIRED
-  m->k1_rows = kK1Rows ? 1 : 0;
+  m->k1_rows = kK1Quads;
 #endif
 #endif
 #endif

@@ -135,7 +135,7 @@ struct EngineOpts {
   // -- the structure of an ADMM iteration (each 0 / 1 is an older, complete form of the same arithmetic)
   int hv_full = 0;            // every row of H V transformed in every iteration
   int xi_full = 0;            // xi kept on the whole padded frame
-  int k1_rows = 1;            // TV / W half inside the paired forward rows where a row is one quad per lane (three launches)
+  int k1_rows = 1;            // TV / W half inside the paired forward rows where a row is one or two quads per lane (three launches)
   int k1_group = 16;          // ... on launches of more than 8192 row blocks: runs of this many consecutive blocks per XCD
                               // (K1Rows::xcd_order; 0: launch order)
   int mid_pc = 1;             // sequential middle on pair-line spectra: H, |G| and the phases precombined per (PSF, step sizes)

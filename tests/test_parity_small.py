@@ -819,12 +819,12 @@ def test_tiny_frames_circular_neighbours(backend, shape):
     assert rel(rec.apply(n_iter=8, disp_iter=None), want) <= 1e-5, rec._handle.plan_info()
 
 
-@pytest.mark.parametrize("shape", [(24, 32, 3), (13, 40, 1), (5, 128, 3), (2, 36, 1), (33, 50, 1)])
+@pytest.mark.parametrize("shape", [(24, 32, 3), (13, 40, 1), (5, 128, 3), (2, 36, 1), (33, 50, 1), (3, 640, 1), (2, 1014, 3)])
 def test_tv_half_inside_forward_rows(backend, monkeypatch, shape):
     """Small frames run an ADMM iteration in three launches: the forward row blocks of r_sp form their two rows
     themselves (k_rfwd_arrays_x<.., K1>, k1_two_rows: the tiled kernel's TV / W statements with the stencil's circular
-    neighbours read from global memory) and the tiled kernel is not launched (default wherever a paired row is one quad
-    per lane; option k1_rows=0: the tiled kernel).  Against the float64 oracle with the TV term active, across two calls
+    neighbours read from global memory) and the tiled kernel is not launched (default wherever a paired row is one or two
+    quads per lane -- the last two shapes: 1280 points on 192 lanes, 2048 on 256; option k1_rows=0: the tiled kernel).  Against the float64 oracle with the TV term active, across two calls
     (plain duals at the call boundary, half-applied ones inside), with the duals stored plain throughout (k1_half=0: the
     V_old path), and against the four-launch plan of the same engine; frames of 2 ... 33 rows, an odd number of padded
     rows included."""
