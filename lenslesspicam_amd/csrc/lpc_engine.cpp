@@ -298,8 +298,16 @@ static void choose_plan(Engine* e, bool allow_static) {
   // half-length transform on its own plan beats them (same-box A/B, profiles/r03_notes.md: FISTA 270x480x3 3.85 -> 3.35 ms
   // per 60 iterations, 380x507x3 4.40 -> 3.75 ms).  ADMM keeps the size rule with either kind of plan (540 x 960: paired
   // 0.298 vs half 0.311 ms per 5 iterations; 768 x 1024: 0.374 vs 0.364; 3072 x 4096: paired 43.6 vs half 44.6 ms per 50).
+  // Round 6: ADMM on compile-time plans keeps PAIRED rows up to 4096 columns -- paired rows take the TV / W half of the
+  // image-domain work (two quads per lane: three launches per iteration, r_sp never stored), which half-length rows cannot
+  // (four quads per lane: slower than the tiled kernel).  Same box, paired + fused against half-length + tiled kernel
+  // (profiles/r06_notes.md): 16 x 1080p (3840 columns) 175.3 -> 170.7 ms per 20 iterations, two of its planes 54.5 -> 52.3,
+  // 1520 x 2028 x 3 (4096) 30.18 -> 29.23 ms per 40; 5000 / 5760 columns -1.3 / -0.5 %, 6000 +1.4 %, 8192 (12 MP) +3 %,
+  // 5120 = 8.8.8.2.5 +10 %: half-length rows above 4096.
   const bool half_ok = g.Wp % 2 == 0 && g.Wp >= 4;
-  const bool wide = admm ? 5 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024 : (g.Wp >= 2048 || (allow_static && g.Wp >= 128));
+  const bool admm_wide = (allow_static && g.Wp % 4 == 0 && o.k1_rows != 0) ? g.Wp > 4096
+                                                                            : 5 * LPC_ROW_SMEM_BYTES(g.Wp, 1) > 160 * 1024;
+  const bool wide = admm ? admm_wide : (g.Wp >= 2048 || (allow_static && g.Wp >= 128));
   e->rows_half = half_ok && wide;
   if (o.rows_half == 0) e->rows_half = false;
   if (o.rows_half == 1 && half_ok) e->rows_half = true;
